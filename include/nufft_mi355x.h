@@ -1,0 +1,207 @@
+/*
+ * nufft_mi355x.h — C ABI of the MI355X-native NUFFT engine (libnufft_mi355x.so).
+ *
+ * Drop-in boundary for the GPU hot path of jipolanco/NonuniformFFTs.jl
+ * (PlanNUFFT -> set_points! -> exec_type1! / exec_type2!).  The reference has no FFI: its
+ * backend "plugin API" is multiple dispatch on a KernelAbstractions backend plus the hooks of
+ * ext/NonuniformFFTsAMDGPUExt.jl.  Each entry point below names the reference generic
+ * function (file:line relative to the reference checkout) that a Julia `ccall` shim would
+ * route to it; INTEGRATION.md shows that shim.
+ *
+ * Conventions (identical to the reference):
+ *   - all data pointers are DEVICE pointers owned by the caller (ROCArray / torch tensor);
+ *   - arrays are column-major ("dimension 1 fastest"), coordinates are structure-of-arrays;
+ *   - no entry point synchronises the device: all work is enqueued on the `stream` argument
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - errors are return codes, never exceptions; nothing is launched when a check fails;
+ *   - the plan owns its scratch (oversampled grids, bin-sort buffers, rocFFT plans);
+ *   - one plan must not be used concurrently from several threads (same as the reference).
+ *
+ * No torch / Julia / C++ types appear in any signature.
+ */
+#ifndef NUFFT_MI355X_H
+#define NUFFT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUFFT_MI355X_VERSION 100 /* 0.1.0 */
+
+/* ---- return codes ------------------------------------------------------------------- */
+enum {
+    NUFFT_OK = 0,
+    NUFFT_ERR_INVALID_ARG   = 1, /* Julia ArgumentError (bad enum/eltype/null pointer)            */
+    NUFFT_ERR_SIZE_TOO_SMALL = 2, /* ArgumentError "data size is too small" src/plan.jl:545-556    */
+    NUFFT_ERR_DIM_MISMATCH  = 3, /* DimensionMismatch src/NonuniformFFTs.jl:92-114                */
+    NUFFT_ERR_LDS_TOO_SMALL = 4, /* ArgumentError of block_dims_gpu_shmem src/gpu_common.jl:55-65 */
+    NUFFT_ERR_UNSUPPORTED   = 5, /* feature outside the built menu (kernel, M, gpu_method, ...)   */
+    NUFFT_ERR_NO_POINTS     = 6, /* exec_* before set_points                                      */
+    NUFFT_ERR_ALLOC         = 7, /* hipMalloc failed                                              */
+    NUFFT_ERR_HIP           = 8, /* any other HIP runtime error                                   */
+    NUFFT_ERR_ROCFFT        = 9, /* rocFFT plan creation / execution failed                       */
+    NUFFT_ERR_NO_DEVICE     = 10 /* device entry point called on a host-only (device = -1) plan   */
+};
+
+/* ---- enums --------------------------------------------------------------------------- */
+enum { NUFFT_F32 = 0, NUFFT_F64 = 1 };                         /* real(Z) of the plan            */
+enum { NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL = 0 };             /* default_kernel(::ROCBackend)   */
+enum { NUFFT_EVAL_DIRECT = 0, NUFFT_EVAL_FAST_APPROXIMATION = 1 }; /* Kernels.EvaluationMode     */
+enum { NUFFT_METHOD_SHARED_MEMORY = 0 };                       /* gpu_method = :shared_memory    */
+enum { NUFFT_POINT_TRANSFORM_IDENTITY = 0 };                   /* point_transform = identity     */
+
+/* Stage identifiers (nufft_get_stage_times), in the order of the reference's TimerOutputs
+ * labels: src/blocking/gpu.jl:93-139, src/NonuniformFFTs.jl:157-186,246-283. */
+enum {
+    NUFFT_STAGE_SET_POINTS = 0, /* "Set points": bin-sort of the points                           */
+    NUFFT_STAGE_T1_ZERO    = 1, /* "(0) Fill with zeros"                                          */
+    NUFFT_STAGE_T1_SPREAD  = 2, /* "(1) Spreading"                                                */
+    NUFFT_STAGE_T1_FFT     = 3, /* "(2) Forward FFT"                                              */
+    NUFFT_STAGE_T1_DECONV  = 4, /* "(3) Deconvolution"                                            */
+    NUFFT_STAGE_T2_DECONV  = 5, /* "(0)+(1) zero-pad + deconvolution" (fused)                     */
+    NUFFT_STAGE_T2_FFT     = 6, /* "(2) Backward FFT"                                             */
+    NUFFT_STAGE_T2_INTERP  = 7, /* "(3) Interpolation"                                            */
+    NUFFT_NUM_STAGES       = 8
+};
+
+typedef struct nufft_plan nufft_plan; /* opaque */
+
+/* Plan parameters: the keyword arguments of PlanNUFFT (src/plan.jl:467-482,568-599) that can
+ * cross a C ABI, plus the MI355X tile knobs that replace `block_size` / `gpu_batch_size`.
+ * Zero-initialise, then set what you need (0 means "reference default" for every field). */
+typedef struct nufft_params {
+    int32_t dtype;           /* NUFFT_F32 | NUFFT_F64  = real(Z)                                  */
+    int32_t is_complex;      /* Z <: Complex (non-uniform values are complex)                     */
+    int32_t ndim;            /* 1..3                                                               */
+    int64_t N[3];            /* uniform grid size Ns (dimension 1 first)                           */
+    int32_t half_support;    /* m = HalfSupport(M); 0 -> 4 (src/plan.jl:583)                       */
+    double  sigma;           /* oversampling factor; 0 -> 2.0 (src/plan.jl:573)                    */
+    int32_t kernel;          /* NUFFT_KERNEL_*                                                     */
+    int32_t evalmode;        /* NUFFT_EVAL_*; the ROC default is Direct (ext/..AMDGPUExt.jl:56)    */
+    int32_t ntransforms;     /* ntransforms = Val(C); 0 -> 1                                       */
+    int32_t fftshift;        /* fftshift = true/false (src/plan.jl:472)                            */
+    int32_t point_transform; /* NUFFT_POINT_TRANSFORM_*                                            */
+    int32_t gpu_method;      /* NUFFT_METHOD_*                                                     */
+    int32_t device;          /* HIP device ordinal; -1 = host-only plan (parameter math only)      */
+    /* --- MI355X tuning knobs (0 = automatic) --- */
+    int32_t tile_dims[3];    /* LDS tile interior n_d (replaces block_dims_gpu_shmem's cube)       */
+    int32_t lds_budget_bytes;/* LDS bytes the tile search may use (<= 163840 on gfx950)            */
+    int32_t spread_threads;  /* workgroup size of the spreading kernel (multiple of 64)            */
+    int32_t interp_threads;  /* workgroup size of the interpolation kernel                         */
+    int32_t reserved[8];
+} nufft_params;
+
+/* What show(::PlanNUFFT) prints (src/plan.jl:362-392) plus sizes a caller needs. */
+typedef struct nufft_info {
+    int32_t dtype, is_complex, ndim, half_support, ntransforms, evalmode, fftshift, device;
+    int64_t N[3];            /* Ns                                                                 */
+    int64_t N_over[3];       /* oversampled grid dims  (src/plan.jl:485-498)                       */
+    int64_t N_out[3];        /* size(p): dims of the uniform arrays (src/plan.jl:426)              */
+    double  sigma;           /* actual sigma = max(N_over / N) (src/plan.jl:500)                   */
+    double  beta[3];         /* kernel shape parameter per dimension                               */
+    int32_t tile_dims[3];    /* LDS tile interior                                                  */
+    int32_t tile_padded[3];  /* interior + 2M - 1                                                  */
+    int32_t tile_row_stride; /* LDS row stride in real elements (bank-conflict padding)            */
+    int32_t ntiles[3];       /* tiles per dimension = cld(N_over, tile_dims)                       */
+    int32_t spread_threads, interp_threads;
+    int64_t lds_bytes_spread, lds_bytes_interp;
+    int64_t workspace_bytes; /* device bytes owned by the plan right now                           */
+    int64_t num_points;      /* Np of the last set_points                                          */
+    int32_t npoly;           /* M + 4 polynomial coefficients per sub-interval                     */
+    int32_t reserved[7];
+} nufft_info;
+
+/* ---- plan lifetime -------------------------------------------------------------------- */
+
+/* PlanNUFFT(Z, Ns; m, σ, kernel, ntransforms, backend = ROCBackend(), kernel_evalmode, fftshift,
+ * gpu_method = :shared_memory) -> _PlanNUFFT, src/plan.jl:467-541; BlockDataGPU src/blocking/gpu.jl:41-69;
+ * init_plan_data (grids + FFT plans) src/plan.jl:37-60. */
+int nufft_plan_create_ex(nufft_plan** out, const nufft_params* params);
+
+/* Flat-argument form of the same constructor (what SURVEY.md §8(b) lists). */
+int nufft_plan_create(nufft_plan** out, int dtype, int is_complex, int ndim, const int64_t* N,
+                      int half_support, double sigma, int kernel, int evalmode, int ntransforms,
+                      int fftshift, int point_transform, int device);
+
+/* Julia finalizer of the plan. */
+int nufft_plan_destroy(nufft_plan* plan);
+
+/* size(p), ndims(p), ntransforms(p), show(p): src/plan.jl:360-435. */
+int nufft_plan_info(const nufft_plan* plan, nufft_info* out);
+
+/* Plan-time host arrays, for inspection and tests:
+ *   phi_hat : Kernels.fourier_coefficients(g), src/Kernels/Kernels.jl:84 (length N_out[dim])
+ *   poly    : piecewise-polynomial coefficients cs[k][j], k < npoly, j < 2M
+ *             (src/Kernels/piecewise_polynomial.jl:50-74), row-major [npoly][2M]
+ *   index_map : non_oversampled_indices!, src/NonuniformFFTs.jl:318-348, 0-based */
+int nufft_plan_get_phi_hat(const nufft_plan* plan, int dim, double* out, int64_t capacity);
+int nufft_plan_get_poly_coefs(const nufft_plan* plan, int dim, double* out, int64_t capacity);
+int nufft_plan_get_index_map(const nufft_plan* plan, int dim, int64_t* out, int64_t capacity);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+
+/* set_points!(p, (xs, ys, zs)) -> set_points_impl!(::GPU, ...), src/set_points.jl:33-52,
+ * src/blocking/gpu.jl:73-142.  coords[d] = device vector of Np reals of the plan's precision.
+ * The coordinates are folded to [0, 2π) and bin-sorted by LDS tile into plan-owned storage; the
+ * caller's arrays are only read (and, unlike the reference, need not stay alive afterwards). */
+int nufft_set_points(nufft_plan* plan, int64_t num_points, const void* const* coords, void* stream);
+
+/* exec_type1!(ûs_k, p, vp), src/NonuniformFFTs.jl:148-195.
+ * values_in[c]: device vector Z[Np]; uhat_out[c]: device array complex(T)[N_out...]. */
+int nufft_exec_type1(nufft_plan* plan, void* const* uhat_out, const void* const* values_in, void* stream);
+
+/* exec_type2!(vp, p, ûs_k), src/NonuniformFFTs.jl:237-291. */
+int nufft_exec_type2(nufft_plan* plan, void* const* values_out, const void* const* uhat_in, void* stream);
+
+/* ---- stage-level entry points (the backend-dispatched generic functions) -- */
+
+/* fill_with_zeros_kernel!(us), src/NonuniformFFTs.jl:116-122,161-167. */
+int nufft_fill_zeros(nufft_plan* plan, void* stream);
+/* spread_from_points!(::GPU, ...), src/spreading/gpu.jl:134-214 (adds onto the plan's grids). */
+int nufft_spread(nufft_plan* plan, const void* const* values_in, void* stream);
+/* _type1_fft!, src/NonuniformFFTs.jl:197-211. */
+int nufft_fft_forward(nufft_plan* plan, void* stream);
+/* copy_deconvolve_to_non_oversampled!(::GPU, ...), src/NonuniformFFTs.jl:387-414. */
+int nufft_deconvolve_truncate(nufft_plan* plan, void* const* uhat_out, void* stream);
+/* fill_with_zeros + copy_deconvolve_to_oversampled!(::GPU, ...), src/NonuniformFFTs.jl:260-272,453-480. */
+int nufft_deconvolve_pad(nufft_plan* plan, const void* const* uhat_in, void* stream);
+/* _type2_fft! / _fft_c2r!, src/NonuniformFFTs.jl:293-314. */
+int nufft_fft_backward(nufft_plan* plan, void* stream);
+/* interpolate!(::GPU, ...), src/interpolation/gpu.jl:40-118. */
+int nufft_interpolate(nufft_plan* plan, void* const* values_out, void* stream);
+
+/* Device pointer of plan-owned oversampled arrays (p.data.us / p.data.ûs, src/plan.jl:3-29):
+ * which = 0 -> us[c] (real T[N_over] or complex), which = 1 -> ûs[c] (real plans only). */
+int nufft_grid_ptr(const nufft_plan* plan, int which, int component, void** out_ptr, int64_t* out_bytes);
+
+/* Device-to-device copy of one plan-owned oversampled array (same `which` as nufft_grid_ptr) into
+ * a caller buffer of at least `capacity_bytes`; enqueued on `stream`. */
+int nufft_copy_grid(const nufft_plan* plan, int which, int component, void* dst, int64_t capacity_bytes, void* stream);
+
+/* Sorted-point inspection: copies the bin-sort permutation (sorted position -> original index,
+ * 0-based; BlockDataGPU.pointperm, src/blocking/gpu.jl:15) and the per-tile offsets
+ * (cumulative_npoints_per_block, :13) to HOST buffers.  Synchronises `stream`. */
+int nufft_get_sort_result(nufft_plan* plan, int32_t* perm_host, int64_t perm_capacity,
+                          uint32_t* tile_offsets_host, int64_t offsets_capacity, void* stream);
+
+/* ---- timing (TimerOutputs analogue, src/plan.jl:397-417) -------------------------------- */
+
+/* enable != 0: bracket every stage with hipEvents on the caller's stream. */
+int nufft_set_timing(nufft_plan* plan, int enable);
+/* Milliseconds of the most recent run of every stage (NUFFT_NUM_STAGES floats; -1 = never run).
+ * Synchronises on the recorded events. */
+int nufft_get_stage_times(nufft_plan* plan, float* ms_out);
+
+/* ---- misc ----------------------------------------------------------------------------- */
+const char* nufft_strerror(int code);
+/* Last error message of the calling thread (more detail than nufft_strerror). */
+const char* nufft_last_error_message(void);
+int nufft_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUFFT_MI355X_H */

@@ -1,0 +1,148 @@
+// set_points!: bin-sort of the non-uniform points by LDS tile.
+//
+// Replaces set_points_impl!(::GPU, ...) of the reference (src/blocking/gpu.jl:73-142):
+//   K2 assign_blocks_kernel!  (:162-180)  -> bin_count_kernel   (histogram + rank)
+//   K3 AK.accumulate!         (:112-115)  -> hipcub exclusive scan over ntiles + 1 counters
+//   K4 sortperm_kernel!       (:182-198)  \
+//   K5 permute_kernel!        (:200-212)  -> bin_scatter_kernel (fused: writes one aligned record
+//                                            {r_1..r_D, original index} per point in tile order)
+// Differences by design: 32-bit counters and indices; the sorted copy stores the coordinates in
+// grid units r = (x / 2π) Ñ, computed once, so that binning, spreading and interpolation derive
+// cell and tile from the *same* number (the consistency hazard noted at src/blocking/gpu.jl:151-155).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace nufft {
+
+template <typename T, int D>
+struct BinArgs {
+    const T* x[3];
+    int64_t np;
+    Geom g;
+};
+
+template <typename T, int D>
+__device__ __forceinline__ uint32_t tile_of_point(const BinArgs<T, D>& a, int64_t p, T (&r)[D]) {
+    uint32_t tile = 0, mul = 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const T xf = fold_to_unit_cell(a.x[d][p]);
+        r[d] = to_grid_units(xf, a.g.Nover[d]);
+        const int i = cell_of(r[d], a.g.Nover[d]);
+        const int t = i / a.g.n[d];                       // block_index, src/blocking/gpu.jl:145-160
+        tile += mul * (uint32_t)t;
+        mul *= (uint32_t)a.g.nt[d];
+    }
+    return tile;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void bin_count_kernel(BinArgs<T, D> a, uint32_t* __restrict__ counts,
+                                                       uint2* __restrict__ binrank) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.np; p += stride) {
+        T r[D];
+        const uint32_t tile = tile_of_point<T, D>(a, p, r);
+        const uint32_t rank = atomicAdd(&counts[tile], 1u);
+        binrank[p] = make_uint2(tile, rank);
+    }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs<T, D> a, const uint32_t* __restrict__ offsets,
+                                                         const uint2* __restrict__ binrank,
+                                                         PointRec<T, D>* __restrict__ sorted) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.np; p += stride) {
+        const uint2 br = binrank[p];
+        PointRec<T, D> rec;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const T xf = fold_to_unit_cell(a.x[d][p]);
+            rec.r[d] = to_grid_units(xf, a.g.Nover[d]);
+        }
+        rec.idx = (int32_t)p;
+        sorted[offsets[br.x] + br.y] = rec;
+    }
+}
+
+template <typename T, int D>
+static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
+    BinArgs<T, D> a;
+    for (int d = 0; d < 3; ++d) a.x[d] = d < D ? static_cast<const T*>(s.coords[d]) : nullptr;
+    a.np = s.np;
+    a.g = s.g;
+    hipError_t e = hipMemsetAsync(s.counts, 0, sizeof(uint32_t) * (size_t)(s.g.ntiles + 1), stream);
+    if (e != hipSuccess) return e;
+    if (s.np > 0) {
+        const int threads = 256;
+        int64_t blocks = (s.np + threads - 1) / threads;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL((bin_count_kernel<T, D>), dim3((unsigned)blocks), dim3(threads), 0, stream, a, s.counts,
+                           static_cast<uint2*>(s.binrank));
+    }
+    size_t tmp = s.scan_tmp_bytes;
+    e = hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.ntiles + 1, stream);
+    if (e != hipSuccess) return e;
+    if (s.np > 0) {
+        const int threads = 256;
+        int64_t blocks = (s.np + threads - 1) / threads;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL((bin_scatter_kernel<T, D>), dim3((unsigned)blocks), dim3(threads), 0, stream, a, s.offsets,
+                           static_cast<const uint2*>(s.binrank), static_cast<PointRec<T, D>*>(s.sorted));
+    }
+    return hipGetLastError();
+}
+
+size_t binsort_scan_tmp_bytes(int ntiles) {
+    size_t bytes = 0;
+    uint32_t* p = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, p, p, ntiles + 1, (hipStream_t)0);
+    return bytes < 16 ? 16 : bytes;
+}
+
+size_t point_record_bytes(int dtype, int D) {
+    if (dtype == NUFFT_F32) return D == 1 ? sizeof(PointRec<float, 1>) : D == 2 ? sizeof(PointRec<float, 2>) : sizeof(PointRec<float, 3>);
+    return D == 1 ? sizeof(PointRec<double, 1>) : D == 2 ? sizeof(PointRec<double, 2>) : sizeof(PointRec<double, 3>);
+}
+
+hipError_t launch_binsort(const SortArgs& s, hipStream_t stream) {
+    if (s.dtype == NUFFT_F32) {
+        switch (s.D) {
+            case 1: return run_binsort<float, 1>(s, stream);
+            case 2: return run_binsort<float, 2>(s, stream);
+            default: return run_binsort<float, 3>(s, stream);
+        }
+    }
+    switch (s.D) {
+        case 1: return run_binsort<double, 1>(s, stream);
+        case 2: return run_binsort<double, 2>(s, stream);
+        default: return run_binsort<double, 3>(s, stream);
+    }
+}
+
+// Extracts the permutation (sorted position -> original index) from the sorted records.
+template <int REC_BYTES>
+__global__ void extract_perm_kernel(const unsigned char* __restrict__ recs, int idx_off, int64_t np, int32_t* __restrict__ perm) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < np) perm[p] = *reinterpret_cast<const int32_t*>(recs + p * REC_BYTES + idx_off);
+}
+
+hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np, int32_t* perm_dev, hipStream_t stream) {
+    if (np <= 0) return hipSuccess;
+    const size_t rb = point_record_bytes(dtype, D);
+    const int idx_off = D * (dtype == NUFFT_F32 ? 4 : 8);
+    const unsigned blocks = (unsigned)((np + 255) / 256);
+    const unsigned char* r = static_cast<const unsigned char*>(sorted);
+    switch (rb) {
+        case 8: hipLaunchKernelGGL(extract_perm_kernel<8>, dim3(blocks), dim3(256), 0, stream, r, idx_off, np, perm_dev); break;
+        case 16: hipLaunchKernelGGL(extract_perm_kernel<16>, dim3(blocks), dim3(256), 0, stream, r, idx_off, np, perm_dev); break;
+        default: hipLaunchKernelGGL(extract_perm_kernel<32>, dim3(blocks), dim3(256), 0, stream, r, idx_off, np, perm_dev); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace nufft

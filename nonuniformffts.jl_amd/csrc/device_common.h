@@ -1,0 +1,208 @@
+// Device-side helpers shared by the HIP kernels (gfx950 / CDNA4, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace nufft {
+
+constexpr int kWave = 64;
+constexpr int kCH = 16;                 // points staged per wave per chunk (== kChunk on the host)
+constexpr int kParts = kWave / kCH;     // lanes cooperating on one staged point
+constexpr int kMaxCompPerLaunch = 8;    // components (ntransforms) handled by one launch
+
+template <typename T> struct TwoPi;
+template <> struct TwoPi<float>  { static constexpr float  value = 6.28318530717958647692f; };
+template <> struct TwoPi<double> { static constexpr double value = 6.28318530717958647692; };
+
+// One bin-sorted point: coordinates in grid units r_d = (x_d / 2π) Ñ_d ∈ [0, Ñ_d] of the folded
+// point, plus its index in the caller's arrays.  Power-of-two sized so that the scatter pass of
+// the bin sort writes one aligned record per point.
+template <typename T, int D>
+struct alignas((D * sizeof(T) + 4 > 8) ? 16 : 8) PointRec {
+    T r[D];
+    int32_t idx;
+};
+static_assert(sizeof(PointRec<double, 3>) == 32, "record layout");
+static_assert(sizeof(PointRec<float, 3>) == 16, "record layout");
+static_assert(sizeof(PointRec<double, 1>) == 16, "record layout");
+static_assert(sizeof(PointRec<float, 1>) == 8, "record layout");
+
+// Geometry passed by value to every kernel.
+struct Geom {
+    int Nover[3];     // oversampled grid
+    int n[3];         // tile interior
+    int P[3];         // padded tile = n + 2M - 1
+    int nt[3];        // tiles per dimension
+    int row_stride;   // LDS row stride in reals (>= ncomp * P[0])
+    int plane_stride; // row_stride * P[1]
+    int tile_elems;   // plane_stride * P[2]
+    int ntiles;       // nt[0] * nt[1] * nt[2]
+};
+
+// to_unit_cell_gpu, reference src/blocking/blocking.jl:26-33.
+template <typename T>
+__device__ __forceinline__ T fold_to_unit_cell(T x) {
+    const T L = TwoPi<T>::value;
+    T r = fmod(x, L);
+    r = (r == T(0)) ? T(0) : r;      // -0.0 -> +0.0
+    return (r < T(0)) ? (L + r) : r;
+}
+
+// point_to_cell, reference src/Kernels/Kernels.jl:121-126: r = (x / L) * N in this order.
+template <typename T>
+__device__ __forceinline__ T to_grid_units(T x_folded, int N) {
+    return (x_folded / TwoPi<T>::value) * T(N);
+}
+
+// Cell index (0-based) from grid units; clamps the (measure-zero) r == N case produced by
+// rounding of L + r in the fold, which the reference leaves out of bounds.
+template <typename T>
+__device__ __forceinline__ int cell_of(T r, int N) {
+    int i = (int)r;
+    return i >= N ? N - 1 : i;
+}
+
+// XCD-aware tile order: blocks b and b + 8 share an XCD (and its L2), so give every XCD a
+// contiguous chunk of the tile list.  Bijective for any number of tiles.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = b & 7, k = b >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+// Order LDS traffic of one wave without a workgroup barrier: LDS instructions of a wave complete
+// in issue order; this only stops the compiler from moving accesses across the point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr __host__ __device__ int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+constexpr __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// LDS layout shared by host (size computation) and kernels.
+//   [tile | polynomial coefficients | per-wave staging]
+struct LdsLayout {
+    int tile_bytes, coef_bytes, stage_bytes_per_wave, total;
+};
+
+constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int real_bytes, int D, int M,
+                                                   int ncomp, int nwaves, bool staging_results) {
+    LdsLayout l{};
+    l.tile_bytes = round_up(tile_elems * real_bytes, 16);
+    l.coef_bytes = round_up(D * (M + 4) * 2 * M * real_bytes, 16);
+    // per staged point: D*2M window values, ncomp value components (or results), D local starts
+    int per_point = (D * 2 * M + ncomp) * real_bytes + D * 4;
+    (void)staging_results;
+    l.stage_bytes_per_wave = round_up(kCH * per_point, 16);
+    l.total = l.tile_bytes + l.coef_bytes + nwaves * l.stage_bytes_per_wave;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window evaluation (backwards Kaiser-Bessel)
+// ---------------------------------------------------------------------------------------------
+
+// Direct: reference src/Kernels/kaiser_bessel_backwards.jl:158-175.
+// j is 0-based (reference j = 1..2M), X ∈ [0, 1].
+template <typename T, int M>
+__device__ __forceinline__ T bkb_direct(T X, int j, T beta, T beta_over_pi) {
+    const T y = (T(M - 1 - j) + X) / T(M);
+    const T z = T(1) - y * y;
+    const T s = sqrt(z > T(0) ? z : T(0));
+    const T bs = beta * s;
+    const T ratio = (s == T(0)) ? T(1) : sinh(bs) / bs;
+    return ratio * beta_over_pi;
+}
+
+// FastApproximation: Horner evaluation of the degree-(M+3) piecewise polynomial,
+// reference src/Kernels/piecewise_polynomial.jl:76-92.  cs points to [npoly][2M] for one dimension.
+template <typename T, int M>
+__device__ __forceinline__ T bkb_poly(T X, int j, const T* cs) {
+    constexpr int NP = M + 4;
+    constexpr int L = 2 * M;
+    const T x = T(2) * X - T(1);
+    T y = cs[(NP - 1) * L + j];
+#pragma unroll
+    for (int k = NP - 2; k >= 0; --k) y = fma(x, y, cs[k * L + j]);
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-level sum over lanes whose index differs in the bits of MASKS (butterfly with DPP and
+// gfx950 permlane swaps; no LDS traffic).  Every participating lane ends with the full sum.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    const long long r = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(double, r);
+}
+
+__device__ __forceinline__ float swap16_add(float x) {
+    const int v = __builtin_bit_cast(int, x);
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float swap32_add(float x) {
+    const int v = __builtin_bit_cast(int, x);
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ double swap16_add(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const long long a0 = ((long long)(int)rh[0] << 32) | (unsigned int)rl[0];
+    const long long a1 = ((long long)(int)rh[1] << 32) | (unsigned int)rl[1];
+    return __builtin_bit_cast(double, a0) + __builtin_bit_cast(double, a1);
+}
+__device__ __forceinline__ double swap32_add(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const long long a0 = ((long long)(int)rh[0] << 32) | (unsigned int)rl[0];
+    const long long a1 = ((long long)(int)rh[1] << 32) | (unsigned int)rl[1];
+    return __builtin_bit_cast(double, a0) + __builtin_bit_cast(double, a1);
+}
+
+// Sum over the lanes of a group of G consecutive lanes (G a power of two ≤ 64).  With SKIP1 the
+// lanes of even and odd index are summed separately (interleaved re/im lanes): every exchange
+// then moves data by an even lane distance.  DPP controls: quad_perm [1,0,3,2] = 0xB1 (xor 1),
+// [2,3,0,1] = 0x4E (xor 2), [3,2,1,0] = 0x1B, row_half_mirror = 0x141, row_ror:4 / :8 =
+// 0x124 / 0x128 (rotations inside a row of 16; two of them visit all four quads).
+template <typename T, int G, bool SKIP1>
+__device__ __forceinline__ T group_sum(T x) {
+    if constexpr (G >= 2 && !SKIP1) x += dpp_move<0xB1>(x);
+    if constexpr (G >= 4) x += dpp_move<0x4E>(x);
+    if constexpr (G == 8) {
+        if constexpr (SKIP1) x += dpp_move<0x141>(dpp_move<0x1B>(x));   // exact xor 4
+        else x += dpp_move<0x141>(x);
+    }
+    if constexpr (G >= 16) {
+        x += dpp_move<0x124>(x);
+        x += dpp_move<0x128>(x);
+    }
+    if constexpr (G >= 32) x = swap16_add(x);   // other row of the pair
+    if constexpr (G >= 64) x = swap32_add(x);   // other half-wave
+    return x;
+}
+
+}  // namespace nufft

@@ -1,0 +1,67 @@
+// Host-callable launchers of the HIP kernels (one translation unit per kernel family).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "device_common.h"
+#include "nufft_mi355x.h"
+
+namespace nufft {
+
+// ---- bin sort (binsort.hip) ------------------------------------------------------------------
+struct SortArgs {
+    int dtype, D;
+    int64_t np;
+    const void* coords[3];
+    Geom g;
+    uint32_t* counts;      // [ntiles + 1]
+    uint32_t* offsets;     // [ntiles + 1]
+    void* binrank;         // uint2[np]
+    void* sorted;          // PointRec<T, D>[np]
+    void* scan_tmp;
+    size_t scan_tmp_bytes;
+};
+size_t binsort_scan_tmp_bytes(int ntiles);
+size_t point_record_bytes(int dtype, int D);
+hipError_t launch_binsort(const SortArgs& s, hipStream_t stream);
+hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np, int32_t* perm_dev, hipStream_t stream);
+
+// ---- spreading / interpolation (spread_*.hip, interp_*.hip) -------------------------------------
+struct TileKernelArgs {
+    int dtype, is_complex, D, M, evalmode, C;
+    Geom g;
+    const void* sorted;        // PointRec<T, D>[np]
+    const uint32_t* offsets;   // [ntiles + 1]
+    const void* coefs;         // T[D][npoly][2M]
+    double beta[3];
+    void* grid;                // C grids, contiguous, Z[Nover...]
+    int64_t grid_stride;       // elements of Z between components
+    const void* const* values_in;   // spread: C device vectors Z[np]
+    void* const* values_out;        // interp: C device vectors Z[np]
+    double prefactor;          // interp: prod(dx_d)
+    int threads;
+    int lds_bytes;
+};
+hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
+hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);
+// Sets the dynamic-LDS attribute of every instantiation that may be launched for this configuration.
+hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes);
+hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes);
+
+// ---- deconvolution (deconv.hip) ------------------------------------------------------------------
+struct DeconvArgs {
+    int dtype, D, C;
+    int nout[3];               // size(p)
+    int nspec[3];              // dims of the oversampled spectrum
+    const void* phihat[3];     // T[nout[d]]
+    const int32_t* index_map[3];   // out index -> oversampled index
+    const int32_t* inv_map[3];     // oversampled index -> out index or -1
+    void* spec;                // C oversampled spectra (complex<T>), contiguous
+    int64_t spec_stride;       // complex elements between components
+    double normfactor;         // prod(2π / Ñ_d) (type 1) or 1 (type 2)
+};
+hipError_t launch_deconv_truncate(const DeconvArgs& a, void* const* uhat_out, hipStream_t stream);
+hipError_t launch_deconv_pad(const DeconvArgs& a, const void* const* uhat_in, hipStream_t stream);
+
+}  // namespace nufft

@@ -1,0 +1,123 @@
+// Internal declarations shared by the host side (plan.cpp, plan_math.cpp) and the HIP kernel
+// translation units of libnufft_mi355x.so.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "nufft_mi355x.h"
+
+struct rocfft_plan_t;
+struct rocfft_execution_info_t;
+
+namespace nufft {
+
+constexpr int kMaxDim = 3;
+constexpr int kMinM = 2;
+constexpr int kMaxM = 10;
+constexpr int kLdsLimit = 163840;      // gfx950: 160 KiB per workgroup
+constexpr int kChunk = 16;             // points staged per wave and chunk (see spread.hip)
+
+void set_error(const std::string& msg);
+
+// -------------------------------------------------------------------------------------------
+// Host parameter math (plan_math.cpp) — restates src/plan.jl:485-505, Kernels/*.jl
+// -------------------------------------------------------------------------------------------
+int64_t nextprod235(int64_t n);
+int64_t oversampled_size(int64_t N, double sigma, bool real_first_dim);
+double bkb_beta(int M, double sigma_d);
+double bkb_function(double y, double beta);
+double bessel_i0(double x);
+// cs[k * 2M + j]: coefficient of x^k on sub-interval j (j = 0 is the rightmost one).
+void bkb_poly_coefficients(int M, double beta, std::vector<double>& cs);
+// wavenumbers of the non-oversampled grid: rfftfreq for (real, dim 0), fftfreq otherwise.
+void wavenumbers(int64_t N, bool r2c, std::vector<double>& ks);
+void fourier_coefficients(const std::vector<double>& ks, int M, int64_t Nover, double beta,
+                          std::vector<double>& phihat);
+void non_oversampled_indices(const std::vector<double>& ks, int64_t n_axis, bool fftshift,
+                             std::vector<int64_t>& indmap);
+
+// Geometry of the LDS tiling (all values per dimension; unused dimensions are 1 / 0).
+struct TileGeom {
+    int n[kMaxDim] = {1, 1, 1};        // interior
+    int P[kMaxDim] = {1, 1, 1};        // padded = n + 2M - 1
+    int nt[kMaxDim] = {1, 1, 1};       // number of tiles
+    int row_stride = 0;                // LDS row stride in real elements
+    int64_t tile_elems = 0;            // row_stride * P[1] * P[2] (real elements)
+    int64_t ntiles_total = 1;
+};
+
+// Chooses the tile interior that minimises the halo amplification under the LDS budget.
+// Returns false if not even the smallest tile fits (-> NUFFT_ERR_LDS_TOO_SMALL).
+bool choose_tile(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
+                 int lds_budget_bytes, int staging_bytes, const int* forced, TileGeom& g);
+int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes);
+
+}  // namespace nufft
+
+// -------------------------------------------------------------------------------------------
+// The plan
+// -------------------------------------------------------------------------------------------
+struct nufft_plan {
+    // parameters
+    int dtype = NUFFT_F64;
+    bool is_complex = false;
+    int D = 1;
+    int64_t N[3] = {1, 1, 1};
+    int M = 4;
+    double sigma_req = 2.0;
+    int evalmode = NUFFT_EVAL_DIRECT;
+    int C = 1;
+    bool fftshift = false;
+    int device = -1;
+    int spread_threads = 256;
+    int interp_threads = 256;
+
+    // derived host data
+    int64_t Nover[3] = {1, 1, 1};
+    int64_t Nout[3] = {1, 1, 1};       // size(p)
+    int64_t Nspec[3] = {1, 1, 1};      // dims of the oversampled spectrum (r2c halves dim 0)
+    double sigma = 2.0;
+    double beta[3] = {0, 0, 0};
+    int npoly = 8;
+    std::vector<double> coefs[3];      // [npoly][2M]
+    std::vector<double> phihat[3];
+    std::vector<int64_t> index_map[3];
+    nufft::TileGeom tile;
+    int64_t lds_spread = 0, lds_interp = 0;
+
+    // device data
+    void* d_coefs = nullptr;           // T[D][npoly][2M]
+    void* d_phihat[3] = {nullptr, nullptr, nullptr};      // T[Nout[d]]
+    int32_t* d_index_map[3] = {nullptr, nullptr, nullptr};// out index -> oversampled index
+    int32_t* d_inv_map[3] = {nullptr, nullptr, nullptr};  // oversampled index -> out index or -1
+    void* d_us = nullptr;              // C grids, contiguous; T[Nover] (real) or complex
+    void* d_uhat = nullptr;            // C spectra complex<T>[Nspec] (real plans only)
+    int64_t grid_elems = 0;            // elements (of Z) per component in d_us
+    int64_t spec_elems = 0;            // complex elements per component in d_uhat (or d_us)
+
+    // bin sort
+    int64_t Np = -1;
+    int64_t Np_capacity = 0;
+    uint32_t* d_counts = nullptr;      // [ntiles + 1]  histogram
+    uint32_t* d_offsets = nullptr;     // [ntiles + 1]  exclusive scan
+    void* d_binrank = nullptr;         // uint2[Np]: (tile, rank)
+    void* d_sorted = nullptr;          // PointRec<T, D>[Np]
+    void* d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    int64_t workspace_bytes = 0;
+
+    // rocFFT
+    rocfft_plan_t* fft_fw = nullptr;
+    rocfft_plan_t* fft_bw = nullptr;
+    rocfft_execution_info_t* fft_info = nullptr;
+    void* d_fft_work = nullptr;
+    size_t fft_work_bytes = 0;
+
+    // timing
+    bool timing = false;
+    void* ev_begin[NUFFT_NUM_STAGES] = {};
+    void* ev_end[NUFFT_NUM_STAGES] = {};
+    bool ev_valid[NUFFT_NUM_STAGES] = {};
+};

@@ -1,0 +1,765 @@
+// C ABI of libnufft_mi355x.so: plan lifetime, set_points, exec_type1 / exec_type2 and the
+// stage-level entry points.  See include/nufft_mi355x.h for the reference functions each entry
+// point replaces.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "kernels.h"
+#include "nufft_internal.h"
+
+namespace nufft {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+static int fail(int code, const std::string& msg) {
+    set_error(msg);
+    return code;
+}
+
+#define NUFFT_HIP(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return nufft::fail(e__ == hipErrorOutOfMemory ? NUFFT_ERR_ALLOC : NUFFT_ERR_HIP,   \
+                               std::string(#expr) + ": " + hipGetErrorString(e__));            \
+    } while (0)
+
+#define NUFFT_ROCFFT(expr)                                                                     \
+    do {                                                                                       \
+        rocfft_status s__ = (expr);                                                            \
+        if (s__ != rocfft_status_success)                                                      \
+            return nufft::fail(NUFFT_ERR_ROCFFT, std::string(#expr) + ": rocfft status " + std::to_string((int)s__)); \
+    } while (0)
+
+static std::once_flag g_rocfft_once;
+
+static size_t real_bytes(const nufft_plan* p) { return p->dtype == NUFFT_F32 ? 4 : 8; }
+static size_t value_bytes(const nufft_plan* p) { return real_bytes(p) * (p->is_complex ? 2 : 1); }
+
+static Geom make_geom(const nufft_plan* p) {
+    Geom g{};
+    for (int d = 0; d < 3; ++d) {
+        g.Nover[d] = (int)p->Nover[d];
+        g.n[d] = p->tile.n[d];
+        g.P[d] = p->tile.P[d];
+        g.nt[d] = p->tile.nt[d];
+    }
+    g.row_stride = p->tile.row_stride;
+    g.plane_stride = p->tile.row_stride * p->tile.P[1];
+    g.tile_elems = (int)p->tile.tile_elems;
+    g.ntiles = (int)p->tile.ntiles_total;
+    return g;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    explicit DeviceGuard(int dev) {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            active = hipSetDevice(dev) == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (active) (void)hipSetDevice(prev);
+    }
+};
+
+static int dev_alloc(nufft_plan* p, void** ptr, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) {
+        *ptr = nullptr;
+        return fail(NUFFT_ERR_ALLOC, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    }
+    p->workspace_bytes += (int64_t)bytes;
+    return NUFFT_OK;
+}
+
+template <typename T>
+static int upload(nufft_plan* p, void** dst, const std::vector<double>& src) {
+    std::vector<T> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = (T)src[i];
+    int rc = dev_alloc(p, dst, tmp.size() * sizeof(T));
+    if (rc) return rc;
+    NUFFT_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return NUFFT_OK;
+}
+
+static int upload_i32(nufft_plan* p, int32_t** dst, const std::vector<int32_t>& src) {
+    int rc = dev_alloc(p, reinterpret_cast<void**>(dst), src.size() * sizeof(int32_t));
+    if (rc) return rc;
+    NUFFT_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return NUFFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage timing
+// ------------------------------------------------------------------------------------------
+struct StageTimer {
+    nufft_plan* p;
+    int stage;
+    hipStream_t stream;
+    StageTimer(nufft_plan* plan, int st, hipStream_t s) : p(plan), stage(st), stream(s) {
+        if (p->timing) (void)hipEventRecord(static_cast<hipEvent_t>(p->ev_begin[stage]), stream);
+    }
+    ~StageTimer() {
+        if (p->timing) {
+            (void)hipEventRecord(static_cast<hipEvent_t>(p->ev_end[stage]), stream);
+            p->ev_valid[stage] = true;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// plan construction
+// ------------------------------------------------------------------------------------------
+static int env_int(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
+
+static int build_host(nufft_plan* p, const nufft_params* in) {
+    p->dtype = in->dtype;
+    p->is_complex = in->is_complex != 0;
+    p->D = in->ndim;
+    p->M = in->half_support > 0 ? in->half_support : 4;
+    p->sigma_req = in->sigma > 0 ? in->sigma : 2.0;
+    p->evalmode = in->evalmode;
+    p->C = in->ntransforms > 0 ? in->ntransforms : 1;
+    p->fftshift = in->fftshift != 0;
+    p->device = in->device;
+
+    if (p->dtype != NUFFT_F32 && p->dtype != NUFFT_F64) return fail(NUFFT_ERR_INVALID_ARG, "dtype must be NUFFT_F32 or NUFFT_F64");
+    if (p->D < 1 || p->D > 3) return fail(NUFFT_ERR_UNSUPPORTED, "ndim must be 1, 2 or 3");
+    if (in->kernel != NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) return fail(NUFFT_ERR_UNSUPPORTED, "only BackwardsKaiserBesselKernel is built");
+    if (p->evalmode != NUFFT_EVAL_DIRECT && p->evalmode != NUFFT_EVAL_FAST_APPROXIMATION)
+        return fail(NUFFT_ERR_INVALID_ARG, "evalmode must be Direct (0) or FastApproximation (1)");
+    if (in->gpu_method != NUFFT_METHOD_SHARED_MEMORY) return fail(NUFFT_ERR_INVALID_ARG, "expected gpu_method = :shared_memory");
+    if (in->point_transform != NUFFT_POINT_TRANSFORM_IDENTITY) return fail(NUFFT_ERR_UNSUPPORTED, "only point_transform = identity is built");
+    if (p->M < kMinM || p->M > kMaxM) return fail(NUFFT_ERR_UNSUPPORTED, "half-support M must be in 2..10");
+    if (!(p->sigma_req >= 1.0)) return fail(NUFFT_ERR_INVALID_ARG, "sigma must be >= 1");
+
+    // sigma is converted to real(Z) before the size rule (src/plan.jl:573-576)
+    const double sigma_wanted = p->dtype == NUFFT_F32 ? (double)(float)p->sigma_req : p->sigma_req;
+    p->sigma = 0.0;
+    for (int d = 0; d < p->D; ++d) {
+        p->N[d] = in->N[d];
+        if (p->N[d] < 1) return fail(NUFFT_ERR_INVALID_ARG, "grid dimensions must be >= 1");
+        const bool r2c = !p->is_complex && d == 0;
+        p->Nover[d] = oversampled_size(p->N[d], sigma_wanted, r2c);
+        if (p->Nover[d] < 2 * p->M) {   // check_nufft_size, src/plan.jl:545-556
+            return fail(NUFFT_ERR_SIZE_TOO_SMALL, "data size is too small: sigma*N = " + std::to_string(p->Nover[d]) +
+                                                      " < " + std::to_string(2 * p->M) + " = 2M");
+        }
+        if (p->Nover[d] > (int64_t)1 << 30) return fail(NUFFT_ERR_UNSUPPORTED, "oversampled dimension exceeds 2^30");
+        p->sigma = std::max(p->sigma, (double)p->Nover[d] / (double)p->N[d]);
+        p->Nspec[d] = r2c ? p->Nover[d] / 2 + 1 : p->Nover[d];
+    }
+    p->npoly = p->M + 4;
+    for (int d = 0; d < p->D; ++d) {
+        const bool r2c = !p->is_complex && d == 0;
+        double sigma_d = (double)p->Nover[d] / (double)p->N[d];               // src/plan.jl:503
+        if (p->dtype == NUFFT_F32) sigma_d = (double)(float)sigma_d;
+        double beta = bkb_beta(p->M, sigma_d);
+        if (p->dtype == NUFFT_F32) beta = (double)(float)beta;
+        p->beta[d] = beta;
+        bkb_poly_coefficients(p->M, beta, p->coefs[d]);
+        std::vector<double> ks;
+        wavenumbers(p->N[d], r2c, ks);
+        p->Nout[d] = (int64_t)ks.size();
+        std::vector<double> kk = ks;
+        if (p->fftshift) {   // AbstractFFTs.fftshift(kx), src/plan.jl:509-511
+            const size_t n = ks.size(), sh = n / 2;
+            for (size_t i = 0; i < n; ++i) kk[(i + sh) % n] = ks[i];
+        }
+        fourier_coefficients(kk, p->M, p->Nover[d], beta, p->phihat[d]);
+        non_oversampled_indices(ks, p->Nspec[d], p->fftshift, p->index_map[d]);
+    }
+
+    // tile geometry
+    p->spread_threads = in->spread_threads > 0 ? in->spread_threads : env_int("NUFFT_SPREAD_THREADS", 512);
+    p->interp_threads = in->interp_threads > 0 ? in->interp_threads : env_int("NUFFT_INTERP_THREADS", 512);
+    if (p->spread_threads % 64 || p->interp_threads % 64 || p->spread_threads > 1024 || p->interp_threads > 1024)
+        return fail(NUFFT_ERR_INVALID_ARG, "workgroup sizes must be multiples of 64 and <= 1024");
+    int budget = in->lds_budget_bytes > 0 ? in->lds_budget_bytes : env_int("NUFFT_LDS_BUDGET", kLdsLimit);
+    if (budget > kLdsLimit) budget = kLdsLimit;
+    const int ncomp = p->is_complex ? 2 : 1;
+    const int rb = (int)real_bytes(p);
+    const int max_waves = std::max(p->spread_threads, p->interp_threads) / 64;
+    const LdsLayout probe = lds_layout(0, rb, p->D, p->M, ncomp, max_waves, true);
+    int forced[3] = {in->tile_dims[0], in->tile_dims[1], in->tile_dims[2]};
+    if (forced[0] <= 0) {
+        const char* e = std::getenv("NUFFT_TILE");
+        if (e && *e) {
+            int a = 0, b = 0, c = 0;
+            const int n = std::sscanf(e, "%d,%d,%d", &a, &b, &c);
+            if (n >= 1) { forced[0] = a; forced[1] = n >= 2 ? b : a; forced[2] = n >= 3 ? c : (n >= 2 ? b : a); }
+        }
+    }
+    if (!choose_tile(p->D, p->M, ncomp, rb, p->Nover, budget, probe.total, forced, p->tile)) {
+        return fail(NUFFT_ERR_LDS_TOO_SMALL,
+                    "LDS is too small for the chosen problem (element type, half-support M, dimensions): "
+                    "reduce M or the tile size");
+    }
+    p->lds_spread = lds_layout((int)p->tile.tile_elems, rb, p->D, p->M, ncomp, p->spread_threads / 64, false).total;
+    p->lds_interp = lds_layout((int)p->tile.tile_elems, rb, p->D, p->M, ncomp, p->interp_threads / 64, true).total;
+    if (p->tile.ntiles_total >= ((int64_t)1 << 31) - 2) return fail(NUFFT_ERR_UNSUPPORTED, "too many tiles");
+    return NUFFT_OK;
+}
+
+static int build_device(nufft_plan* p) {
+    int ndev = 0;
+    NUFFT_HIP(hipGetDeviceCount(&ndev));
+    if (p->device >= ndev) return fail(NUFFT_ERR_INVALID_ARG, "device ordinal out of range");
+    DeviceGuard guard(p->device);
+    std::call_once(g_rocfft_once, [] { (void)rocfft_setup(); });
+
+    int rc;
+    const int D = p->D, L = 2 * p->M;
+    // polynomial coefficients [D][npoly][2M]
+    {
+        std::vector<double> all;
+        for (int d = 0; d < D; ++d) all.insert(all.end(), p->coefs[d].begin(), p->coefs[d].end());
+        (void)L;
+        rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_coefs, all) : upload<double>(p, &p->d_coefs, all);
+        if (rc) return rc;
+    }
+    for (int d = 0; d < D; ++d) {
+        rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_phihat[d], p->phihat[d]) : upload<double>(p, &p->d_phihat[d], p->phihat[d]);
+        if (rc) return rc;
+        std::vector<int32_t> im(p->index_map[d].size());
+        std::vector<int32_t> inv((size_t)p->Nspec[d], -1);
+        for (size_t i = 0; i < im.size(); ++i) {
+            im[i] = (int32_t)p->index_map[d][i];
+            inv[(size_t)im[i]] = (int32_t)i;
+        }
+        if ((rc = upload_i32(p, &p->d_index_map[d], im))) return rc;
+        if ((rc = upload_i32(p, &p->d_inv_map[d], inv))) return rc;
+    }
+
+    // oversampled arrays (init_plan_data, src/plan.jl:37-60), components contiguous
+    p->grid_elems = 1;
+    p->spec_elems = 1;
+    for (int d = 0; d < D; ++d) {
+        p->grid_elems *= p->Nover[d];
+        p->spec_elems *= p->Nspec[d];
+    }
+    if ((rc = dev_alloc(p, &p->d_us, (size_t)p->grid_elems * value_bytes(p) * p->C))) return rc;
+    if (!p->is_complex) {
+        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->spec_elems * 2 * real_bytes(p) * p->C))) return rc;
+    }
+
+    // bin-sort scratch that does not depend on Np
+    const size_t nt1 = (size_t)p->tile.ntiles_total + 1;
+    if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_counts), nt1 * sizeof(uint32_t)))) return rc;
+    if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_offsets), nt1 * sizeof(uint32_t)))) return rc;
+    p->scan_tmp_bytes = binsort_scan_tmp_bytes((int)p->tile.ntiles_total);
+    if ((rc = dev_alloc(p, &p->d_scan_tmp, p->scan_tmp_bytes))) return rc;
+
+    // rocFFT plans (plan_rfft / plan_brfft / plan_fft! / plan_bfft!, src/plan.jl:45-46,57-58)
+    size_t lengths[3] = {1, 1, 1};
+    for (int d = 0; d < D; ++d) lengths[d] = (size_t)p->Nover[d];
+    const rocfft_precision prec = p->dtype == NUFFT_F32 ? rocfft_precision_single : rocfft_precision_double;
+    if (p->is_complex) {
+        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_fw, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec,
+                                        (size_t)D, lengths, (size_t)p->C, nullptr));
+        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_bw, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec,
+                                        (size_t)D, lengths, (size_t)p->C, nullptr));
+    } else {
+        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_fw, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec,
+                                        (size_t)D, lengths, (size_t)p->C, nullptr));
+        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_bw, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec,
+                                        (size_t)D, lengths, (size_t)p->C, nullptr));
+    }
+    size_t wf = 0, wb = 0;
+    NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft_fw, &wf));
+    NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft_bw, &wb));
+    p->fft_work_bytes = std::max(wf, wb);
+    NUFFT_ROCFFT(rocfft_execution_info_create(&p->fft_info));
+    if (p->fft_work_bytes > 0) {
+        if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes))) return rc;
+        NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
+    }
+
+    // kernels: allow the large dynamic LDS allocations
+    NUFFT_HIP(prepare_spread(p->dtype, p->is_complex, D, p->M, (int)p->lds_spread));
+    NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp));
+
+    for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
+        hipEvent_t a, b;
+        NUFFT_HIP(hipEventCreate(&a));
+        NUFFT_HIP(hipEventCreate(&b));
+        p->ev_begin[s] = a;
+        p->ev_end[s] = b;
+    }
+    return NUFFT_OK;
+}
+
+static void release(nufft_plan* p) {
+    if (!p) return;
+    if (p->device >= 0) {
+        DeviceGuard guard(p->device);
+        (void)hipDeviceSynchronize();
+        auto fr = [](void* q) { if (q) (void)hipFree(q); };
+        fr(p->d_coefs);
+        for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
+        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted);
+        fr(p->d_scan_tmp); fr(p->d_fft_work);
+        if (p->fft_fw) (void)rocfft_plan_destroy(p->fft_fw);
+        if (p->fft_bw) (void)rocfft_plan_destroy(p->fft_bw);
+        if (p->fft_info) (void)rocfft_execution_info_destroy(p->fft_info);
+        for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
+            if (p->ev_begin[s]) (void)hipEventDestroy(static_cast<hipEvent_t>(p->ev_begin[s]));
+            if (p->ev_end[s]) (void)hipEventDestroy(static_cast<hipEvent_t>(p->ev_end[s]));
+        }
+    }
+    delete p;
+}
+
+static int require_device(const nufft_plan* p) {
+    if (!p) return fail(NUFFT_ERR_INVALID_ARG, "null plan");
+    if (p->device < 0) return fail(NUFFT_ERR_NO_DEVICE, "host-only plan (device = -1) has no device path");
+    return NUFFT_OK;
+}
+
+static int require_points(const nufft_plan* p) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    if (p->Np < 0) return fail(NUFFT_ERR_NO_POINTS, "set_points must be called before exec");
+    return NUFFT_OK;
+}
+
+static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
+    TileKernelArgs a{};
+    a.dtype = p->dtype;
+    a.is_complex = p->is_complex;
+    a.D = p->D;
+    a.M = p->M;
+    a.evalmode = p->evalmode;
+    a.C = p->C;
+    a.g = make_geom(p);
+    a.sorted = p->d_sorted;
+    a.offsets = p->d_offsets;
+    a.coefs = p->d_coefs;
+    for (int d = 0; d < 3; ++d) a.beta[d] = p->beta[d];
+    a.grid = p->d_us;
+    a.grid_stride = p->grid_elems;
+    a.prefactor = 1.0;
+    if (interp) {
+        // prefactor = prod(Δx_d), src/interpolation/gpu.jl:55-56
+        for (int d = 0; d < p->D; ++d) a.prefactor *= 2.0 * M_PI / (double)p->Nover[d];
+    }
+    a.threads = interp ? p->interp_threads : p->spread_threads;
+    a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
+    return a;
+}
+
+static DeconvArgs deconv_args(const nufft_plan* p) {
+    DeconvArgs a{};
+    a.dtype = p->dtype;
+    a.D = p->D;
+    a.C = p->C;
+    for (int d = 0; d < 3; ++d) {
+        a.nout[d] = (int)p->Nout[d];
+        a.nspec[d] = (int)p->Nspec[d];
+        a.phihat[d] = p->d_phihat[d];
+        a.index_map[d] = p->d_index_map[d];
+        a.inv_map[d] = p->d_inv_map[d];
+    }
+    a.spec = p->is_complex ? p->d_us : p->d_uhat;
+    a.spec_stride = p->spec_elems;
+    a.normfactor = 1.0;
+    return a;
+}
+
+static int fft_exec(nufft_plan* p, bool forward, hipStream_t stream) {
+    NUFFT_ROCFFT(rocfft_execution_info_set_stream(p->fft_info, stream));
+    void* in[1];
+    void* out[1];
+    if (p->is_complex) {
+        in[0] = p->d_us;
+        NUFFT_ROCFFT(rocfft_execute(forward ? p->fft_fw : p->fft_bw, in, nullptr, p->fft_info));
+    } else if (forward) {
+        in[0] = p->d_us;
+        out[0] = p->d_uhat;
+        NUFFT_ROCFFT(rocfft_execute(p->fft_fw, in, out, p->fft_info));
+    } else {
+        in[0] = p->d_uhat;
+        out[0] = p->d_us;
+        NUFFT_ROCFFT(rocfft_execute(p->fft_bw, in, out, p->fft_info));
+    }
+    return NUFFT_OK;
+}
+
+}  // namespace nufft
+
+using namespace nufft;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int nufft_version(void) { return NUFFT_MI355X_VERSION; }
+
+const char* nufft_last_error_message(void) { return g_last_error.c_str(); }
+
+const char* nufft_strerror(int code) {
+    switch (code) {
+        case NUFFT_OK: return "success";
+        case NUFFT_ERR_INVALID_ARG: return "invalid argument (ArgumentError)";
+        case NUFFT_ERR_SIZE_TOO_SMALL: return "data size is too small: sigma*N < 2M (ArgumentError)";
+        case NUFFT_ERR_DIM_MISMATCH: return "dimension mismatch (DimensionMismatch)";
+        case NUFFT_ERR_LDS_TOO_SMALL: return "LDS too small for the chosen problem (ArgumentError)";
+        case NUFFT_ERR_UNSUPPORTED: return "unsupported configuration";
+        case NUFFT_ERR_NO_POINTS: return "set_points has not been called";
+        case NUFFT_ERR_ALLOC: return "device allocation failed";
+        case NUFFT_ERR_HIP: return "HIP runtime error";
+        case NUFFT_ERR_ROCFFT: return "rocFFT error";
+        case NUFFT_ERR_NO_DEVICE: return "host-only plan has no device path";
+        default: return "unknown error code";
+    }
+}
+
+int nufft_plan_create_ex(nufft_plan** out, const nufft_params* params) {
+    if (!out || !params) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    nufft_plan* p = new (std::nothrow) nufft_plan();
+    if (!p) return fail(NUFFT_ERR_ALLOC, "out of host memory");
+    int rc = build_host(p, params);
+    if (rc == NUFFT_OK && p->device >= 0) rc = build_device(p);
+    if (rc != NUFFT_OK) {
+        const std::string keep = g_last_error;
+        release(p);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = p;
+    return NUFFT_OK;
+}
+
+int nufft_plan_create(nufft_plan** out, int dtype, int is_complex, int ndim, const int64_t* N, int half_support,
+                      double sigma, int kernel, int evalmode, int ntransforms, int fftshift, int point_transform,
+                      int device) {
+    if (!N) return fail(NUFFT_ERR_INVALID_ARG, "null dims");
+    if (ndim < 1 || ndim > 3) return fail(NUFFT_ERR_UNSUPPORTED, "ndim must be 1, 2 or 3");
+    nufft_params prm;
+    std::memset(&prm, 0, sizeof(prm));
+    prm.dtype = dtype;
+    prm.is_complex = is_complex;
+    prm.ndim = ndim;
+    for (int d = 0; d < ndim; ++d) prm.N[d] = N[d];
+    prm.half_support = half_support;
+    prm.sigma = sigma;
+    prm.kernel = kernel;
+    prm.evalmode = evalmode;
+    prm.ntransforms = ntransforms;
+    prm.fftshift = fftshift;
+    prm.point_transform = point_transform;
+    prm.gpu_method = NUFFT_METHOD_SHARED_MEMORY;
+    prm.device = device;
+    return nufft_plan_create_ex(out, &prm);
+}
+
+int nufft_plan_destroy(nufft_plan* plan) {
+    release(plan);
+    return NUFFT_OK;
+}
+
+int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
+    if (!p || !o) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
+    std::memset(o, 0, sizeof(*o));
+    o->dtype = p->dtype;
+    o->is_complex = p->is_complex;
+    o->ndim = p->D;
+    o->half_support = p->M;
+    o->ntransforms = p->C;
+    o->evalmode = p->evalmode;
+    o->fftshift = p->fftshift;
+    o->device = p->device;
+    for (int d = 0; d < 3; ++d) {
+        o->N[d] = d < p->D ? p->N[d] : 1;
+        o->N_over[d] = d < p->D ? p->Nover[d] : 1;
+        o->N_out[d] = d < p->D ? p->Nout[d] : 1;
+        o->beta[d] = p->beta[d];
+        o->tile_dims[d] = p->tile.n[d];
+        o->tile_padded[d] = p->tile.P[d];
+        o->ntiles[d] = p->tile.nt[d];
+    }
+    o->sigma = p->sigma;
+    o->tile_row_stride = p->tile.row_stride;
+    o->spread_threads = p->spread_threads;
+    o->interp_threads = p->interp_threads;
+    o->lds_bytes_spread = p->lds_spread;
+    o->lds_bytes_interp = p->lds_interp;
+    o->workspace_bytes = p->workspace_bytes;
+    o->num_points = p->Np;
+    o->npoly = p->npoly;
+    return NUFFT_OK;
+}
+
+int nufft_plan_get_phi_hat(const nufft_plan* p, int dim, double* out, int64_t capacity) {
+    if (!p || !out || dim < 0 || dim >= p->D) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
+    if (capacity < (int64_t)p->phihat[dim].size()) return fail(NUFFT_ERR_DIM_MISMATCH, "buffer too small");
+    std::memcpy(out, p->phihat[dim].data(), p->phihat[dim].size() * sizeof(double));
+    return NUFFT_OK;
+}
+
+int nufft_plan_get_poly_coefs(const nufft_plan* p, int dim, double* out, int64_t capacity) {
+    if (!p || !out || dim < 0 || dim >= p->D) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
+    if (capacity < (int64_t)p->coefs[dim].size()) return fail(NUFFT_ERR_DIM_MISMATCH, "buffer too small");
+    std::memcpy(out, p->coefs[dim].data(), p->coefs[dim].size() * sizeof(double));
+    return NUFFT_OK;
+}
+
+int nufft_plan_get_index_map(const nufft_plan* p, int dim, int64_t* out, int64_t capacity) {
+    if (!p || !out || dim < 0 || dim >= p->D) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
+    if (capacity < (int64_t)p->index_map[dim].size()) return fail(NUFFT_ERR_DIM_MISMATCH, "buffer too small");
+    std::memcpy(out, p->index_map[dim].data(), p->index_map[dim].size() * sizeof(int64_t));
+    return NUFFT_OK;
+}
+
+int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void* stream_) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    if (np < 0) return fail(NUFFT_ERR_INVALID_ARG, "negative number of points");
+    if (np >= ((int64_t)1 << 31) - 1) return fail(NUFFT_ERR_UNSUPPORTED, "number of points exceeds 2^31 - 2");
+    if (!coords) return fail(NUFFT_ERR_INVALID_ARG, "null coordinate table");
+    for (int d = 0; d < p->D; ++d)
+        if (np > 0 && !coords[d]) return fail(NUFFT_ERR_INVALID_ARG, "null coordinate vector");
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (np > p->Np_capacity) {
+        // resize_no_copy!, src/blocking/blocking.jl:55-61 (old contents are discarded)
+        if (p->d_binrank) { (void)hipFree(p->d_binrank); p->workspace_bytes -= p->Np_capacity * 8; p->d_binrank = nullptr; }
+        if (p->d_sorted) {
+            (void)hipFree(p->d_sorted);
+            p->workspace_bytes -= p->Np_capacity * (int64_t)point_record_bytes(p->dtype, p->D);
+            p->d_sorted = nullptr;
+        }
+        p->Np_capacity = 0;
+        if ((rc = dev_alloc(p, &p->d_binrank, (size_t)np * 8))) return rc;
+        if ((rc = dev_alloc(p, &p->d_sorted, (size_t)np * point_record_bytes(p->dtype, p->D)))) return rc;
+        p->Np_capacity = np;
+    }
+    StageTimer tm(p, NUFFT_STAGE_SET_POINTS, stream);
+    SortArgs s{};
+    s.dtype = p->dtype;
+    s.D = p->D;
+    s.np = np;
+    for (int d = 0; d < 3; ++d) s.coords[d] = d < p->D ? coords[d] : nullptr;
+    s.g = make_geom(p);
+    s.counts = p->d_counts;
+    s.offsets = p->d_offsets;
+    s.binrank = p->d_binrank;
+    s.sorted = p->d_sorted;
+    s.scan_tmp = p->d_scan_tmp;
+    s.scan_tmp_bytes = p->scan_tmp_bytes;
+    NUFFT_HIP(launch_binsort(s, stream));
+    p->Np = np;
+    return NUFFT_OK;
+}
+
+int nufft_fill_zeros(nufft_plan* p, void* stream_) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer tm(p, NUFFT_STAGE_T1_ZERO, stream);
+    NUFFT_HIP(hipMemsetAsync(p->d_us, 0, (size_t)p->grid_elems * value_bytes(p) * p->C, stream));
+    return NUFFT_OK;
+}
+
+int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    if (!values_in) return fail(NUFFT_ERR_INVALID_ARG, "null value table");
+    for (int c = 0; c < p->C; ++c)
+        if (p->Np > 0 && !values_in[c]) return fail(NUFFT_ERR_INVALID_ARG, "null value vector");
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer tm(p, NUFFT_STAGE_T1_SPREAD, stream);
+    if (p->Np == 0) return NUFFT_OK;
+    TileKernelArgs a = tile_args(p, false);
+    a.values_in = values_in;
+    NUFFT_HIP(launch_spread(a, stream));
+    return NUFFT_OK;
+}
+
+int nufft_fft_forward(nufft_plan* p, void* stream_) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer tm(p, NUFFT_STAGE_T1_FFT, stream);
+    return fft_exec(p, true, stream);
+}
+
+int nufft_deconvolve_truncate(nufft_plan* p, void* const* uhat_out, void* stream_) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    if (!uhat_out) return fail(NUFFT_ERR_INVALID_ARG, "null output table");
+    for (int c = 0; c < p->C; ++c)
+        if (!uhat_out[c]) return fail(NUFFT_ERR_INVALID_ARG, "null output array");
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer tm(p, NUFFT_STAGE_T1_DECONV, stream);
+    DeconvArgs a = deconv_args(p);
+    a.normfactor = 1.0;
+    for (int d = 0; d < p->D; ++d) a.normfactor *= 2.0 * M_PI / (double)p->Nover[d];   // src/NonuniformFFTs.jl:181
+    NUFFT_HIP(launch_deconv_truncate(a, uhat_out, stream));
+    return NUFFT_OK;
+}
+
+int nufft_deconvolve_pad(nufft_plan* p, const void* const* uhat_in, void* stream_) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    if (!uhat_in) return fail(NUFFT_ERR_INVALID_ARG, "null input table");
+    for (int c = 0; c < p->C; ++c)
+        if (!uhat_in[c]) return fail(NUFFT_ERR_INVALID_ARG, "null input array");
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer tm(p, NUFFT_STAGE_T2_DECONV, stream);
+    DeconvArgs a = deconv_args(p);
+    NUFFT_HIP(launch_deconv_pad(a, uhat_in, stream));
+    return NUFFT_OK;
+}
+
+int nufft_fft_backward(nufft_plan* p, void* stream_) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer tm(p, NUFFT_STAGE_T2_FFT, stream);
+    return fft_exec(p, false, stream);
+}
+
+int nufft_interpolate(nufft_plan* p, void* const* values_out, void* stream_) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    if (!values_out) return fail(NUFFT_ERR_INVALID_ARG, "null output table");
+    for (int c = 0; c < p->C; ++c)
+        if (p->Np > 0 && !values_out[c]) return fail(NUFFT_ERR_INVALID_ARG, "null output vector");
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer tm(p, NUFFT_STAGE_T2_INTERP, stream);
+    if (p->Np == 0) return NUFFT_OK;
+    TileKernelArgs a = tile_args(p, true);
+    a.values_out = values_out;
+    NUFFT_HIP(launch_interp(a, stream));
+    return NUFFT_OK;
+}
+
+int nufft_exec_type1(nufft_plan* p, void* const* uhat_out, const void* const* values_in, void* stream) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    if (!uhat_out || !values_in) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
+    if ((rc = nufft_fill_zeros(p, stream))) return rc;                 // (0) src/NonuniformFFTs.jl:161-167
+    if ((rc = nufft_spread(p, values_in, stream))) return rc;          // (1) :169-172
+    if ((rc = nufft_fft_forward(p, stream))) return rc;                // (2) :174-177
+    return nufft_deconvolve_truncate(p, uhat_out, stream);             // (3) :179-185
+}
+
+int nufft_exec_type2(nufft_plan* p, void* const* values_out, const void* const* uhat_in, void* stream) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    if (!values_out || !uhat_in) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
+    if ((rc = nufft_deconvolve_pad(p, uhat_in, stream))) return rc;    // (0)+(1) :260-272
+    if ((rc = nufft_fft_backward(p, stream))) return rc;               // (2) :274-277
+    return nufft_interpolate(p, values_out, stream);                   // (3) :279-282
+}
+
+int nufft_grid_ptr(const nufft_plan* p, int which, int component, void** out_ptr, int64_t* out_bytes) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    if (!out_ptr || component < 0 || component >= p->C) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
+    if (which == 0) {
+        const size_t bytes = (size_t)p->grid_elems * value_bytes(p);
+        *out_ptr = static_cast<char*>(p->d_us) + bytes * component;
+        if (out_bytes) *out_bytes = (int64_t)bytes;
+    } else if (which == 1 && !p->is_complex) {
+        const size_t bytes = (size_t)p->spec_elems * 2 * real_bytes(p);
+        *out_ptr = static_cast<char*>(p->d_uhat) + bytes * component;
+        if (out_bytes) *out_bytes = (int64_t)bytes;
+    } else {
+        return fail(NUFFT_ERR_INVALID_ARG, "which must be 0 (us) or 1 (ûs, real plans only)");
+    }
+    return NUFFT_OK;
+}
+
+int nufft_copy_grid(const nufft_plan* p, int which, int component, void* dst, int64_t capacity_bytes, void* stream_) {
+    void* src = nullptr;
+    int64_t bytes = 0;
+    int rc = nufft_grid_ptr(p, which, component, &src, &bytes);
+    if (rc) return rc;
+    if (!dst) return fail(NUFFT_ERR_INVALID_ARG, "null destination");
+    if (capacity_bytes < bytes) return fail(NUFFT_ERR_DIM_MISMATCH, "destination buffer too small");
+    DeviceGuard guard(p->device);
+    NUFFT_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream_)));
+    return NUFFT_OK;
+}
+
+int nufft_get_sort_result(nufft_plan* p, int32_t* perm_host, int64_t perm_capacity, uint32_t* tile_offsets_host,
+                          int64_t offsets_capacity, void* stream_) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (perm_host) {
+        if (perm_capacity < p->Np) return fail(NUFFT_ERR_DIM_MISMATCH, "perm buffer too small");
+        if (p->Np > 0) {
+            int32_t* tmp = nullptr;
+            NUFFT_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)p->Np * sizeof(int32_t)));
+            hipError_t e = launch_extract_perm(p->dtype, p->D, p->d_sorted, p->Np, tmp, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(perm_host, tmp, (size_t)p->Np * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            (void)hipFree(tmp);
+            NUFFT_HIP(e);
+        }
+    }
+    if (tile_offsets_host) {
+        const int64_t n = p->tile.ntiles_total + 1;
+        if (offsets_capacity < n) return fail(NUFFT_ERR_DIM_MISMATCH, "offset buffer too small");
+        NUFFT_HIP(hipMemcpyAsync(tile_offsets_host, p->d_offsets, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        NUFFT_HIP(hipStreamSynchronize(stream));
+    }
+    return NUFFT_OK;
+}
+
+int nufft_set_timing(nufft_plan* p, int enable) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    p->timing = enable != 0;
+    if (!p->timing)
+        for (int s = 0; s < NUFFT_NUM_STAGES; ++s) p->ev_valid[s] = false;
+    return NUFFT_OK;
+}
+
+int nufft_get_stage_times(nufft_plan* p, float* ms_out) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    if (!ms_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
+    DeviceGuard guard(p->device);
+    for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
+        ms_out[s] = -1.0f;
+        if (!p->ev_valid[s]) continue;
+        hipEvent_t a = static_cast<hipEvent_t>(p->ev_begin[s]);
+        hipEvent_t b = static_cast<hipEvent_t>(p->ev_end[s]);
+        NUFFT_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        NUFFT_HIP(hipEventElapsedTime(&ms, a, b));
+        ms_out[s] = ms;
+    }
+    return NUFFT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// Plan-time parameter math (host only, double precision).
+//
+// Restates the scalar work of _PlanNUFFT (reference src/plan.jl:467-541) for the backwards
+// Kaiser-Bessel kernel: oversampled size rule, shape parameter, piecewise-polynomial fit,
+// Fourier coefficients, index map, plus the MI355X LDS tile search that replaces
+// block_dims_gpu_shmem (src/gpu_common.jl:19-92).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+
+#include "nufft_internal.h"
+
+namespace nufft {
+
+// Julia nextprod((2, 3, 5), n): smallest 2^a 3^b 5^c >= n (src/plan.jl:492-494).
+int64_t nextprod235(int64_t n) {
+    if (n < 1) n = 1;
+    int64_t best = std::numeric_limits<int64_t>::max();
+    for (int64_t p2 = 1;; p2 *= 2) {
+        for (int64_t p23 = p2;; p23 *= 3) {
+            int64_t p = p23;
+            while (p < n) p *= 5;
+            best = std::min(best, p);
+            if (p23 >= n) break;
+        }
+        if (p2 >= n) break;
+    }
+    return best;
+}
+
+// src/plan.jl:485-498
+int64_t oversampled_size(int64_t N, double sigma, bool real_first_dim) {
+    if (real_first_dim) return 2 * nextprod235((int64_t)std::floor(sigma * (double)((N + 1) / 2)));
+    return nextprod235((int64_t)std::floor(sigma * (double)N));
+}
+
+// src/Kernels/kaiser_bessel_backwards.jl:123-136
+double bkb_beta(int M, double sigma_d) {
+    const double a = M * (2.0 - 1.0 / sigma_d);
+    const double gamma = std::max(0.995, std::sqrt(1.0 - 0.3 / (a * a)));
+    return M_PI * a * gamma;
+}
+
+// src/Kernels/kaiser_bessel_backwards.jl:99-102
+double bkb_function(double y, double beta) {
+    const double z = 1.0 - y * y;
+    const double s = std::sqrt(z > 0.0 ? z : 0.0);
+    const double bs = beta * s;
+    const double ratio = (bs == 0.0) ? 1.0 : std::sinh(bs) / bs;
+    return ratio * (beta / M_PI);
+}
+
+// Modified Bessel function I0 (stands in for Bessels.besseli0, called at
+// src/Kernels/kaiser_bessel_backwards.jl:143).  Power series: all terms positive, no cancellation.
+double bessel_i0(double x) {
+    const double q = 0.25 * x * x;
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 1000; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-17 * sum) break;
+    }
+    return sum;
+}
+
+// Solves the (npoly x npoly) Vandermonde system by Gaussian elimination with partial pivoting
+// (solve_polynomial_coefficients!, src/Kernels/piecewise_polynomial.jl:23-41).
+static void solve_dense(std::vector<double>& A, std::vector<double>& b, int n) {
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < n; ++r)
+            if (std::fabs(A[r * n + col]) > std::fabs(A[piv * n + col])) piv = r;
+        if (piv != col) {
+            for (int c = 0; c < n; ++c) std::swap(A[col * n + c], A[piv * n + c]);
+            std::swap(b[col], b[piv]);
+        }
+        const double d = A[col * n + col];
+        for (int r = col + 1; r < n; ++r) {
+            const double f = A[r * n + col] / d;
+            if (f == 0.0) continue;
+            for (int c = col; c < n; ++c) A[r * n + c] -= f * A[col * n + c];
+            b[r] -= f * b[col];
+        }
+    }
+    for (int r = n - 1; r >= 0; --r) {
+        double s = b[r];
+        for (int c = r + 1; c < n; ++c) s -= A[r * n + c] * b[c];
+        b[r] = s / A[r * n + r];
+    }
+}
+
+// solve_piecewise_polynomial_coefficients, src/Kernels/piecewise_polynomial.jl:50-74 with
+// Npoly = M + 4 (src/Kernels/kaiser_bessel_backwards.jl:98).
+void bkb_poly_coefficients(int M, double beta, std::vector<double>& cs) {
+    const int L = 2 * M;
+    const int np = M + 4;
+    cs.assign((size_t)np * L, 0.0);
+    std::vector<double> xs(np), A((size_t)np * np), ys(np);
+    for (int i = 1; i <= np; ++i) xs[i - 1] = std::cos(M_PI * ((double)i - 0.5) / (double)np);
+    const double delta = 1.0 / (double)L;
+    for (int j = 1; j <= L; ++j) {
+        const double h = 1.0 - 2.0 * ((double)j - 0.5) / (double)L;
+        for (int i = 0; i < np; ++i) {
+            double pw = 1.0;
+            for (int k = 0; k < np; ++k) {
+                A[(size_t)i * np + k] = pw;
+                pw *= xs[i];
+            }
+            ys[i] = bkb_function(h + xs[i] * delta, beta);
+        }
+        solve_dense(A, ys, np);
+        for (int k = 0; k < np; ++k) cs[(size_t)k * L + (j - 1)] = ys[k];
+    }
+}
+
+// init_wavenumbers, src/plan.jl:558-566
+void wavenumbers(int64_t N, bool r2c, std::vector<double>& ks) {
+    if (r2c) {
+        ks.resize((size_t)(N / 2 + 1));
+        for (int64_t i = 0; i <= N / 2; ++i) ks[(size_t)i] = (double)i;
+    } else {
+        ks.resize((size_t)N);
+        for (int64_t i = 0; i < N; ++i) ks[(size_t)i] = (double)(i >= (N + 1) / 2 ? i - N : i);
+    }
+}
+
+// evaluate_fourier_func, src/Kernels/kaiser_bessel_backwards.jl:138-145
+void fourier_coefficients(const std::vector<double>& ks, int M, int64_t Nover, double beta,
+                          std::vector<double>& phihat) {
+    const double w = M * (2.0 * M_PI / (double)Nover);
+    phihat.resize(ks.size());
+    for (size_t i = 0; i < ks.size(); ++i) {
+        const double q = w * ks[i];
+        const double s = std::sqrt(beta * beta - q * q);
+        phihat[i] = w * bessel_i0(s);
+    }
+}
+
+// non_oversampled_indices!, src/NonuniformFFTs.jl:318-348 (0-based result)
+void non_oversampled_indices(const std::vector<double>& ks, int64_t n_axis, bool fftshift,
+                             std::vector<int64_t>& indmap) {
+    const int64_t Nk = (int64_t)ks.size();
+    indmap.resize((size_t)Nk);
+    const bool r2c = ks.back() > 0;
+    if (r2c) {
+        for (int64_t i = 0; i < Nk; ++i) indmap[(size_t)i] = i;
+    } else if (Nk % 2 == 0) {
+        const int64_t h = Nk / 2;
+        for (int64_t i = 0; i < h; ++i) {
+            if (fftshift) {
+                indmap[(size_t)i] = n_axis - h + i;
+                indmap[(size_t)(h + i)] = i;
+            } else {
+                indmap[(size_t)i] = i;
+                indmap[(size_t)(h + i)] = n_axis - h + i;
+            }
+        }
+    } else {
+        const int64_t h = (Nk - 1) / 2;
+        if (fftshift) {
+            for (int64_t i = 0; i < h; ++i) indmap[(size_t)i] = n_axis - h + i;
+            for (int64_t i = 0; i <= h; ++i) indmap[(size_t)(h + i)] = i;
+        } else {
+            for (int64_t i = 0; i <= h; ++i) indmap[(size_t)i] = i;
+            for (int64_t i = 0; i < h; ++i) indmap[(size_t)(h + 1 + i)] = n_axis - h + i;
+        }
+    }
+}
+
+// LDS row stride (in reals).  A wave instruction of the spreading / interpolation kernels touches
+// several consecutive rows, each with `stencil_inner` contiguous reals.  Rows land on disjoint
+// banks when the stride is congruent to the stencil width modulo the 128-byte bank period.
+int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes) {
+    static const bool no_pad = std::getenv("NUFFT_LDS_NO_PAD") != nullptr;
+    const int period = 128 / real_bytes;
+    if (no_pad || stencil_inner >= period) return inner_elems;
+    int s = inner_elems;
+    while (s % period != stencil_inner % period) ++s;
+    return s;
+}
+
+bool choose_tile(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,
+                 int staging_bytes, const int* forced, TileGeom& g) {
+    const int halo = 2 * M - 1;
+    const int64_t avail = ((int64_t)lds_budget_bytes - staging_bytes) / real_bytes;   // reals for the tile
+    auto fill = [&](const int n[3]) {
+        for (int d = 0; d < 3; ++d) {
+            g.n[d] = d < D ? n[d] : 1;
+            g.P[d] = d < D ? n[d] + halo : 1;
+            g.nt[d] = d < D ? (int)((Nover[d] + n[d] - 1) / n[d]) : 1;
+        }
+        g.row_stride = D >= 2 ? lds_row_stride(ncomp * g.P[0], ncomp * 2 * M, real_bytes) : ncomp * g.P[0];
+        g.tile_elems = (int64_t)g.row_stride * g.P[1] * g.P[2];
+        g.ntiles_total = (int64_t)g.nt[0] * g.nt[1] * g.nt[2];
+    };
+    if (forced && forced[0] > 0) {
+        int n[3] = {1, 1, 1};
+        for (int d = 0; d < D; ++d) {
+            n[d] = forced[d] > 0 ? forced[d] : forced[0];
+            if (n[d] > Nover[d]) n[d] = (int)Nover[d];
+        }
+        fill(n);
+        return g.tile_elems <= avail;
+    }
+    const int cap = 64;   // longest tile edge considered
+    int lim[3] = {1, 1, 1};
+    for (int d = 0; d < D; ++d) lim[d] = (int)std::min<int64_t>(Nover[d], D == 1 ? 4096 : cap);
+    double best_cost = std::numeric_limits<double>::infinity();
+    int best[3] = {0, 0, 0};
+    for (int n3 = 1; n3 <= lim[2]; ++n3) {
+        for (int n2 = 1; n2 <= lim[1]; ++n2) {
+            if (D == 3 && n2 < n3 && lim[1] == lim[2]) continue;   // symmetric duplicates
+            for (int n1 = 1; n1 <= lim[0]; ++n1) {
+                const int P1 = n1 + halo, P2 = D >= 2 ? n2 + halo : 1, P3 = D >= 3 ? n3 + halo : 1;
+                const int S = D >= 2 ? lds_row_stride(ncomp * P1, ncomp * 2 * M, real_bytes) : ncomp * P1;
+                const int64_t elems = (int64_t)S * P2 * P3;
+                if (elems > avail) break;   // larger n1 only grows
+                // cost: global atomics / loads per interior cell (halo amplification); ties -> longer rows
+                const double cost = ((double)P1 * P2 * P3) / ((double)n1 * n2 * n3) - 1e-6 * n1;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best[0] = n1; best[1] = n2; best[2] = n3;
+                }
+            }
+        }
+    }
+    if (best[0] == 0) return false;
+    fill(best);
+    return true;
+}
+
+}  // namespace nufft

@@ -1,0 +1,6 @@
+// spread kernels, T = float, complex = true (see tile_kernels.h).
+#define NUFFT_T float
+#define NUFFT_CPLX true
+#define NUFFT_KERNEL spread_tile_kernel
+#define NUFFT_GETTER spread_kernel_f32c
+#include "tile_inst.h"

@@ -1,0 +1,75 @@
+// Host-side dispatch of the tile kernels over (precision, complex?, D, M).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "tile_kernels.h"
+
+namespace nufft {
+
+const void* spread_kernel_f32r(int D, int M);
+const void* spread_kernel_f32c(int D, int M);
+const void* spread_kernel_f64r(int D, int M);
+const void* spread_kernel_f64c(int D, int M);
+const void* interp_kernel_f32r(int D, int M);
+const void* interp_kernel_f32c(int D, int M);
+const void* interp_kernel_f64r(int D, int M);
+const void* interp_kernel_f64c(int D, int M);
+
+static const void* pick(bool interp, int dtype, int is_complex, int D, int M) {
+    if (interp) {
+        if (dtype == NUFFT_F32) return is_complex ? interp_kernel_f32c(D, M) : interp_kernel_f32r(D, M);
+        return is_complex ? interp_kernel_f64c(D, M) : interp_kernel_f64r(D, M);
+    }
+    if (dtype == NUFFT_F32) return is_complex ? spread_kernel_f32c(D, M) : spread_kernel_f32r(D, M);
+    return is_complex ? spread_kernel_f64c(D, M) : spread_kernel_f64r(D, M);
+}
+
+static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, int lds_bytes) {
+    const void* fn = pick(interp, dtype, is_complex, D, M);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
+
+hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes) {
+    return prepare(false, dtype, is_complex, D, M, lds_bytes);
+}
+hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes) {
+    return prepare(true, dtype, is_complex, D, M, lds_bytes);
+}
+
+template <typename T>
+static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t stream) {
+    const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M);
+    if (!fn) return hipErrorInvalidValue;
+    const int ncr = a.is_complex ? 2 : 1;
+    for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
+        const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
+        TileArgs<T> k{};
+        k.g = a.g;
+        k.sorted = a.sorted;
+        k.offsets = a.offsets;
+        k.coefs = static_cast<const T*>(a.coefs);
+        for (int d = 0; d < 3; ++d) k.beta[d] = (T)a.beta[d];
+        for (int c = 0; c < nc; ++c) {
+            k.grid[c] = static_cast<T*>(a.grid) + (int64_t)(c0 + c) * a.grid_stride * ncr;
+            k.vin[c] = a.values_in ? static_cast<const T*>(a.values_in[c0 + c]) : nullptr;
+            k.vout[c] = a.values_out ? static_cast<T*>(a.values_out[c0 + c]) : nullptr;
+        }
+        k.prefactor = (T)a.prefactor;
+        k.evalmode = a.evalmode;
+        void* params[] = {&k};
+        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.g.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
+                                       params, (size_t)a.lds_bytes, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_t<float>(false, a, stream) : launch_t<double>(false, a, stream);
+}
+hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_t<float>(true, a, stream) : launch_t<double>(true, a, stream);
+}
+
+}  // namespace nufft

@@ -305,7 +305,10 @@ def evaluate_window(plan: OraclePlan, d: int, x: np.ndarray):
     M = plan.M
     T = x.dtype.type
     i, r = point_to_cell(x, plan.Nover[d])
-    X = (r - i.astype(x.dtype)).astype(x.dtype)          # in [0, 1)
+    # r == N can only come from rounding of L + r in the fold (x = -tiny); the reference would index
+    # out of bounds there.  Keep the point in the last cell with X = 1 (same window by continuity).
+    i = np.minimum(i, plan.Nover[d] - 1)
+    X = (r - i.astype(x.dtype)).astype(x.dtype)          # in [0, 1]
     if plan.evalmode == DIRECT:
         js = np.arange(1, 2 * M + 1, dtype=x.dtype)
         ys = (T(M) - js[None, :] + X[:, None]) / T(M)

@@ -1,0 +1,204 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs.  Mirrors the reference's GPU-vs-CPU matrix (test/pseudo_gpu.jl:109-226): dims (35, 64, 40),
+Np = prod(dims) there; smaller Np here so the numpy oracle finishes in seconds.
+
+Tolerances (written here as the reference writes them): rtol 1e-7 for Float64 and 1e-5 for Float32 on
+the 2-norm (test/pseudo_gpu.jl:159-171).  Summation order inside a tile is nondeterministic on the
+GPU (atomics), so comparisons are never bitwise.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import nufft_oracle as O  # noqa: E402
+
+
+def _nufft():
+    from nufft_pkg import nufft
+    return nufft
+
+
+def _rtol(dtype):
+    return 1e-7 if np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.complex128)) else 1e-5
+
+
+def _rel(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+
+
+def _make_case(Z, dims, M, sigma, evalmode, C, Np, seed, **kw):
+    nufft = _nufft()
+    Z = np.dtype(Z)
+    is_real = Z.kind == "f"
+    T = np.dtype(np.float32) if Z.itemsize in (4,) or Z == np.complex64 else np.dtype(np.float64)
+    rng = np.random.default_rng(seed)
+    xs = [(rng.random(Np) * 3 - 1) * O.TWO_PI for _ in dims]          # points outside the unit cell too
+    xs = [x.astype(T) for x in xs]
+    if is_real:
+        vs = [rng.standard_normal(Np).astype(Z) for _ in range(C)]
+    else:
+        vs = [(rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Z) for _ in range(C)]
+    mode = nufft.Direct() if evalmode == O.DIRECT else nufft.FastApproximation()
+    plan = nufft.PlanNUFFT(Z, dims, m=M, sigma=sigma, ntransforms=C, kernel_evalmode=mode,
+                           backend=nufft.ROCBackend(0), **kw)
+    oplan = O.OraclePlan(dims, is_real=is_real, dtype=T.type, M=M, sigma=sigma, evalmode=evalmode, ntransforms=C)
+    return nufft, plan, oplan, xs, vs
+
+
+CASES = [
+    # Z, dims, M, sigma, evalmode, C
+    (np.float64, (35, 64, 40), 4, 1.5, O.DIRECT, 1),
+    (np.float64, (35, 64, 40), 4, 1.5, O.FAST_APPROXIMATION, 1),
+    (np.complex128, (35, 64, 40), 4, 1.5, O.DIRECT, 1),
+    (np.float32, (35, 64, 40), 4, 1.5, O.DIRECT, 1),
+    (np.complex64, (35, 64, 40), 4, 1.5, O.FAST_APPROXIMATION, 1),
+    (np.float64, (35, 64, 40), 4, 2.0, O.DIRECT, 2),              # ntransforms = 2
+    (np.complex128, (24, 20, 30), 6, 2.0, O.FAST_APPROXIMATION, 3),
+    (np.float64, (64, 64), 4, 2.0, O.DIRECT, 1),
+    (np.complex128, (37, 41), 5, 1.25, O.FAST_APPROXIMATION, 1),
+    (np.float32, (64, 48), 2, 2.0, O.DIRECT, 2),
+    (np.float64, (256,), 4, 2.0, O.DIRECT, 1),                    # BASELINE config C1 shape
+    (np.complex128, (256,), 8, 1.25, O.FAST_APPROXIMATION, 1),
+    (np.complex64, (100,), 3, 2.0, O.DIRECT, 1),
+    (np.float64, (20, 16, 18), 8, 2.0, O.DIRECT, 1),              # wide support
+    (np.complex64, (16, 16, 16), 8, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float64, (12, 16, 10), 10, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float64, (30, 30, 30), 3, 2.0, O.DIRECT, 1),              # odd half-support
+]
+
+
+@pytest.mark.parametrize("Z,dims,M,sigma,evalmode,C", CASES)
+def test_type1_type2_match_oracle(Z, dims, M, sigma, evalmode, C):
+    Np = 2000
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, sigma, evalmode, C, Np, seed=42)
+    dev = plan.device
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
+    vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
+    nufft.set_points(plan, xd)
+    O.set_points(oplan, xs)
+
+    # type 1
+    us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+    ref = O.exec_type1(oplan, vs if C > 1 else vs[0])
+    ref = ref if C > 1 else [ref]
+    tol = _rtol(Z)
+    for c in range(C):
+        assert _rel(us[c].cpu().numpy(), ref[c]) < tol
+
+    # type 2 (random spectrum)
+    rng = np.random.default_rng(7)
+    ws = [(rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)).astype(oplan.cdtype) for _ in range(C)]
+    wd = tuple(torch.from_numpy(w).to(dev) for w in ws)
+    out = tuple(torch.empty(Np, dtype=plan.Z, device=dev) for _ in range(C))
+    nufft.exec_type2(out if C > 1 else out[0], plan, wd if C > 1 else wd[0])
+    ref2 = O.exec_type2(oplan, ws if C > 1 else ws[0])
+    ref2 = ref2 if C > 1 else [ref2]
+    for c in range(C):
+        assert _rel(out[c].cpu().numpy(), ref2[c]) < tol
+
+
+@pytest.mark.parametrize("Z", [np.float64, np.complex64])
+def test_spread_and_interp_stages_match_oracle(Z):
+    """Stage-level parity of spread_from_points! / interpolate! on the oversampled grid itself."""
+    dims, M, sigma, Np = (20, 24, 18), 4, 2.0, 3000
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, sigma, O.DIRECT, 1, Np, seed=3)
+    dev = plan.device
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
+    nufft.set_points(plan, xd)
+    O.set_points(oplan, xs)
+    nufft.spread_from_points(plan, torch.from_numpy(vs[0]).to(dev))
+    grid = nufft.oversampled_grid(plan).cpu().numpy()
+    ref = O.spread(oplan, vs)[0]
+    assert _rel(grid, ref) < (1e-12 if np.dtype(Z).itemsize >= 8 and Z != np.complex64 else 1e-5)
+    # interpolate from the grid that is now in the plan
+    out = torch.empty(Np, dtype=plan.Z, device=dev)
+    nufft.interpolate(plan, out)
+    ref2 = O.interpolate(oplan, [grid])[0]
+    assert _rel(out.cpu().numpy(), ref2) < (1e-12 if Z == np.float64 else 1e-5)
+
+
+def test_bin_sort_is_a_permutation_grouped_by_tile():
+    nufft = _nufft()
+    dims, Np = (40, 36, 50), 20000
+    plan = nufft.PlanNUFFT(np.float64, dims, m=4, sigma=2.0, backend=nufft.ROCBackend(0), tile_dims=(8, 6, 10))
+    rng = np.random.default_rng(0)
+    xs = [(rng.random(Np) * 5 - 2) * O.TWO_PI for _ in dims]
+    nufft.set_points(plan, tuple(torch.from_numpy(x).cuda() for x in xs))
+    perm, offs = nufft.sort_result(plan)
+    assert np.array_equal(np.sort(perm), np.arange(Np))                # bijection
+    assert offs[0] == 0 and offs[-1] == Np and np.all(np.diff(offs.astype(np.int64)) >= 0)
+    info = plan.info()
+    Nover = plan.oversampled_dims
+    tile = np.zeros(Np, dtype=np.int64)
+    mul = 1
+    for d in range(3):
+        i, _ = O.point_to_cell(O.to_unit_cell(xs[d]), Nover[d])
+        i = np.minimum(i, Nover[d] - 1)
+        tile += mul * (i // info.tile_dims[d])
+        mul *= info.ntiles[d]
+    sorted_tiles = tile[perm]
+    assert np.all(np.diff(sorted_tiles) >= 0)                           # grouped by tile, tiles ascending
+    counts = np.bincount(tile, minlength=len(offs) - 1)
+    assert np.array_equal(np.diff(offs.astype(np.int64)), counts)
+
+
+def test_edge_points_and_empty_input():
+    """prevfloat(2π), prevfloat(π), 0, negative and shifted points (test/near_2pi.jl); Np = 0."""
+    nufft = _nufft()
+    N, M = 32, 8
+    plan = nufft.PlanNUFFT(np.complex128, N, m=M, sigma=1.5, backend=nufft.ROCBackend(0))
+    x = np.array([np.nextafter(O.TWO_PI, 0.0), np.nextafter(np.pi, 0.0), 0.0, -0.0, -1e-20, O.TWO_PI,
+                  -O.TWO_PI, 3 * O.TWO_PI + 0.1, -7.3], dtype=np.float64)
+    v = (np.arange(len(x)) + 1.0) * (4.2 + 3j)
+    nufft.set_points(plan, torch.from_numpy(x).cuda())
+    u = torch.empty(plan.shape, dtype=torch.complex128, device="cuda")
+    nufft.exec_type1(u, plan, torch.from_numpy(v).cuda())
+    exact = O.nudft_type1([O.fftfreq_int(N)], [x], v)
+    assert _rel(u.cpu().numpy(), exact) < 1e-11                          # test/near_2pi.jl:69
+    # empty point set: type-1 gives zeros, type-2 gives an empty vector
+    nufft.set_points(plan, torch.empty(0, dtype=torch.float64, device="cuda"))
+    nufft.exec_type1(u, plan, torch.empty(0, dtype=torch.complex128, device="cuda"))
+    assert float(u.abs().max()) == 0.0
+    out = torch.empty(0, dtype=torch.complex128, device="cuda")
+    nufft.exec_type2(out, plan, u)
+    assert out.numel() == 0
+
+
+def test_clustered_points_single_tile():
+    """All points inside one tile (stress for the LDS atomics and the flush)."""
+    Z, dims, M = np.float64, (32, 32, 32), 4
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, O.FAST_APPROXIMATION, 1, 5000, seed=11)
+    xs = [(0.05 + 0.02 * np.random.default_rng(d).random(5000)).astype(np.float64) for d in range(3)]
+    dev = plan.device
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    O.set_points(oplan, xs)
+    u = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    nufft.exec_type1(u, plan, torch.from_numpy(vs[0]).to(dev))
+    assert _rel(u.cpu().numpy(), O.exec_type1(oplan, vs[0])) < 1e-7
+
+
+def test_errors_mirror_the_reference():
+    nufft = _nufft()
+    with pytest.raises(ValueError):                 # test/errors.jl:5-10 (Ñ < 2M)
+        nufft.PlanNUFFT(np.float64, 4, m=8, sigma=1.25, backend=nufft.ROCBackend(0))
+    plan = nufft.PlanNUFFT(np.float64, (16, 16), backend=nufft.ROCBackend(0))
+    x = torch.zeros(10, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):                 # exec before set_points
+        nufft.exec_type1(torch.empty(plan.shape, dtype=torch.complex128, device="cuda"), plan, x)
+    with pytest.raises(ValueError):                 # wrong precision of the points, src/set_points.jl:35
+        nufft.set_points(plan, (x.float(), x.float()))
+    with pytest.raises(nufft.DimensionMismatch):    # different lengths, src/blocking/gpu.jl:86
+        nufft.set_points(plan, (x, x[:5].contiguous()))
+    nufft.set_points(plan, (x, x))
+    with pytest.raises(ValueError):                 # complex64 output for a Float64 plan, src/NonuniformFFTs.jl:154
+        nufft.exec_type1(torch.empty(plan.shape, dtype=torch.complex64, device="cuda"), plan, x)
+    with pytest.raises(nufft.DimensionMismatch):    # wrong uniform shape, :92-103
+        nufft.exec_type1(torch.empty((16, 16), dtype=torch.complex128, device="cuda"), plan, x)
+    with pytest.raises(nufft.DimensionMismatch):    # wrong number of values, :105-114
+        nufft.exec_type1(torch.empty(plan.shape, dtype=torch.complex128, device="cuda"), plan, x[:3].contiguous())
