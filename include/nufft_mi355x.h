@@ -111,7 +111,8 @@ typedef struct nufft_info {
     int64_t workspace_bytes; /* device bytes owned by the plan right now                           */
     int64_t num_points;      /* Np of the last set_points                                          */
     int32_t npoly;           /* M + 4 polynomial coefficients per sub-interval                     */
-    int32_t reserved[7];
+    int32_t window_scale_log2[3]; /* device windows and phi_hat are scaled by 2^k_d (exact) */
+    int32_t reserved[4];
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */

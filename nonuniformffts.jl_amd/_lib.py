@@ -56,7 +56,7 @@ class NufftInfo(C.Structure):
         ("spread_threads", C.c_int32), ("interp_threads", C.c_int32),
         ("lds_bytes_spread", C.c_int64), ("lds_bytes_interp", C.c_int64),
         ("workspace_bytes", C.c_int64), ("num_points", C.c_int64),
-        ("npoly", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("npoly", C.c_int32), ("window_scale_log2", C.c_int32 * 3), ("reserved", C.c_int32 * 4),
     ]
 
 

@@ -94,14 +94,16 @@ struct LdsLayout {
     int tile_bytes, coef_bytes, stage_bytes_per_wave, total;
 };
 
-constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int real_bytes, int D, int M,
-                                                   int ncomp, int nwaves, bool staging_results) {
+// tile_elem_bytes: the spreading tile always accumulates in Float64 (ds_add_f32 is ~22x slower than
+// ds_add_f64 on gfx950: 193 vs 8.5 cycles per wave instruction, scripts/microbench.hip), the
+// interpolation tile holds the grid's own precision.
+constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int tile_elem_bytes, int real_bytes, int D, int M,
+                                                   int ncomp, int nwaves) {
     LdsLayout l{};
-    l.tile_bytes = round_up(tile_elems * real_bytes, 16);
+    l.tile_bytes = round_up(tile_elems * tile_elem_bytes, 16);
     l.coef_bytes = round_up(D * (M + 4) * 2 * M * real_bytes, 16);
     // per staged point: D*2M window values, ncomp value components (or results), D local starts
     int per_point = (D * 2 * M + ncomp) * real_bytes + D * 4;
-    (void)staging_results;
     l.stage_bytes_per_wave = round_up(kCH * per_point, 16);
     l.total = l.tile_bytes + l.coef_bytes + nwaves * l.stage_bytes_per_wave;
     return l;

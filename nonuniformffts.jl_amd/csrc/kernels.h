@@ -35,6 +35,7 @@ struct TileKernelArgs {
     const uint32_t* offsets;   // [ntiles + 1]
     const void* coefs;         // T[D][npoly][2M]
     double beta[3];
+    double beta_over_pi[3];    // (β/π) * 2^scale_exp, see plan.cpp
     void* grid;                // C grids, contiguous, Z[Nover...]
     int64_t grid_stride;       // elements of Z between components
     const void* const* values_in;   // spread: C device vectors Z[np]

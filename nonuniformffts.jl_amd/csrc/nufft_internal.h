@@ -80,6 +80,8 @@ struct nufft_plan {
     int64_t Nspec[3] = {1, 1, 1};      // dims of the oversampled spectrum (r2c halves dim 0)
     double sigma = 2.0;
     double beta[3] = {0, 0, 0};
+    int scale_exp[3] = {0, 0, 0};      // device windows and phi_hat carry a factor 2^scale_exp[d]
+    double beta_over_pi_scaled[3] = {0, 0, 0};   // (β/π rounded to T) * 2^scale_exp[d]
     int npoly = 8;
     std::vector<double> coefs[3];      // [npoly][2M]
     std::vector<double> phihat[3];

@@ -172,6 +172,16 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         double beta = bkb_beta(p->M, sigma_d);
         if (p->dtype == NUFFT_F32) beta = (double)(float)beta;
         p->beta[d] = beta;
+        // Power-of-two normalisation of the window: the BKB window peaks at sinh(β)/π ≈ e^β/2π (4e15 at
+        // M = 8), so products of D window values overflow Float32 (and 1/ϕ̂^D underflows) in the
+        // reference's formulation.  Scaling window and ϕ̂ by the same 2^k is exact in binary floating
+        // point, leaves every result bit-identical where the reference is finite, and keeps all
+        // intermediates O(1).
+        p->scale_exp[d] = -(int)std::lround(std::log2(std::sinh(beta) / M_PI));
+        {
+            const double bop = p->dtype == NUFFT_F32 ? (double)((float)beta / (float)M_PI) : beta / M_PI;
+            p->beta_over_pi_scaled[d] = std::ldexp(bop, p->scale_exp[d]);
+        }
         bkb_poly_coefficients(p->M, beta, p->coefs[d]);
         std::vector<double> ks;
         wavenumbers(p->N[d], r2c, ks);
@@ -195,7 +205,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     const int ncomp = p->is_complex ? 2 : 1;
     const int rb = (int)real_bytes(p);
     const int max_waves = std::max(p->spread_threads, p->interp_threads) / 64;
-    const LdsLayout probe = lds_layout(0, rb, p->D, p->M, ncomp, max_waves, true);
+    const LdsLayout probe = lds_layout(0, 8, rb, p->D, p->M, ncomp, max_waves);
     int forced[3] = {in->tile_dims[0], in->tile_dims[1], in->tile_dims[2]};
     if (forced[0] <= 0) {
         const char* e = std::getenv("NUFFT_TILE");
@@ -205,13 +215,14 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
             if (n >= 1) { forced[0] = a; forced[1] = n >= 2 ? b : a; forced[2] = n >= 3 ? c : (n >= 2 ? b : a); }
         }
     }
-    if (!choose_tile(p->D, p->M, ncomp, rb, p->Nover, budget, probe.total, forced, p->tile)) {
+    // the spreading tile accumulates in Float64 whatever the plan's precision (lds_layout)
+    if (!choose_tile(p->D, p->M, ncomp, 8, p->Nover, budget, probe.total, forced, p->tile)) {
         return fail(NUFFT_ERR_LDS_TOO_SMALL,
                     "LDS is too small for the chosen problem (element type, half-support M, dimensions): "
                     "reduce M or the tile size");
     }
-    p->lds_spread = lds_layout((int)p->tile.tile_elems, rb, p->D, p->M, ncomp, p->spread_threads / 64, false).total;
-    p->lds_interp = lds_layout((int)p->tile.tile_elems, rb, p->D, p->M, ncomp, p->interp_threads / 64, true).total;
+    p->lds_spread = lds_layout((int)p->tile.tile_elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64).total;
+    p->lds_interp = lds_layout((int)p->tile.tile_elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64).total;
     if (p->tile.ntiles_total >= ((int64_t)1 << 31) - 2) return fail(NUFFT_ERR_UNSUPPORTED, "too many tiles");
     return NUFFT_OK;
 }
@@ -228,14 +239,23 @@ static int build_device(nufft_plan* p) {
     // polynomial coefficients [D][npoly][2M]
     {
         std::vector<double> all;
-        for (int d = 0; d < D; ++d) all.insert(all.end(), p->coefs[d].begin(), p->coefs[d].end());
+        for (int d = 0; d < D; ++d)
+            for (double c : p->coefs[d]) all.push_back(std::ldexp(c, p->scale_exp[d]));
         (void)L;
         rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_coefs, all) : upload<double>(p, &p->d_coefs, all);
         if (rc) return rc;
     }
     for (int d = 0; d < D; ++d) {
-        rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_phihat[d], p->phihat[d]) : upload<double>(p, &p->d_phihat[d], p->phihat[d]);
-        if (rc) return rc;
+        {
+            // round to T first, then scale: the scaled device value is exactly 2^k times the reference's
+            std::vector<double> ph(p->phihat[d].size());
+            for (size_t i = 0; i < ph.size(); ++i) {
+                const double v = p->dtype == NUFFT_F32 ? (double)(float)p->phihat[d][i] : p->phihat[d][i];
+                ph[i] = std::ldexp(v, p->scale_exp[d]);
+            }
+            rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_phihat[d], ph) : upload<double>(p, &p->d_phihat[d], ph);
+            if (rc) return rc;
+        }
         std::vector<int32_t> im(p->index_map[d].size());
         std::vector<int32_t> inv((size_t)p->Nspec[d], -1);
         for (size_t i = 0; i < im.size(); ++i) {
@@ -350,7 +370,10 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.sorted = p->d_sorted;
     a.offsets = p->d_offsets;
     a.coefs = p->d_coefs;
-    for (int d = 0; d < 3; ++d) a.beta[d] = p->beta[d];
+    for (int d = 0; d < 3; ++d) {
+        a.beta[d] = p->beta[d];
+        a.beta_over_pi[d] = p->beta_over_pi_scaled[d];
+    }
     a.grid = p->d_us;
     a.grid_stride = p->grid_elems;
     a.prefactor = 1.0;
@@ -494,6 +517,7 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
         o->tile_dims[d] = p->tile.n[d];
         o->tile_padded[d] = p->tile.P[d];
         o->ntiles[d] = p->tile.nt[d];
+        o->window_scale_log2[d] = d < p->D ? p->scale_exp[d] : 0;
     }
     o->sigma = p->sigma;
     o->tile_row_stride = p->tile.row_stride;

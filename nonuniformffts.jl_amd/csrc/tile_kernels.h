@@ -33,6 +33,7 @@ struct TileArgs {
     const uint32_t* offsets;
     const T* coefs;                       // [D][npoly][2M]
     T beta[3];
+    T bop[3];                             // β/π times the power-of-two window normalisation
     T* grid[kMaxCompPerLaunch];           // component grids (as arrays of reals)
     const T* vin[kMaxCompPerLaunch];      // spread: values (as reals; complex = interleaved)
     T* vout[kMaxCompPerLaunch];           // interp
@@ -86,7 +87,7 @@ __device__ __forceinline__ int stage_chunk(const TileArgs<T>& a, const PointRec<
             if (part == 0) st.ss[pt * D + d] = i - origin[d];
             if (a.evalmode == NUFFT_EVAL_DIRECT) {
                 const T beta = a.beta[d];
-                const T bop = beta / T(3.14159265358979323846);
+                const T bop = a.bop[d];
                 for (int j = part; j < L; j += kParts) st.wv[pt * NV + d * L + j] = bkb_direct<T, M>(X, j, beta, bop);
             } else {
                 const T* cs = coefs_lds + d * (M + 4) * L;
@@ -176,13 +177,14 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         for (int d = 0; d < 3; ++d) origin[d] = t[d] * g.n[d];
     }
 
-    const LdsLayout lay = lds_layout(g.tile_elems, (int)sizeof(T), D, M, NC, nwaves, false);
-    T* tile = reinterpret_cast<T*>(smem);
+    using A = double;   // LDS accumulation type (see lds_layout)
+    const LdsLayout lay = lds_layout(g.tile_elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves);
+    A* tile = reinterpret_cast<A*>(smem);
     T* coefs_lds = reinterpret_cast<T*>(smem + lay.tile_bytes);
     Stage<T, NC, D, M> st(smem + lay.tile_bytes + lay.coef_bytes + wave * lay.stage_bytes_per_wave);
 
     // zero the tile, copy the polynomial coefficients
-    for (int i = tid; i < g.tile_elems; i += nthreads) tile[i] = T(0);
+    for (int i = tid; i < g.tile_elems; i += nthreads) tile[i] = A(0);
     if (a.evalmode != NUFFT_EVAL_DIRECT)
         for (int i = tid; i < D * (M + 4) * L; i += nthreads) coefs_lds[i] = a.coefs[i];
     __syncthreads();
@@ -231,12 +233,12 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                     if (act[ps]) {
                         T w = st.vv[pt * NC + cmp[ps]] * wv[j1v[ps]];
                         if constexpr (D >= 2) w *= wv[L + j2v[ps]];
-                        T* dst = tile + base + lane_off[ps];
+                        A* dst = tile + base + lane_off[ps];
                         if constexpr (D >= 3) {
 #pragma unroll
-                            for (int j3 = 0; j3 < L; ++j3) lds_atomic_add(dst + j3 * g.plane_stride, w * wv[2 * L + j3]);
+                            for (int j3 = 0; j3 < L; ++j3) lds_atomic_add(dst + j3 * g.plane_stride, (A)(w * wv[2 * L + j3]));
                         } else {
-                            lds_atomic_add(dst, w);
+                            lds_atomic_add(dst, (A)w);
                         }
                     }
                 }
@@ -255,9 +257,9 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         if constexpr (D >= 2) rowbase = (int64_t)wrap_index(o2 + rw.l2, g.Nover[1]);
         if constexpr (D >= 3) rowbase += (int64_t)wrap_index(o3 + rw.l3, g.Nover[2]) * g.Nover[1];
         rowbase *= (int64_t)g.Nover[0] * NC;
-        const T* src = tile + rw.l2 * g.row_stride + rw.l3 * g.plane_stride;
+        const A* src = tile + rw.l2 * g.row_stride + rw.l3 * g.plane_stride;
         for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) {
-            const T v = src[e];
+            const T v = (T)src[e];
             if (v != T(0)) {
                 const int l1 = e / NC, c = e % NC;
                 const int g1 = wrap_index(o1 + l1, g.Nover[0]);
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         for (int d = 0; d < 3; ++d) origin[d] = t[d] * g.n[d];
     }
 
-    const LdsLayout lay = lds_layout(g.tile_elems, (int)sizeof(T), D, M, NC, nwaves, true);
+    const LdsLayout lay = lds_layout(g.tile_elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves);
     T* tile = reinterpret_cast<T*>(smem);
     T* coefs_lds = reinterpret_cast<T*>(smem + lay.tile_bytes);
     Stage<T, NC, D, M> st(smem + lay.tile_bytes + lay.coef_bytes + wave * lay.stage_bytes_per_wave);

@@ -49,7 +49,10 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         k.sorted = a.sorted;
         k.offsets = a.offsets;
         k.coefs = static_cast<const T*>(a.coefs);
-        for (int d = 0; d < 3; ++d) k.beta[d] = (T)a.beta[d];
+        for (int d = 0; d < 3; ++d) {
+            k.beta[d] = (T)a.beta[d];
+            k.bop[d] = (T)a.beta_over_pi[d];
+        }
         for (int c = 0; c < nc; ++c) {
             k.grid[c] = static_cast<T*>(a.grid) + (int64_t)(c0 + c) * a.grid_stride * ncr;
             k.vin[c] = a.values_in ? static_cast<const T*>(a.values_in[c0 + c]) : nullptr;

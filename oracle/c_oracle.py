@@ -1,0 +1,126 @@
+"""ctypes wrapper of oracle/libnufft_oracle.so (plain-C blocked CPU spreading / interpolation) and a
+full type-1 / type-2 pipeline built from it + scipy's pocketfft.  TEST INFRASTRUCTURE ONLY — see the
+header of oracle/nufft_oracle.py.  Used by tests (cross-check of the numpy oracle, larger parity
+cases) and by bench.py's ``cpu_baseline`` leg ("port": the reference's Julia CPU backend cannot run
+here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import nufft_oracle as O
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libnufft_oracle.so")
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(_LIB)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise ImportError(f"{_LIB} not built: run `make -C oracle`")
+        _lib = C.CDLL(_LIB)
+        for name in ("oracle_spread_blocked", "oracle_interp_blocked"):
+            getattr(_lib, name).restype = C.c_int
+        _lib.oracle_num_threads.restype = C.c_int
+    return _lib
+
+
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())
+
+
+def _ptrs(arrs):
+    tbl = (C.c_void_p * len(arrs))()
+    for i, a in enumerate(arrs):
+        tbl[i] = a.ctypes.data
+    return tbl
+
+
+def _common(plan: O.OraclePlan):
+    assert np.dtype(plan.dtype) == np.float64, "the C oracle is Float64 only"
+    D = plan.ndim
+    N = (C.c_int64 * 3)(*(list(plan.Nover) + [1] * (3 - D)))
+    coefs = np.ascontiguousarray(np.stack([plan.coefs[d] for d in range(D)]))   # [D][npoly][2M]
+    betas = (C.c_double * 3)(*(list(plan.betas) + [0.0] * (3 - D)))
+    xs = [np.ascontiguousarray(x, dtype=np.float64) for x in plan.points]
+    return D, N, coefs, betas, xs
+
+
+def spread(plan: O.OraclePlan, vps):
+    """C restatement of spread_from_points!(::CPU, ..., ::BlockDataCPU, ...) (src/spreading/cpu_blocked.jl:94-168).
+    Returns grids with reversed axes, like nufft_oracle.spread."""
+    D, N, coefs, betas, xs = _common(plan)
+    ncomp = 1 if plan.is_real else 2
+    Np = len(xs[0])
+    vs = [np.ascontiguousarray(v, dtype=np.float64 if plan.is_real else np.complex128) for v in vps]
+    shape = tuple(reversed(plan.Nover))
+    us = [np.zeros(shape, dtype=np.float64 if plan.is_real else np.complex128) for _ in vs]
+    rc = lib().oracle_spread_blocked(C.c_int(D), N, C.c_int(plan.M), C.c_int(plan.evalmode), C.c_int(ncomp),
+                                     C.c_void_p(coefs.ctypes.data), betas, C.c_int64(Np), _ptrs(xs),
+                                     C.c_int(len(vs)), _ptrs(vs), _ptrs(us))
+    assert rc == 0
+    return us
+
+
+def interpolate(plan: O.OraclePlan, us):
+    """C restatement of interpolate!(::CPU, ..., ::BlockDataCPU, ...) (src/interpolation/cpu_blocked.jl:95-153)."""
+    D, N, coefs, betas, xs = _common(plan)
+    ncomp = 1 if plan.is_real else 2
+    Np = len(xs[0])
+    gs = [np.ascontiguousarray(u, dtype=np.float64 if plan.is_real else np.complex128) for u in us]
+    vs = [np.empty(Np, dtype=np.float64 if plan.is_real else np.complex128) for _ in gs]
+    rc = lib().oracle_interp_blocked(C.c_int(D), N, C.c_int(plan.M), C.c_int(plan.evalmode), C.c_int(ncomp),
+                                     C.c_void_p(coefs.ctypes.data), betas, C.c_int64(Np), _ptrs(xs),
+                                     C.c_int(len(gs)), _ptrs(gs), _ptrs(vs))
+    assert rc == 0
+    return vs
+
+
+def _fft_workers():
+    return max(1, os.cpu_count() or 1)
+
+
+def exec_type1(plan: O.OraclePlan, vp):
+    """exec_type1! with the C spreading stage and scipy (pocketfft, all cores) for the FFT."""
+    import scipy.fft as sfft
+    single = not isinstance(vp, (list, tuple))
+    us = spread(plan, [vp] if single else list(vp))
+    norm = float(np.prod([O.TWO_PI / n for n in plan.Nover]))
+    fac = norm / O._deconv_factor(plan)
+    outs = []
+    for u in us:
+        uh = sfft.rfftn(u, workers=_fft_workers()) if plan.is_real else sfft.fftn(u, workers=_fft_workers())
+        outs.append((uh[O._gather_index(plan)] * fac).astype(plan.cdtype))
+    return outs[0] if single else outs
+
+
+def exec_type2(plan: O.OraclePlan, uhat):
+    import scipy.fft as sfft
+    single = not isinstance(uhat, (list, tuple))
+    fac = 1.0 / O._deconv_factor(plan)
+    grids = []
+    for w in ([uhat] if single else list(uhat)):
+        if plan.is_real:
+            shape = tuple(reversed((plan.Nover[0] // 2 + 1,) + plan.Nover[1:]))
+        else:
+            shape = tuple(reversed(plan.Nover))
+        uh = np.zeros(shape, dtype=np.complex128)
+        uh[O._gather_index(plan)] = np.asarray(w, dtype=np.complex128) * fac
+        ntot = float(np.prod(plan.Nover))
+        axes = tuple(range(plan.ndim))
+        if plan.is_real:
+            u = sfft.irfftn(uh, s=tuple(reversed(plan.Nover)), axes=axes, workers=_fft_workers()) * ntot
+        else:
+            u = sfft.ifftn(uh, workers=_fft_workers()) * ntot
+        grids.append(u)
+    vs = interpolate(plan, grids)
+    return vs[0] if single else vs
