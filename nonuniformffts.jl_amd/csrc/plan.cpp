@@ -204,8 +204,6 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     if (budget > kLdsLimit) budget = kLdsLimit;
     const int ncomp = p->is_complex ? 2 : 1;
     const int rb = (int)real_bytes(p);
-    const int max_waves = std::max(p->spread_threads, p->interp_threads) / 64;
-    const LdsLayout probe = lds_layout(0, 8, rb, p->D, p->M, ncomp, max_waves);
     int forced[3] = {in->tile_dims[0], in->tile_dims[1], in->tile_dims[2]};
     if (forced[0] <= 0) {
         const char* e = std::getenv("NUFFT_TILE");
@@ -215,8 +213,19 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
             if (n >= 1) { forced[0] = a; forced[1] = n >= 2 ? b : a; forced[2] = n >= 3 ? c : (n >= 2 ? b : a); }
         }
     }
-    // the spreading tile accumulates in Float64 whatever the plan's precision (lds_layout)
-    if (!choose_tile(p->D, p->M, ncomp, 8, p->Nover, budget, probe.total, forced, p->tile)) {
+    // The spreading tile accumulates in Float64 whatever the plan's precision (lds_layout).  When the
+    // per-wave staging strips leave no room for even the smallest tile (large M), fall back to fewer
+    // waves per workgroup before giving up.
+    bool found = false;
+    for (;;) {
+        const int max_waves = std::max(p->spread_threads, p->interp_threads) / 64;
+        const LdsLayout probe = lds_layout(0, 8, rb, p->D, p->M, ncomp, max_waves);
+        if (choose_tile(p->D, p->M, ncomp, 8, p->Nover, budget, probe.total, forced, p->tile)) { found = true; break; }
+        if (max_waves == 1) break;
+        p->spread_threads = std::max(64, p->spread_threads / 2);
+        p->interp_threads = std::max(64, p->interp_threads / 2);
+    }
+    if (!found) {
         return fail(NUFFT_ERR_LDS_TOO_SMALL,
                     "LDS is too small for the chosen problem (element type, half-support M, dimensions): "
                     "reduce M or the tile size");

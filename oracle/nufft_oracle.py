@@ -485,7 +485,7 @@ def exec_type2(plan: OraclePlan, uhat, return_grid: bool = False):
         ntot = int(np.prod(plan.Nover))
         if plan.is_real:
             # brfft: unnormalised c2r of length Nover[0] along dim 1
-            u = np.fft.irfftn(uh, s=tuple(reversed(plan.Nover))) * ntot
+            u = np.fft.irfftn(uh, s=tuple(reversed(plan.Nover)), axes=tuple(range(plan.ndim))) * ntot
             u = u.astype(plan.dtype)
         else:
             u = (np.fft.ifftn(uh) * ntot).astype(plan.cdtype)
