@@ -147,9 +147,14 @@ def test_spread_and_interp_stages_match_oracle(Z):
     # interpolate from the grid that is now in the plan
     out = torch.empty(Np, dtype=plan.Z, device=dev)
     nufft.interpolate(plan, out)
-    ref2 = O.interpolate(oplan, [grid])[0]       # oracle windows are un-normalised; grid was rescaled above
+    # The oracle's windows are un-normalised (peak e^β/2π per dimension) and the grid holds raw spread
+    # values here, so a Float32 oracle would overflow: evaluate the expectation in Float64 from the same
+    # Float32-rounded inputs.
+    o64 = O.OraclePlan(dims, is_real=oplan.is_real, dtype=np.float64, M=M, sigma=sigma, evalmode=O.DIRECT)
+    O.set_points(o64, [x.astype(np.float64) for x in xs])
+    ref2 = O.interpolate(o64, [grid.astype(wide)])[0]
     got = out.cpu().numpy().astype(wide) / scale / scale
-    assert _rel(got, ref2) < (1e-12 if Z == np.float64 else 1e-5)
+    assert _rel(got, ref2) < (1e-12 if Z == np.float64 else 2e-5)
 
 
 def test_bin_sort_is_a_permutation_grouped_by_tile():
