@@ -22,16 +22,33 @@ __global__ __launch_bounds__(512) void lds_kernel(T* out, int iters, int stride)
     if (MODE == 0) off = (lane & 7) + (lane >> 3) * stride;          // 8x8 face
     else if (MODE == 1) off = 0;                                      // same address
     else if (MODE == 2) off = (lane * 97 + wave * 13) & 4095;         // scattered
-    else off = lane;                                                  // contiguous 64
+    else if (MODE == 3) off = lane;                                   // contiguous 64
+    else off = (lane & 7);                                            // MODE 4/5/6: 8 random 8-element segments
     T acc = T(0);
     T v = T(1) + T(lane) * T(1e-3);
     int base = wave * 37;
     for (int it = 0; it < iters; ++it) {
+        if (MODE >= 4) {
+            // pseudo-random segment base per 8-lane group, changing every iteration
+            unsigned h = (unsigned)(it * 2654435761u) ^ (unsigned)((lane >> 3) * 40503u + wave * 9176u);
+            h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+            const int seg = (int)(h & 2047) * (MODE == 6 ? 8 : 1);       // MODE 6: 64-B aligned segments
+            const bool active = MODE != 5 || (lane & 4) == 0;              // MODE 5: half of the lanes masked
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                T* p = tile + ((seg + off + j * 24) & 16383);
+                if (active) {
+                    if (ATOMIC) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else acc += *p;
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             T* p = tile + ((base + off + j * 648) & 16383);
             if (ATOMIC) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else acc += *p;
+        }
         }
         base = (base + 5) & 1023;
     }
@@ -111,7 +128,13 @@ void run_flush(const char* name, int n1, int n2, int n3, int halo) {
 
 int main() {
     printf("== LDS atomics / reads (8 per iteration, 16K-element tile) ==\n");
-    for (int threads : {256, 512, 1024}) {
+    for (int threads : {256, 512}) {
+        run_lds<double, 4, true>("ds_add_f64 8 random 8-double segments", threads, 1, 0);
+        run_lds<double, 6, true>("ds_add_f64 8 random aligned segments", threads, 1, 0);
+        run_lds<double, 5, true>("ds_add_f64 random segments, half lanes", threads, 1, 0);
+        run_lds<double, 4, false>("ds_read_b64 8 random 8-double segments", threads, 1, 0);
+        run_lds<double, 6, false>("ds_read_b64 8 random aligned segments", threads, 1, 0);
+        run_lds<float, 4, false>("ds_read_b32 8 random 8-float segments", threads, 1, 0);
         run_lds<double, 0, true>("ds_add_f64 8x8 face stride 24", threads, 1, 24);
         run_lds<double, 0, true>("ds_add_f64 8x8 face stride 32", threads, 1, 32);
         run_lds<double, 3, true>("ds_add_f64 contiguous 64", threads, 1, 0);

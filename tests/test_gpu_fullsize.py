@@ -1,0 +1,109 @@
+"""Full-size parity at BASELINE config C2 (256^3, Np = 1e7, Float64, m = 4, sigma = 2), where the CPU
+oracle is too slow: size-independent properties and exact spot checks computed on the GPU with plain
+torch arithmetic (O(Np) per mode, O(N^3) per point)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N, NP, M, SIGMA = 256, 10_000_000, 4, 2.0
+CEIL = 6 * 10.0 ** (-1.9 * M)        # test/accuracy.jl:33-35 (1.5e-7 at m = 4, sigma = 2)
+
+
+@pytest.fixture(scope="module")
+def case():
+    from nufft_pkg import nufft
+    plan = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, backend=nufft.ROCBackend(0))
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    xs = tuple(torch.rand(NP, dtype=torch.float64, device="cuda", generator=g) * (2 * np.pi) for _ in range(3))
+    v = torch.randn(NP, dtype=torch.float64, device="cuda", generator=g)
+    nufft.set_points(plan, xs)
+    u = torch.empty(plan.shape, dtype=torch.complex128, device="cuda")
+    nufft.exec_type1(u, plan, v)
+    return nufft, plan, xs, v, u
+
+
+def _wavenumbers(plan):
+    k1 = torch.arange(N // 2 + 1, dtype=torch.float64, device="cuda")
+    k = torch.arange(N, dtype=torch.float64, device="cuda")
+    k = torch.where(k >= (N + 1) // 2, k - N, k)
+    return k1, k, k
+
+
+def test_type1_spot_modes_against_exact_sum(case):
+    nufft, plan, xs, v, u = case
+    k1, k2, k3 = _wavenumbers(plan)
+    rng = np.random.default_rng(0)
+    num = den = 0.0
+    for _ in range(24):
+        i1, i2, i3 = int(rng.integers(0, N // 2 + 1)), int(rng.integers(0, N)), int(rng.integers(0, N))
+        phase = k1[i1] * xs[0] + k2[i2] * xs[1] + k3[i3] * xs[2]
+        exact = torch.complex((v * torch.cos(phase)).sum(), -(v * torch.sin(phase)).sum())
+        got = u[i3, i2, i1]
+        num += float((got - exact).abs() ** 2)
+        den += float(exact.abs() ** 2)
+    assert np.sqrt(num / den) < 2 * CEIL
+
+
+def test_type2_spot_points_against_exact_sum(case):
+    nufft, plan, xs, v, u = case
+    g = torch.Generator(device="cuda").manual_seed(7)
+    w = torch.complex(torch.randn(plan.shape, dtype=torch.float64, device="cuda", generator=g),
+                      torch.randn(plan.shape, dtype=torch.float64, device="cuda", generator=g))
+    out = torch.empty(NP, dtype=torch.float64, device="cuda")
+    nufft.exec_type2(out, plan, w)
+    k1, k2, k3 = _wavenumbers(plan)
+    h = torch.full((N // 2 + 1,), 2.0, dtype=torch.float64, device="cuda")
+    h[0] = 1.0                                    # Hermitian weights, test/accuracy.jl:184-186
+    num = den = 0.0
+    for j in np.random.default_rng(1).integers(0, NP, 16):
+        e1 = torch.polar(h, k1 * xs[0][j])
+        e2 = torch.polar(torch.ones_like(k2), k2 * xs[1][j])
+        e3 = torch.polar(torch.ones_like(k3), k3 * xs[2][j])
+        exact = torch.einsum("cba,c,b,a->", w, e3, e2, e1).real
+        num += float((out[j] - exact) ** 2)
+        den += float(exact ** 2)
+    assert np.sqrt(num / den) < 2 * CEIL
+
+
+def test_linearity_and_adjointness(case):
+    nufft, plan, xs, v, u = case
+    g = torch.Generator(device="cuda").manual_seed(99)
+    v2 = torch.randn(NP, dtype=torch.float64, device="cuda", generator=g)
+    u2 = torch.empty_like(u)
+    nufft.exec_type1(u2, plan, v2)
+    u3 = torch.empty_like(u)
+    nufft.exec_type1(u3, plan, 0.75 * v - 2.5 * v2)
+    lin = (u3 - (0.75 * u - 2.5 * u2)).norm() / u3.norm()
+    assert float(lin) < 1e-12                     # atomics reorder the sums: round-off level, not bitwise
+    # adjointness: sum_j v_j (T2 w)_j == Re sum_k h(k1) w_k conj((T1 v)_k)
+    w = torch.complex(torch.randn(plan.shape, dtype=torch.float64, device="cuda", generator=g),
+                      torch.randn(plan.shape, dtype=torch.float64, device="cuda", generator=g))
+    out = torch.empty(NP, dtype=torch.float64, device="cuda")
+    nufft.exec_type2(out, plan, w)
+    h = torch.full((N // 2 + 1,), 2.0, dtype=torch.float64, device="cuda")
+    h[0] = 1.0
+    lhs = float((v * out).sum())
+    rhs = float((h * (w * u.conj()).real).sum())
+    scale = float(v.norm() * out.norm())
+    assert abs(lhs - rhs) / scale < 1e-6
+
+
+def test_repeatability_and_reuse(case):
+    """Same inputs twice: identical up to the summation order of the atomics; set_points with a smaller
+    point set afterwards reuses the plan's buffers correctly."""
+    nufft, plan, xs, v, u = case
+    ub = torch.empty_like(u)
+    nufft.exec_type1(ub, plan, v)
+    assert float((ub - u).norm() / u.norm()) < 1e-13
+    n = 1000
+    xs_small = tuple(x[:n].contiguous() for x in xs)
+    nufft.set_points(plan, xs_small)
+    us = torch.empty_like(u)
+    nufft.exec_type1(us, plan, v[:n].contiguous())
+    k1, k2, k3 = _wavenumbers(plan)
+    phase = k1[5] * xs_small[0] + k2[250] * xs_small[1] + k3[3] * xs_small[2]
+    exact = torch.complex((v[:n] * torch.cos(phase)).sum(), -(v[:n] * torch.sin(phase)).sum())
+    assert float((us[3, 250, 5] - exact).abs() / exact.abs()) < 1e-5
+    nufft.set_points(plan, xs)                    # restore for other tests
