@@ -112,8 +112,7 @@ def main():
         if ev: ev[0].record()
         nufft.set_points(plan, xs)
         if ev: ev[1].record()
-        _check(lib.nufft_fill_zeros(plan._handle, s))
-        if ev: ev[2].record()
+        if ev: ev[2].record()      # "(0) fill with zeros" no longer exists: the spreading kernel writes every cell
         _check(lib.nufft_spread(plan._handle, _ptr_table((vp,)), s))
         if ev: ev[3].record()
         _check(lib.nufft_fft_forward(plan._handle, s))
@@ -212,7 +211,8 @@ def main():
                         f"m={a.m}, sigma={a.sigma} (oversampled {plan.oversampled_dims}), "
                         f"{'Direct' if a.evalmode == 'direct' else 'FastApproximation'} window",
             "protocol": "set_points! + exec_type1! per step, inputs resident in HBM (reference benchmark protocol)",
-            "tile": [int(info.tile_dims[d]) for d in range(3)],
+            "spread_tile": [int(info.spread_tile[d]) for d in range(3)],
+            "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
             "lds_bytes": int(info.lds_bytes_spread),
             "parallelism": f"{world} independent plan(s), one per GPU" + ("" if world == 1 or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
         },

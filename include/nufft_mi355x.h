@@ -87,11 +87,13 @@ typedef struct nufft_params {
     int32_t gpu_method;      /* NUFFT_METHOD_*                                                     */
     int32_t device;          /* HIP device ordinal; -1 = host-only plan (parameter math only)      */
     /* --- MI355X tuning knobs (0 = automatic) --- */
-    int32_t tile_dims[3];    /* LDS tile interior n_d (replaces block_dims_gpu_shmem's cube)       */
+    int32_t tile_dims[3];    /* spreading tile (cells; replaces block_dims_gpu_shmem's cube)       */
     int32_t lds_budget_bytes;/* LDS bytes the tile search may use (<= 163840 on gfx950)            */
     int32_t spread_threads;  /* workgroup size of the spreading kernel (multiple of 64)            */
     int32_t interp_threads;  /* workgroup size of the interpolation kernel                         */
-    int32_t reserved[8];
+    int32_t interp_tile_dims[3]; /* interpolation tile interior (cells)                            */
+    int32_t bin_log2;        /* log2 of the bin edge of the point sort (default 2: 4^D cells)      */
+    int32_t reserved[4];
 } nufft_params;
 
 /* What show(::PlanNUFFT) prints (src/plan.jl:362-392) plus sizes a caller needs. */
@@ -102,10 +104,12 @@ typedef struct nufft_info {
     int64_t N_out[3];        /* size(p): dims of the uniform arrays (src/plan.jl:426)              */
     double  sigma;           /* actual sigma = max(N_over / N) (src/plan.jl:500)                   */
     double  beta[3];         /* kernel shape parameter per dimension                               */
-    int32_t tile_dims[3];    /* LDS tile interior                                                  */
-    int32_t tile_padded[3];  /* interior + 2M - 1                                                  */
-    int32_t tile_row_stride; /* LDS row stride in real elements (bank-conflict padding)            */
-    int32_t ntiles[3];       /* tiles per dimension = cld(N_over, tile_dims)                       */
+    int32_t bin_dims[3];     /* cells per sort bin                                                 */
+    int32_t nbins[3];        /* bins per dimension                                                 */
+    int32_t spread_tile[3];  /* spreading tile: interior cells held in LDS (no halo)               */
+    int32_t spread_ntiles[3];
+    int32_t interp_tile[3];  /* interpolation tile interior; LDS holds interior + 2M - 1           */
+    int32_t interp_ntiles[3];
     int32_t spread_threads, interp_threads;
     int64_t lds_bytes_spread, lds_bytes_interp;
     int64_t workspace_bytes; /* device bytes owned by the plan right now                           */

@@ -41,7 +41,8 @@ class NufftParams(C.Structure):
         ("device", C.c_int32),
         ("tile_dims", C.c_int32 * 3),
         ("lds_budget_bytes", C.c_int32), ("spread_threads", C.c_int32), ("interp_threads", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("interp_tile_dims", C.c_int32 * 3), ("bin_log2", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -51,8 +52,9 @@ class NufftInfo(C.Structure):
         ("ntransforms", C.c_int32), ("evalmode", C.c_int32), ("fftshift", C.c_int32), ("device", C.c_int32),
         ("N", C.c_int64 * 3), ("N_over", C.c_int64 * 3), ("N_out", C.c_int64 * 3),
         ("sigma", C.c_double), ("beta", C.c_double * 3),
-        ("tile_dims", C.c_int32 * 3), ("tile_padded", C.c_int32 * 3), ("tile_row_stride", C.c_int32),
-        ("ntiles", C.c_int32 * 3),
+        ("bin_dims", C.c_int32 * 3), ("nbins", C.c_int32 * 3),
+        ("spread_tile", C.c_int32 * 3), ("spread_ntiles", C.c_int32 * 3),
+        ("interp_tile", C.c_int32 * 3), ("interp_ntiles", C.c_int32 * 3),
         ("spread_threads", C.c_int32), ("interp_threads", C.c_int32),
         ("lds_bytes_spread", C.c_int64), ("lds_bytes_interp", C.c_int64),
         ("workspace_bytes", C.c_int64), ("num_points", C.c_int64),

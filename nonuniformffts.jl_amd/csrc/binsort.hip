@@ -1,8 +1,8 @@
-// set_points!: bin-sort of the non-uniform points by LDS tile.
+// set_points!: bin-sort of the non-uniform points by fine bins (4^D cells by default).
 //
 // Replaces set_points_impl!(::GPU, ...) of the reference (src/blocking/gpu.jl:73-142):
 //   K2 assign_blocks_kernel!  (:162-180)  -> bin_count_kernel   (histogram + rank)
-//   K3 AK.accumulate!         (:112-115)  -> hipcub exclusive scan over ntiles + 1 counters
+//   K3 AK.accumulate!         (:112-115)  -> hipcub exclusive scan over nbins + 1 counters
 //   K4 sortperm_kernel!       (:182-198)  \
 //   K5 permute_kernel!        (:200-212)  -> bin_scatter_kernel (fused: writes one aligned record
 //                                            {r_1..r_D, original index} per point in tile order)
@@ -24,19 +24,20 @@ struct BinArgs {
     Geom g;
 };
 
+// Linear index of the fine bin of point p (dimension 1 fastest); the analogue of block_index,
+// src/blocking/gpu.jl:145-160, with power-of-two bins so that the division is a shift.
 template <typename T, int D>
 __device__ __forceinline__ uint32_t tile_of_point(const BinArgs<T, D>& a, int64_t p, T (&r)[D]) {
-    uint32_t tile = 0, mul = 1;
+    uint32_t bin = 0, mul = 1;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const T xf = fold_to_unit_cell(a.x[d][p]);
         r[d] = to_grid_units(xf, a.g.Nover[d]);
         const int i = cell_of(r[d], a.g.Nover[d]);
-        const int t = i / a.g.n[d];                       // block_index, src/blocking/gpu.jl:145-160
-        tile += mul * (uint32_t)t;
-        mul *= (uint32_t)a.g.nt[d];
+        bin += mul * (uint32_t)(i >> a.g.blog[d]);
+        mul *= (uint32_t)a.g.nb[d];
     }
-    return tile;
+    return bin;
 }
 
 template <typename T, int D>
@@ -75,7 +76,7 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
     for (int d = 0; d < 3; ++d) a.x[d] = d < D ? static_cast<const T*>(s.coords[d]) : nullptr;
     a.np = s.np;
     a.g = s.g;
-    hipError_t e = hipMemsetAsync(s.counts, 0, sizeof(uint32_t) * (size_t)(s.g.ntiles + 1), stream);
+    hipError_t e = hipMemsetAsync(s.counts, 0, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
     if (e != hipSuccess) return e;
     if (s.np > 0) {
         const int threads = 256;
@@ -85,7 +86,7 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
                            static_cast<uint2*>(s.binrank));
     }
     size_t tmp = s.scan_tmp_bytes;
-    e = hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.ntiles + 1, stream);
+    e = hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.nbins + 1, stream);
     if (e != hipSuccess) return e;
     if (s.np > 0) {
         const int threads = 256;
@@ -97,10 +98,10 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
     return hipGetLastError();
 }
 
-size_t binsort_scan_tmp_bytes(int ntiles) {
+size_t binsort_scan_tmp_bytes(int nbins) {
     size_t bytes = 0;
     uint32_t* p = nullptr;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, p, p, ntiles + 1, (hipStream_t)0);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, p, p, nbins + 1, (hipStream_t)0);
     return bytes < 16 ? 16 : bytes;
 }
 

@@ -7,8 +7,6 @@
 namespace nufft {
 
 constexpr int kWave = 64;
-constexpr int kCH = 16;                 // points staged per wave per chunk (== kChunk on the host)
-constexpr int kParts = kWave / kCH;     // lanes cooperating on one staged point
 constexpr int kMaxCompPerLaunch = 8;    // components (ntransforms) handled by one launch
 
 template <typename T> struct TwoPi;
@@ -29,15 +27,30 @@ static_assert(sizeof(PointRec<double, 1>) == 16, "record layout");
 static_assert(sizeof(PointRec<float, 1>) == 8, "record layout");
 
 // Geometry passed by value to every kernel.
+//
+// Points are bin-sorted by *fine bins* of b_d cells (b_d a power of two, 4 by default); the bin index
+// runs with dimension 1 fastest.  Spreading and interpolation then tile the grid independently, with
+// tile edges that are multiples of the bin size:
+//   * spreading tile: the INTERIOR only lives in LDS ("output-driven": the workgroup visits every point
+//     whose stencil touches its tile, clips the stencil, and stores the finished tile with plain
+//     coalesced stores — no global atomics, no zero fill of the grid);
+//   * interpolation tile: interior + (2M-1) halo in LDS, every point visited exactly once.
+struct TileShape {
+    int n[3];          // interior cells per dimension
+    int nt[3];         // tiles per dimension
+    int row_stride;    // LDS row stride in reals
+    int plane_stride;  // row_stride * rows per plane
+    int elems;         // LDS reals of the tile
+    int ntiles;
+};
+
 struct Geom {
-    int Nover[3];     // oversampled grid
-    int n[3];         // tile interior
-    int P[3];         // padded tile = n + 2M - 1
-    int nt[3];        // tiles per dimension
-    int row_stride;   // LDS row stride in reals (>= ncomp * P[0])
-    int plane_stride; // row_stride * P[1]
-    int tile_elems;   // plane_stride * P[2]
-    int ntiles;       // nt[0] * nt[1] * nt[2]
+    int Nover[3];      // oversampled grid
+    int blog[3];       // log2 of the bin size
+    int nb[3];         // bins per dimension
+    int nbins;
+    TileShape sp;      // spreading tile (interior only)
+    TileShape ip;      // interpolation tile (n = interior; LDS holds n + 2M - 1 per dimension)
 };
 
 // to_unit_cell_gpu, reference src/blocking/blocking.jl:26-33.
@@ -88,24 +101,23 @@ constexpr __host__ __device__ int next_pow2(int x) {
 
 constexpr __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
-// LDS layout shared by host (size computation) and kernels.
-//   [tile | polynomial coefficients | per-wave staging]
+// LDS layout shared by host (size computation) and kernels:  [tile | per-wave window strips].
+// The spreading tile always accumulates in Float64 (ds_add_f32 is ~22x slower than ds_add_f64 on
+// gfx950: 193 vs 8.5 cycles per wave instruction, scripts/microbench.hip); the interpolation tile holds
+// the grid's own precision.
+constexpr __host__ __device__ int lanes_per_point(int ncomp, int M) { return next_pow2(ncomp * 2 * M); }
+
 struct LdsLayout {
-    int tile_bytes, coef_bytes, stage_bytes_per_wave, total;
+    int tile_bytes, strip_bytes_per_wave, total;
 };
 
-// tile_elem_bytes: the spreading tile always accumulates in Float64 (ds_add_f32 is ~22x slower than
-// ds_add_f64 on gfx950: 193 vs 8.5 cycles per wave instruction, scripts/microbench.hip), the
-// interpolation tile holds the grid's own precision.
 constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int tile_elem_bytes, int real_bytes, int D, int M,
                                                    int ncomp, int nwaves) {
     LdsLayout l{};
     l.tile_bytes = round_up(tile_elems * tile_elem_bytes, 16);
-    l.coef_bytes = round_up(D * (M + 4) * 2 * M * real_bytes, 16);
-    // per staged point: D*2M window values, ncomp value components (or results), D local starts
-    int per_point = (D * 2 * M + ncomp) * real_bytes + D * 4;
-    l.stage_bytes_per_wave = round_up(kCH * per_point, 16);
-    l.total = l.tile_bytes + l.coef_bytes + nwaves * l.stage_bytes_per_wave;
+    const int ppw = kWave / lanes_per_point(ncomp, M);           // points a wave works on at once
+    l.strip_bytes_per_wave = round_up(ppw * D * 2 * M * real_bytes, 16);
+    l.total = l.tile_bytes + nwaves * l.strip_bytes_per_wave;
     return l;
 }
 

@@ -3,4 +3,5 @@
 #define NUFFT_CPLX false
 #define NUFFT_KERNEL interp_tile_kernel
 #define NUFFT_GETTER interp_kernel_f32r
+#define NUFFT_HAS_WRAP_VARIANT 0
 #include "tile_inst.h"

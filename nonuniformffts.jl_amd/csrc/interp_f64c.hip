@@ -3,4 +3,5 @@
 #define NUFFT_CPLX true
 #define NUFFT_KERNEL interp_tile_kernel
 #define NUFFT_GETTER interp_kernel_f64c
+#define NUFFT_HAS_WRAP_VARIANT 0
 #include "tile_inst.h"

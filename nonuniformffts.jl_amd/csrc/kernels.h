@@ -15,14 +15,14 @@ struct SortArgs {
     int64_t np;
     const void* coords[3];
     Geom g;
-    uint32_t* counts;      // [ntiles + 1]
-    uint32_t* offsets;     // [ntiles + 1]
+    uint32_t* counts;      // [nbins + 1]
+    uint32_t* offsets;     // [nbins + 1]
     void* binrank;         // uint2[np]
     void* sorted;          // PointRec<T, D>[np]
     void* scan_tmp;
     size_t scan_tmp_bytes;
 };
-size_t binsort_scan_tmp_bytes(int ntiles);
+size_t binsort_scan_tmp_bytes(int nbins);
 size_t point_record_bytes(int dtype, int D);
 hipError_t launch_binsort(const SortArgs& s, hipStream_t stream);
 hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np, int32_t* perm_dev, hipStream_t stream);
@@ -32,7 +32,7 @@ struct TileKernelArgs {
     int dtype, is_complex, D, M, evalmode, C;
     Geom g;
     const void* sorted;        // PointRec<T, D>[np]
-    const uint32_t* offsets;   // [ntiles + 1]
+    const uint32_t* offsets;   // [nbins + 1]
     const void* coefs;         // T[D][npoly][2M]
     double beta[3];
     double beta_over_pi[3];    // (β/π) * 2^scale_exp, see plan.cpp
@@ -43,6 +43,7 @@ struct TileKernelArgs {
     double prefactor;          // interp: prod(dx_d)
     int threads;
     int lds_bytes;
+    int ntiles;                // workgroups per component
 };
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
 hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);

@@ -17,7 +17,6 @@ constexpr int kMaxDim = 3;
 constexpr int kMinM = 2;
 constexpr int kMaxM = 10;
 constexpr int kLdsLimit = 163840;      // gfx950: 160 KiB per workgroup
-constexpr int kChunk = 16;             // points staged per wave and chunk (see spread.hip)
 
 void set_error(const std::string& msg);
 
@@ -38,21 +37,29 @@ void fourier_coefficients(const std::vector<double>& ks, int M, int64_t Nover, d
 void non_oversampled_indices(const std::vector<double>& ks, int64_t n_axis, bool fftshift,
                              std::vector<int64_t>& indmap);
 
-// Geometry of the LDS tiling (all values per dimension; unused dimensions are 1 / 0).
-struct TileGeom {
-    int n[kMaxDim] = {1, 1, 1};        // interior
-    int P[kMaxDim] = {1, 1, 1};        // padded = n + 2M - 1
-    int nt[kMaxDim] = {1, 1, 1};       // number of tiles
-    int row_stride = 0;                // LDS row stride in real elements
-    int64_t tile_elems = 0;            // row_stride * P[1] * P[2] (real elements)
-    int64_t ntiles_total = 1;
+// Geometry of the fine bins and of the two LDS tilings (host mirror of device_common.h's Geom).
+struct TileShapeHost {
+    int n[kMaxDim] = {1, 1, 1};        // interior cells
+    int nt[kMaxDim] = {1, 1, 1};       // tiles per dimension
+    int row_stride = 0;                // LDS row stride in reals
+    int rows[2] = {1, 1};              // LDS rows per plane, planes
+    int64_t elems = 0;                 // LDS reals
+    int64_t ntiles = 1;
 };
 
-// Chooses the tile interior that minimises the halo amplification under the LDS budget.
-// Returns false if not even the smallest tile fits (-> NUFFT_ERR_LDS_TOO_SMALL).
-bool choose_tile(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
-                 int lds_budget_bytes, int staging_bytes, const int* forced, TileGeom& g);
-int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes);
+struct TileGeom {
+    int blog[kMaxDim] = {0, 0, 0};     // log2(bin size)
+    int nb[kMaxDim] = {1, 1, 1};       // bins per dimension
+    int64_t nbins = 1;
+    TileShapeHost sp;                  // spreading tile: interior only in LDS (Float64)
+    TileShapeHost ip;                  // interpolation tile: interior + 2M - 1 halo in LDS
+};
+
+// Chooses bins and both tile shapes under the LDS budget; `forced_*` (cells, 0 = automatic) override
+// the search.  Returns false if not even the smallest tile fits (-> NUFFT_ERR_LDS_TOO_SMALL).
+bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,
+                  int spread_waves, int interp_waves, const int* forced_sp, const int* forced_ip, int bin_log2,
+                  TileGeom& g);
 
 }  // namespace nufft
 

@@ -45,18 +45,29 @@ static std::once_flag g_rocfft_once;
 static size_t real_bytes(const nufft_plan* p) { return p->dtype == NUFFT_F32 ? 4 : 8; }
 static size_t value_bytes(const nufft_plan* p) { return real_bytes(p) * (p->is_complex ? 2 : 1); }
 
+static TileShape make_shape(const nufft::TileShapeHost& h) {
+    TileShape t{};
+    for (int d = 0; d < 3; ++d) {
+        t.n[d] = h.n[d];
+        t.nt[d] = h.nt[d];
+    }
+    t.row_stride = h.row_stride;
+    t.plane_stride = h.row_stride * h.rows[0];
+    t.elems = (int)h.elems;
+    t.ntiles = (int)h.ntiles;
+    return t;
+}
+
 static Geom make_geom(const nufft_plan* p) {
     Geom g{};
     for (int d = 0; d < 3; ++d) {
         g.Nover[d] = (int)p->Nover[d];
-        g.n[d] = p->tile.n[d];
-        g.P[d] = p->tile.P[d];
-        g.nt[d] = p->tile.nt[d];
+        g.blog[d] = p->tile.blog[d];
+        g.nb[d] = p->tile.nb[d];
     }
-    g.row_stride = p->tile.row_stride;
-    g.plane_stride = p->tile.row_stride * p->tile.P[1];
-    g.tile_elems = (int)p->tile.tile_elems;
-    g.ntiles = (int)p->tile.ntiles_total;
+    g.nbins = (int)p->tile.nbins;
+    g.sp = make_shape(p->tile.sp);
+    g.ip = make_shape(p->tile.ip);
     return g;
 }
 
@@ -195,44 +206,44 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         non_oversampled_indices(ks, p->Nspec[d], p->fftshift, p->index_map[d]);
     }
 
-    // tile geometry
-    p->spread_threads = in->spread_threads > 0 ? in->spread_threads : env_int("NUFFT_SPREAD_THREADS", 512);
-    p->interp_threads = in->interp_threads > 0 ? in->interp_threads : env_int("NUFFT_INTERP_THREADS", 512);
-    if (p->spread_threads % 64 || p->interp_threads % 64 || p->spread_threads > 1024 || p->interp_threads > 1024)
-        return fail(NUFFT_ERR_INVALID_ARG, "workgroup sizes must be multiples of 64 and <= 1024");
+    // bins and tile geometry
+    p->spread_threads = in->spread_threads > 0 ? in->spread_threads : env_int("NUFFT_SPREAD_THREADS", 1024);
+    p->interp_threads = in->interp_threads > 0 ? in->interp_threads : env_int("NUFFT_INTERP_THREADS", 1024);
+    if (p->spread_threads % 64 || p->interp_threads % 64 || p->spread_threads > 1024 || p->interp_threads > 1024 ||
+        p->spread_threads < 64 || p->interp_threads < 64)
+        return fail(NUFFT_ERR_INVALID_ARG, "workgroup sizes must be multiples of 64 in 64..1024");
     int budget = in->lds_budget_bytes > 0 ? in->lds_budget_bytes : env_int("NUFFT_LDS_BUDGET", kLdsLimit);
-    if (budget > kLdsLimit) budget = kLdsLimit;
+    if (budget > kLdsLimit - 256) budget = kLdsLimit - 256;   // small margin for compiler-generated LDS
     const int ncomp = p->is_complex ? 2 : 1;
     const int rb = (int)real_bytes(p);
-    int forced[3] = {in->tile_dims[0], in->tile_dims[1], in->tile_dims[2]};
-    if (forced[0] <= 0) {
-        const char* e = std::getenv("NUFFT_TILE");
-        if (e && *e) {
+    int forced_sp[3] = {in->tile_dims[0], in->tile_dims[1], in->tile_dims[2]};
+    int forced_ip[3] = {in->interp_tile_dims[0], in->interp_tile_dims[1], in->interp_tile_dims[2]};
+    auto env_tile = [](const char* name, int* out) {
+        const char* e = std::getenv(name);
+        if (e && *e && out[0] <= 0) {
             int a = 0, b = 0, c = 0;
             const int n = std::sscanf(e, "%d,%d,%d", &a, &b, &c);
-            if (n >= 1) { forced[0] = a; forced[1] = n >= 2 ? b : a; forced[2] = n >= 3 ? c : (n >= 2 ? b : a); }
+            if (n >= 1) { out[0] = a; out[1] = n >= 2 ? b : a; out[2] = n >= 3 ? c : (n >= 2 ? b : a); }
         }
-    }
-    // The spreading tile accumulates in Float64 whatever the plan's precision (lds_layout).  When the
-    // per-wave staging strips leave no room for even the smallest tile (large M), fall back to fewer
-    // waves per workgroup before giving up.
+    };
+    env_tile("NUFFT_SPREAD_TILE", forced_sp);
+    env_tile("NUFFT_INTERP_TILE", forced_ip);
+    int bin_log2 = in->bin_log2 > 0 ? in->bin_log2 : env_int("NUFFT_BIN_LOG2", 2);
+    if (bin_log2 < 1 || bin_log2 > 4) return fail(NUFFT_ERR_INVALID_ARG, "bin_log2 must be in 1..4");
+    // Tile edges are multiples of the bin edge; when even one bin plus halo overflows the LDS (large M,
+    // complex Float64) retry with smaller bins down to single cells.
     bool found = false;
-    for (;;) {
-        const int max_waves = std::max(p->spread_threads, p->interp_threads) / 64;
-        const LdsLayout probe = lds_layout(0, 8, rb, p->D, p->M, ncomp, max_waves);
-        if (choose_tile(p->D, p->M, ncomp, 8, p->Nover, budget, probe.total, forced, p->tile)) { found = true; break; }
-        if (max_waves == 1) break;
-        p->spread_threads = std::max(64, p->spread_threads / 2);
-        p->interp_threads = std::max(64, p->interp_threads / 2);
-    }
+    for (; bin_log2 >= 0 && !found; --bin_log2)
+        found = choose_tiles(p->D, p->M, ncomp, rb, p->Nover, budget, p->spread_threads / 64, p->interp_threads / 64,
+                             forced_sp, forced_ip, bin_log2, p->tile);
     if (!found) {
         return fail(NUFFT_ERR_LDS_TOO_SMALL,
                     "LDS is too small for the chosen problem (element type, half-support M, dimensions): "
                     "reduce M or the tile size");
     }
-    p->lds_spread = lds_layout((int)p->tile.tile_elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64).total;
-    p->lds_interp = lds_layout((int)p->tile.tile_elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64).total;
-    if (p->tile.ntiles_total >= ((int64_t)1 << 31) - 2) return fail(NUFFT_ERR_UNSUPPORTED, "too many tiles");
+    p->lds_spread = lds_layout((int)p->tile.sp.elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64).total;
+    p->lds_interp = lds_layout((int)p->tile.ip.elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64).total;
+    if (p->tile.nbins >= ((int64_t)1 << 31) - 2) return fail(NUFFT_ERR_UNSUPPORTED, "too many bins");
     return NUFFT_OK;
 }
 
@@ -288,10 +299,10 @@ static int build_device(nufft_plan* p) {
     }
 
     // bin-sort scratch that does not depend on Np
-    const size_t nt1 = (size_t)p->tile.ntiles_total + 1;
+    const size_t nt1 = (size_t)p->tile.nbins + 1;
     if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_counts), nt1 * sizeof(uint32_t)))) return rc;
     if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_offsets), nt1 * sizeof(uint32_t)))) return rc;
-    p->scan_tmp_bytes = binsort_scan_tmp_bytes((int)p->tile.ntiles_total);
+    p->scan_tmp_bytes = binsort_scan_tmp_bytes((int)p->tile.nbins);
     if ((rc = dev_alloc(p, &p->d_scan_tmp, p->scan_tmp_bytes))) return rc;
 
     // rocFFT plans (plan_rfft / plan_brfft / plan_fft! / plan_bfft!, src/plan.jl:45-46,57-58)
@@ -392,6 +403,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     }
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
+    a.ntiles = (int)(interp ? p->tile.ip.ntiles : p->tile.sp.ntiles);
     return a;
 }
 
@@ -523,13 +535,15 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
         o->N_over[d] = d < p->D ? p->Nover[d] : 1;
         o->N_out[d] = d < p->D ? p->Nout[d] : 1;
         o->beta[d] = p->beta[d];
-        o->tile_dims[d] = p->tile.n[d];
-        o->tile_padded[d] = p->tile.P[d];
-        o->ntiles[d] = p->tile.nt[d];
+        o->bin_dims[d] = d < p->D ? 1 << p->tile.blog[d] : 1;
+        o->nbins[d] = p->tile.nb[d];
+        o->spread_tile[d] = p->tile.sp.n[d];
+        o->spread_ntiles[d] = p->tile.sp.nt[d];
+        o->interp_tile[d] = p->tile.ip.n[d];
+        o->interp_ntiles[d] = p->tile.ip.nt[d];
         o->window_scale_log2[d] = d < p->D ? p->scale_exp[d] : 0;
     }
     o->sigma = p->sigma;
-    o->tile_row_stride = p->tile.row_stride;
     o->spread_threads = p->spread_threads;
     o->interp_threads = p->interp_threads;
     o->lds_bytes_spread = p->lds_spread;
@@ -621,7 +635,6 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_SPREAD, stream);
-    if (p->Np == 0) return NUFFT_OK;
     TileKernelArgs a = tile_args(p, false);
     a.values_in = values_in;
     NUFFT_HIP(launch_spread(a, stream));
@@ -696,7 +709,8 @@ int nufft_exec_type1(nufft_plan* p, void* const* uhat_out, const void* const* va
     int rc = require_points(p);
     if (rc) return rc;
     if (!uhat_out || !values_in) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
-    if ((rc = nufft_fill_zeros(p, stream))) return rc;                 // (0) src/NonuniformFFTs.jl:161-167
+    // (0) "Fill with zeros" (src/NonuniformFFTs.jl:161-167) is not needed: the output-driven spreading
+    // kernel stores every grid cell exactly once.
     if ((rc = nufft_spread(p, values_in, stream))) return rc;          // (1) :169-172
     if ((rc = nufft_fft_forward(p, stream))) return rc;                // (2) :174-177
     return nufft_deconvolve_truncate(p, uhat_out, stream);             // (3) :179-185
@@ -760,7 +774,7 @@ int nufft_get_sort_result(nufft_plan* p, int32_t* perm_host, int64_t perm_capaci
         }
     }
     if (tile_offsets_host) {
-        const int64_t n = p->tile.ntiles_total + 1;
+        const int64_t n = p->tile.nbins + 1;
         if (offsets_capacity < n) return fail(NUFFT_ERR_DIM_MISMATCH, "offset buffer too small");
         NUFFT_HIP(hipMemcpyAsync(tile_offsets_host, p->d_offsets, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         NUFFT_HIP(hipStreamSynchronize(stream));

@@ -168,9 +168,26 @@ void non_oversampled_indices(const std::vector<double>& ks, int64_t n_axis, bool
     }
 }
 
-// LDS row stride (in reals).  A wave instruction of the spreading / interpolation kernels touches
-// several consecutive rows, each with `stencil_inner` contiguous reals.  Rows land on disjoint
-// banks when the stride is congruent to the stencil width modulo the 128-byte bank period.
+static int strip_bytes(int D, int M, int ncomp, int real_bytes, int nwaves) {
+    int g = 1;
+    while (g < ncomp * 2 * M) g <<= 1;
+    const int ppw = 64 / g;
+    const int per_wave = (ppw * D * 2 * M * real_bytes + 15) / 16 * 16;
+    return nwaves * per_wave;
+}
+
+// Candidate tile edges along one axis: multiples of the bin size that leave room for the clipped halo
+// (n + 2M - 1 <= Ñ, so that a point has at most one periodic image next to the tile), or the whole axis.
+static void edge_candidates(int64_t N, int b, int M, int cap, std::vector<int>& out) {
+    out.clear();
+    for (int n = b; n < N && n <= cap; n += b)
+        if (n + 2 * M - 1 <= N) out.push_back(n);
+    if (N <= cap || out.empty()) out.push_back((int)N);      // single tile spanning the axis (wrap mode)
+}
+
+// LDS row stride (in Float64 reals) of the spreading tile.  A wave instruction of the accumulation
+// touches consecutive rows with `stencil_inner` contiguous reals each; the rows land on disjoint banks
+// when the stride is congruent to the stencil width modulo the 128-byte bank period.
 int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes) {
     static const bool no_pad = std::getenv("NUFFT_LDS_NO_PAD") != nullptr;
     const int period = 128 / real_bytes;
@@ -180,53 +197,110 @@ int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes) {
     return s;
 }
 
-bool choose_tile(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,
-                 int staging_bytes, const int* forced, TileGeom& g) {
+static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, const int64_t* Nover, const int n[3], bool padded) {
+    const int halo = padded ? 2 * M - 1 : 0;
+    int P[3] = {1, 1, 1};
+    t.ntiles = 1;
+    for (int d = 0; d < 3; ++d) {
+        t.n[d] = d < D ? n[d] : 1;
+        t.nt[d] = d < D ? (int)((Nover[d] + n[d] - 1) / n[d]) : 1;
+        P[d] = d < D ? n[d] + halo : 1;
+        t.ntiles *= t.nt[d];
+    }
+    t.row_stride = (!padded && D >= 2) ? lds_row_stride(ncomp * P[0], ncomp * 2 * M, 8) : ncomp * P[0];
+    t.rows[0] = P[1];
+    t.rows[1] = P[2];
+    t.elems = (int64_t)t.row_stride * P[1] * P[2];
+}
+
+bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,
+                  int spread_waves, int interp_waves, const int* forced_sp, const int* forced_ip, int bin_log2,
+                  TileGeom& g) {
     const int halo = 2 * M - 1;
-    const int64_t avail = ((int64_t)lds_budget_bytes - staging_bytes) / real_bytes;   // reals for the tile
-    auto fill = [&](const int n[3]) {
-        for (int d = 0; d < 3; ++d) {
-            g.n[d] = d < D ? n[d] : 1;
-            g.P[d] = d < D ? n[d] + halo : 1;
-            g.nt[d] = d < D ? (int)((Nover[d] + n[d] - 1) / n[d]) : 1;
-        }
-        g.row_stride = D >= 2 ? lds_row_stride(ncomp * g.P[0], ncomp * 2 * M, real_bytes) : ncomp * g.P[0];
-        g.tile_elems = (int64_t)g.row_stride * g.P[1] * g.P[2];
-        g.ntiles_total = (int64_t)g.nt[0] * g.nt[1] * g.nt[2];
-    };
-    if (forced && forced[0] > 0) {
-        int n[3] = {1, 1, 1};
-        for (int d = 0; d < D; ++d) {
-            n[d] = forced[d] > 0 ? forced[d] : forced[0];
-            if (n[d] > Nover[d]) n[d] = (int)Nover[d];
-        }
-        fill(n);
-        return g.tile_elems <= avail;
+    g.nbins = 1;
+    for (int d = 0; d < 3; ++d) {
+        g.blog[d] = d < D ? bin_log2 : 0;
+        g.nb[d] = d < D ? (int)((Nover[d] + (1 << bin_log2) - 1) >> bin_log2) : 1;
+        g.nbins *= g.nb[d];
     }
-    const int cap = 64;   // longest tile edge considered
-    int lim[3] = {1, 1, 1};
-    for (int d = 0; d < D; ++d) lim[d] = (int)std::min<int64_t>(Nover[d], D == 1 ? 4096 : cap);
-    double best_cost = std::numeric_limits<double>::infinity();
-    int best[3] = {0, 0, 0};
-    for (int n3 = 1; n3 <= lim[2]; ++n3) {
-        for (int n2 = 1; n2 <= lim[1]; ++n2) {
-            if (D == 3 && n2 < n3 && lim[1] == lim[2]) continue;   // symmetric duplicates
-            for (int n1 = 1; n1 <= lim[0]; ++n1) {
-                const int P1 = n1 + halo, P2 = D >= 2 ? n2 + halo : 1, P3 = D >= 3 ? n3 + halo : 1;
-                const int S = D >= 2 ? lds_row_stride(ncomp * P1, ncomp * 2 * M, real_bytes) : ncomp * P1;
-                const int64_t elems = (int64_t)S * P2 * P3;
-                if (elems > avail) break;   // larger n1 only grows
-                // cost: global atomics / loads per interior cell (halo amplification); ties -> longer rows
-                const double cost = ((double)P1 * P2 * P3) / ((double)n1 * n2 * n3) - 1e-6 * n1;
-                if (cost < best_cost) {
-                    best_cost = cost;
-                    best[0] = n1; best[1] = n2; best[2] = n3;
+    const int b = 1 << bin_log2;
+    std::vector<int> cand[3];
+    for (int d = 0; d < 3; ++d) {
+        if (d < D) edge_candidates(Nover[d], b, M, D == 1 ? 8192 : 96, cand[d]);
+        else cand[d].assign(1, 1);
+    }
+    // --- spreading tile: interior only, Float64 accumulation; cost = point visits per point ---
+    {
+        const int64_t avail = ((int64_t)lds_budget_bytes - strip_bytes(D, M, ncomp, real_bytes, spread_waves)) / 8;
+        double best = std::numeric_limits<double>::infinity();
+        int bn[3] = {0, 0, 0};
+        if (forced_sp && forced_sp[0] > 0) {
+            for (int d = 0; d < 3; ++d) {
+                int n = d < D ? (forced_sp[d] > 0 ? forced_sp[d] : forced_sp[0]) : 1;
+                if (d < D) {
+                    n = std::max(b, n / b * b);
+                    if (n + halo > Nover[d]) n = (int)Nover[d];
                 }
+                bn[d] = n;
             }
+            if ((int64_t)(D >= 2 ? lds_row_stride(ncomp * bn[0], ncomp * 2 * M, 8) : ncomp * bn[0]) * bn[1] * bn[2] > avail) return false;
+        } else {
+            for (int n3 : cand[2]) for (int n2 : cand[1]) for (int n1 : cand[0]) {
+                const int64_t elems = (int64_t)(D >= 2 ? lds_row_stride(ncomp * n1, ncomp * 2 * M, 8) : ncomp * n1) * n2 * n3;
+                if (elems > avail) continue;
+                double cost = 1.0;
+                const int n[3] = {n1, n2, n3};
+                for (int d = 0; d < D; ++d)
+                    if (n[d] < Nover[d]) cost *= (double)(n[d] + halo) / n[d];
+                // every tile also pays a fixed cost (zeroing + storing the LDS tile): prefer enough work per tile
+                cost -= 1e-6 * n1;
+                if (cost < best) { best = cost; bn[0] = n1; bn[1] = n2; bn[2] = n3; }
+            }
+            if (bn[0] == 0) return false;
         }
+        fill_shape(g.sp, D, M, ncomp, Nover, bn, false);
     }
-    if (best[0] == 0) return false;
-    fill(best);
+    // --- interpolation tile: padded, grid precision; cost = halo amplification of the tile load ---
+    {
+        const int64_t avail = ((int64_t)lds_budget_bytes - strip_bytes(D, M, ncomp, real_bytes, interp_waves)) / real_bytes;
+        double best = std::numeric_limits<double>::infinity();
+        int bn[3] = {0, 0, 0};
+        if (forced_ip && forced_ip[0] > 0) {
+            for (int d = 0; d < 3; ++d) {
+                int n = d < D ? (forced_ip[d] > 0 ? forced_ip[d] : forced_ip[0]) : 1;
+                if (d < D) {
+                    n = std::max(b, n / b * b);
+                    if (n >= Nover[d]) n = (int)Nover[d];
+                }
+                bn[d] = n;
+            }
+            int64_t e = ncomp;
+            for (int d = 0; d < D; ++d) e *= bn[d] + halo;
+            if (e > avail) return false;
+        } else {
+            std::vector<int> ic[3];
+            for (int d = 0; d < 3; ++d) {
+                ic[d].clear();
+                if (d >= D) { ic[d].push_back(1); continue; }
+                for (int n = b; n < Nover[d] && n <= (D == 1 ? 8192 : 96); n += b) ic[d].push_back(n);
+                if (Nover[d] <= (D == 1 ? 8192 : 96) || ic[d].empty()) ic[d].push_back((int)Nover[d]);
+            }
+            for (int n3 : ic[2]) for (int n2 : ic[1]) for (int n1 : ic[0]) {
+                const int n[3] = {n1, n2, n3};
+                int64_t elems = ncomp;
+                double cost = 1.0;
+                for (int d = 0; d < D; ++d) {
+                    elems *= n[d] + halo;
+                    cost *= (double)(n[d] + halo) / n[d];
+                }
+                if (elems > avail) continue;
+                cost -= 1e-6 * n1;
+                if (cost < best) { best = cost; bn[0] = n1; bn[1] = n2; bn[2] = n3; }
+            }
+            if (bn[0] == 0) return false;
+        }
+        fill_shape(g.ip, D, M, ncomp, Nover, bn, true);
+    }
     return true;
 }
 

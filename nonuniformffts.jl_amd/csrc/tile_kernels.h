@@ -3,20 +3,22 @@
 // Replaces the reference's shared-memory kernels
 //   spread_from_points_shmem_kernel!    src/spreading/gpu.jl:237-377 (+ :381-434)
 //   interpolate_to_points_shmem_kernel! src/interpolation/gpu.jl:211-328 (+ :331-395)
-// with an MI355X-first design:
-//   * one workgroup per tile of the oversampled grid; the padded tile (interior + 2M-1 halo)
-//     lives in LDS (up to 160 KiB on gfx950, non-cubic tiles, bank-aware row stride);
-//   * points arrive bin-sorted as aligned records {r_1..r_D, idx} (binsort.hip);
-//   * each wave stages 16 points at a time: 4 lanes per point evaluate the D·2M window values
-//     (direct sinh form or the piecewise polynomial) into a wave-private LDS strip;
-//   * spreading: the wave then walks its staged points; for every point the lanes own one
-//     (component, j1, j2) element of the stencil face and loop over j3, accumulating with
-//     LDS float atomics (ds_add_f64 / ds_add_f32, no return) — no workgroup barrier per point
-//     (the reference needs one, src/spreading/gpu.jl:354-360).  The finished tile is flushed to
-//     HBM with global float atomics in row-contiguous wave instructions, skipping exact zeros;
-//   * interpolation: the padded tile is loaded once (coalesced rows, periodic wrap), then every
-//     point is gathered by a whole wave (conflict-free row reads) and reduced with DPP /
-//     permlane-swap butterflies; results leave through the staging strip in one scattered store.
+// with an MI355X-first design (see DESIGN.md §4.1 for the measurements behind each choice):
+//
+//   * Points arrive sorted by fine bins (binsort.hip) as aligned records {r_1..r_D, idx}; a tile is a
+//     box of bins, so its points are a few contiguous runs of the sorted array.
+//   * Lane mapping: G = nextpow2(ncomp * 2M) consecutive lanes own one point (one lane per
+//     (component, j1) of the stencil's first dimension); a wave works on 64 / G points at once and
+//     every lane loops over (j2, j3).  The D*2M window values of a point are evaluated once by its G
+//     lanes (direct sinh form, or the piecewise polynomial with the lane's coefficients held in
+//     registers), exchanged through a wave-private LDS strip, and kept in registers.
+//   * Spreading is OUTPUT-DRIVEN: only the tile interior lives in LDS (Float64 accumulation with
+//     native ds_add_f64); the workgroup visits every point whose stencil touches the tile, clips the
+//     stencil to the tile, and finally stores the tile with plain coalesced stores.  There are no
+//     global atomics (memory-side float atomics run at 1.2 TB/s on MI355X, 3-5x below plain stores) and
+//     the grid needs no zero fill: every cell is written exactly once.
+//   * Interpolation loads the padded tile (interior + 2M-1 halo) once, visits each point exactly once,
+//     gathers with the same loops and reduces over the G lanes with DPP / permlane-swap butterflies.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -30,8 +32,8 @@ template <typename T>
 struct TileArgs {
     Geom g;
     const void* sorted;
-    const uint32_t* offsets;
-    const T* coefs;                       // [D][npoly][2M]
+    const uint32_t* offsets;              // [nbins + 1]
+    const T* coefs;                       // [D][npoly][2M], scaled by the window normalisation
     T beta[3];
     T bop[3];                             // β/π times the power-of-two window normalisation
     T* grid[kMaxCompPerLaunch];           // component grids (as arrays of reals)
@@ -41,99 +43,132 @@ struct TileArgs {
     int evalmode;
 };
 
-// Per-lane description of the stencil face element(s) a lane owns.
-template <int NC, int D, int M>
-struct Face {
+template <int NC, int M>
+struct Grp {
     static constexpr int L = 2 * M;
-    static constexpr int W1 = NC * L;                         // inner extent in reals
-    static constexpr int FACE = W1 * (D >= 2 ? L : 1);
-    static constexpr int G = FACE >= kWave ? kWave : next_pow2(FACE);   // lanes per point
-    static constexpr int PPW = kWave / G;                     // points processed at once
-    static constexpr int NPASS = (FACE + G - 1) / G;
+    static constexpr int W1 = NC * L;                   // reals of the stencil along dimension 1
+    static constexpr int G = lanes_per_point(NC, M);    // lanes per point
+    static constexpr int PPW = kWave / G;               // points per wave at once
 };
 
-// Wave-private staging strip.
-template <typename T, int NC, int D, int M>
-struct Stage {
-    static constexpr int NV = D * 2 * M;
-    T* wv;     // [kCH][NV]   window values
-    T* vv;     // [kCH][NC]   input values (spread) / results (interp)
-    int* ss;   // [kCH][D]    local stencil start
-    __device__ Stage(unsigned char* base) {
-        wv = reinterpret_cast<T*>(base);
-        vv = wv + kCH * NV;
-        ss = reinterpret_cast<int*>(vv + kCH * NC);
+// Contiguous runs of bins that cover the cell interval [lo, hi) of a periodic axis of N cells.
+struct BinSegs {
+    int n;          // number of runs (1 or 2)
+    int lo[2];      // first bin of each run
+    int len[2];     // bins in each run
+    __device__ __forceinline__ int total() const { return len[0] + len[1]; }
+    __device__ __forceinline__ int bin(int r) const { return r < len[0] ? lo[0] + r : lo[1] + (r - len[0]); }
+};
+
+__device__ __forceinline__ BinSegs bin_segments(int lo, int hi, int N, int blog, int nb) {
+    BinSegs s;
+    s.n = 1;
+    s.lo[0] = 0; s.len[0] = nb; s.lo[1] = 0; s.len[1] = 0;
+    if (hi - lo >= N) return s;                       // whole axis
+    if (lo >= 0 && hi <= N) {                         // no wrap
+        s.lo[0] = lo >> blog;
+        s.len[0] = ((hi - 1) >> blog) - s.lo[0] + 1;
+        return s;
     }
-};
+    // wraps once: [lo', N) and [0, hi')
+    const int lo2 = lo < 0 ? lo + N : lo;
+    const int hi2 = lo < 0 ? hi : hi - N;
+    const int a_first = lo2 >> blog;                  // run A: a_first .. nb-1
+    const int b_last = (hi2 - 1) >> blog;             // run B: 0 .. b_last
+    if (b_last + 1 >= a_first) return s;              // runs touch or overlap: whole axis
+    s.n = 2;
+    s.lo[0] = a_first; s.len[0] = nb - a_first;
+    s.lo[1] = 0;       s.len[1] = b_last + 1;
+    return s;
+}
 
-// Loads the chunk's records, evaluates the windows and fills the staging strip.
-// Returns the original index of this lane's point (valid for lanes with part == 0 and pt < npts).
+// Window evaluation of one wave: the G lanes of a group evaluate the D*2M values of their point and
+// exchange them through the wave's LDS strip.  Coefficients of the piecewise polynomial stay in
+// registers (the lane's (dimension, j) role per slot never changes).
 template <typename T, int NC, int D, int M>
-__device__ __forceinline__ int stage_chunk(const TileArgs<T>& a, const PointRec<T, D>* __restrict__ sorted,
-                                           uint32_t first, int npts, const int (&origin)[3], const T* coefs_lds,
-                                           Stage<T, NC, D, M>& st, int lane) {
-    constexpr int L = 2 * M;
-    constexpr int NV = D * L;
-    const int pt = lane % kCH;
-    const int part = lane / kCH;
-    int idx = -1;
-    if (pt < npts) {
-        const PointRec<T, D> rec = sorted[first + pt];
-        idx = rec.idx;
+struct WindowEval {
+    using GP = Grp<NC, M>;
+    static constexpr int L = 2 * M;
+    static constexpr int NV = D * L;
+    static constexpr int NSLOT = (NV + GP::G - 1) / GP::G;
+    static constexpr int NP = M + 4;
+    T cs[NSLOT][NP];
+    int dsel[NSLOT], jsel[NSLOT];
+    bool has[NSLOT];
+    T beta_s[NSLOT], bop_s[NSLOT];
+
+    __device__ __forceinline__ void init(const TileArgs<T>& a, int q) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int i = cell_of(rec.r[d], a.g.Nover[d]);
-            const T X = rec.r[d] - T(i);
-            if (part == 0) st.ss[pt * D + d] = i - origin[d];
-            if (a.evalmode == NUFFT_EVAL_DIRECT) {
-                const T beta = a.beta[d];
-                const T bop = a.bop[d];
-                for (int j = part; j < L; j += kParts) st.wv[pt * NV + d * L + j] = bkb_direct<T, M>(X, j, beta, bop);
+        for (int s = 0; s < NSLOT; ++s) {
+            const int k = q + s * GP::G;
+            has[s] = k < NV;
+            const int kk = has[s] ? k : 0;
+            dsel[s] = kk / L;
+            jsel[s] = kk % L;
+            beta_s[s] = a.beta[dsel[s]];
+            bop_s[s] = a.bop[dsel[s]];
+            if (a.evalmode != NUFFT_EVAL_DIRECT) {
+#pragma unroll
+                for (int c = 0; c < NP; ++c) cs[s][c] = a.coefs[(dsel[s] * NP + c) * L + jsel[s]];
             } else {
-                const T* cs = coefs_lds + d * (M + 4) * L;
-                for (int j = part; j < L; j += kParts) st.wv[pt * NV + d * L + j] = bkb_poly<T, M>(X, j, cs);
+#pragma unroll
+                for (int c = 0; c < NP; ++c) cs[s][c] = T(0);
             }
         }
     }
-    return idx;
-}
+
+    // X[d]: cell fraction of this lane's point; strip: this group's NV slots in LDS.
+    __device__ __forceinline__ void eval_to_strip(const TileArgs<T>& a, const T (&X)[3], T* strip, int q) const {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const T x = dsel[s] == 0 ? X[0] : (dsel[s] == 1 ? X[1] : X[2]);
+            T val;
+            if (a.evalmode == NUFFT_EVAL_DIRECT) {
+                val = bkb_direct<T, M>(x, jsel[s], beta_s[s], bop_s[s]);
+            } else {
+                const T xx = T(2) * x - T(1);
+                val = cs[s][NP - 1];
+#pragma unroll
+                for (int c = NP - 2; c >= 0; --c) val = fma(xx, val, cs[s][c]);
+            }
+            if (has[s]) strip[q + s * GP::G] = val;
+        }
+    }
+};
 
 template <typename T>
 __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-template <typename T>
-__device__ __forceinline__ void global_atomic_add(T* p, T v) {
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
-// Row walker for tile <-> global traffic: a wave instruction covers RPW rows of the padded tile
-// (row = fixed l2, l3; W_row = NC * P[0] reals), lanes running along dimension 1 so that global
-// addresses are contiguous within a row.
+// Row walker for tile <-> global traffic: a wave instruction covers RPW rows of the tile
+// (row = fixed l2, l3; w_row reals), lanes running along dimension 1 so that global addresses are
+// contiguous within a row.
 struct RowWalker {
     int lanes_per_row, rpw, sub, lane_in_row;
-    int rows_total, row, l2, l3, step, step2, step3;
-    __device__ RowWalker(const Geom& g, int w_row, int wave, int nwaves, int lane) {
+    int rows2, rows_total, row, l2, l3, step, step2, step3;
+    __device__ RowWalker(int rows2_, int rows3_, int w_row, int wave, int nwaves, int lane) {
         int lpr = kWave;
         while (lpr / 2 >= w_row && lpr > 1) lpr >>= 1;
         lanes_per_row = lpr;
         rpw = kWave / lpr;
         sub = lane / lpr;
         lane_in_row = lane % lpr;
-        rows_total = g.P[1] * g.P[2];
+        rows2 = rows2_;
+        rows_total = rows2_ * rows3_;
         row = wave * rpw + sub;
-        l2 = row % g.P[1];
-        l3 = row / g.P[1];
+        l2 = row % rows2;
+        l3 = row / rows2;
         step = nwaves * rpw;
-        step2 = step % g.P[1];
-        step3 = step / g.P[1];
+        step2 = step % rows2;
+        step3 = step / rows2;
     }
     __device__ __forceinline__ bool valid() const { return row < rows_total; }
-    __device__ __forceinline__ void next(const Geom& g) {
+    __device__ __forceinline__ void next() {
         row += step;
         l2 += step2;
         l3 += step3;
-        if (l2 >= g.P[1]) { l2 -= g.P[1]; l3 += 1; }
+        if (l2 >= rows2) { l2 -= rows2; l3 += 1; }
     }
 };
 
@@ -144,14 +179,43 @@ __device__ __forceinline__ int wrap_index(int gidx, int N) {
     return gidx;
 }
 
+__device__ __forceinline__ void tile_coords(int tile_id, const TileShape& ts, int (&t)[3]) {
+    int rem = tile_id;
+    t[0] = rem % ts.nt[0]; rem /= ts.nt[0];
+    t[1] = rem % ts.nt[1]; rem /= ts.nt[1];
+    t[2] = rem;
+}
+
 // ---------------------------------------------------------------------------------------------
-// Spreading
+// Spreading (output-driven)
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool CPLX, int D, int M>
+__device__ __forceinline__ float readlane_t(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ double readlane_t(double x, int l) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Windows are evaluated with the group mapping (G lanes per point, 64 / G points per chunk); the
+// accumulation then walks the chunk's points one at a time with the FACE mapping: the 64 lanes own the
+// (component, j1, j2) elements of the stencil face (NPASS passes when the face has more than 64
+// elements) and loop over j3.  Rows of the LDS tile are strided so that the rows one wave instruction
+// touches fall on disjoint banks (8.8 cycles per ds_add_f64 wave instruction instead of 12-16 for
+// randomly placed segments, scripts/microbench.hip), and stencil planes outside the tile are skipped
+// by a scalar branch.  WRAP = some axis is spanned by a single tile (small grids): stencil indices
+// then wrap around that axis instead of being clipped; the hot instantiation (WRAP = false) carries
+// none of that code.
+template <typename T, bool CPLX, int D, int M, bool WRAP>
 __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
-    using F = Face<NC, D, M>;
+    using GP = Grp<NC, M>;
+    using A = double;
+    constexpr int FACE = GP::W1 * (D >= 2 ? L : 1);
+    constexpr int NPASS = (FACE + kWave - 1) / kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -160,85 +224,161 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     const int nthreads = blockDim.x;
     const int nwaves = nthreads / kWave;
     const Geom& g = a.g;
+    const TileShape& ts = g.sp;
 
-    const int tile_id = xcd_remap(blockIdx.x, g.ntiles);
-    const uint32_t pa = a.offsets[tile_id];
-    const uint32_t pb = a.offsets[tile_id + 1];
-    if (pa == pb) return;   // nothing to spread: skip zeroing and flush (reference src/spreading/gpu.jl:364)
-
+    const int tile_id = xcd_remap(blockIdx.x, ts.ntiles);
     const int comp_id = blockIdx.y;
-    int t[3], origin[3];
-    {
-        int rem = tile_id;
-        t[0] = rem % g.nt[0]; rem /= g.nt[0];
-        t[1] = rem % g.nt[1]; rem /= g.nt[1];
-        t[2] = rem;
+    int t[3];
+    tile_coords(tile_id, ts, t);
+    int org[3], neff[3];
+    bool wrapd[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) origin[d] = t[d] * g.n[d];
+    for (int d = 0; d < 3; ++d) {
+        org[d] = t[d] * ts.n[d];
+        neff[d] = min(ts.n[d], g.Nover[d] - org[d]);
+        wrapd[d] = WRAP && ts.nt[d] == 1;   // a single tile spans the axis: wrap instead of clip
     }
 
-    using A = double;   // LDS accumulation type (see lds_layout)
-    const LdsLayout lay = lds_layout(g.tile_elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves);
+    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves);
     A* tile = reinterpret_cast<A*>(smem);
-    T* coefs_lds = reinterpret_cast<T*>(smem + lay.tile_bytes);
-    Stage<T, NC, D, M> st(smem + lay.tile_bytes + lay.coef_bytes + wave * lay.stage_bytes_per_wave);
+    T* strip_wave = reinterpret_cast<T*>(smem + lay.tile_bytes + wave * lay.strip_bytes_per_wave);
 
-    // zero the tile, copy the polynomial coefficients
-    for (int i = tid; i < g.tile_elems; i += nthreads) tile[i] = A(0);
-    if (a.evalmode != NUFFT_EVAL_DIRECT)
-        for (int i = tid; i < D * (M + 4) * L; i += nthreads) coefs_lds[i] = a.coefs[i];
+    for (int i = tid; i < ts.elems; i += nthreads) tile[i] = A(0);
+
+    // evaluation roles
+    const int grp = lane / GP::G, q = lane % GP::G;
+    T* strip = strip_wave + grp * (D * L);
+    WindowEval<T, NC, D, M> we;
+    we.init(a, q);
+    // accumulation roles
+    int j1f[NPASS], j2f[NPASS], cmpf[NPASS];
+    bool actf[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int e = lane + ps * kWave;
+        actf[ps] = e < FACE;
+        const int e1 = e % GP::W1;
+        j2f[ps] = (e / GP::W1) % L;
+        cmpf[ps] = e1 % NC;
+        j1f[ps] = e1 / NC;
+    }
     __syncthreads();
 
-    // lane roles on the stencil face
-    const int gq = lane / F::G, q = lane % F::G;
-    int lane_off[F::NPASS], j1v[F::NPASS], j2v[F::NPASS], cmp[F::NPASS];
-    bool act[F::NPASS];
+    // bins whose points can touch this tile
+    BinSegs seg[3];
 #pragma unroll
-    for (int ps = 0; ps < F::NPASS; ++ps) {
-        const int e = q + ps * F::G;
-        act[ps] = e < F::FACE;
-        const int e1 = e % F::W1;
-        const int j2 = e / F::W1;
-        cmp[ps] = e1 % NC;
-        j1v[ps] = e1 / NC;
-        j2v[ps] = j2;
-        lane_off[ps] = j2 * g.row_stride + e1;
+    for (int d = 0; d < 3; ++d) {
+        if (d < D) seg[d] = bin_segments(org[d] - M, org[d] + neff[d] + M - 1, g.Nover[d], g.blog[d], g.nb[d]);
+        else { seg[d].n = 1; seg[d].lo[0] = 0; seg[d].len[0] = 1; seg[d].lo[1] = 0; seg[d].len[1] = 0; }
     }
+    const int R2 = seg[1].total(), R3 = seg[2].total();
+    const int nitems = R2 * R3 * seg[0].n;
 
     const PointRec<T, D>* sorted = static_cast<const PointRec<T, D>*>(a.sorted);
     const T* vin = a.vin[comp_id];
-    const int npts_tile = (int)(pb - pa);
-    const int nchunks = (npts_tile + kCH - 1) / kCH;
 
-    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-        const uint32_t first = pa + (uint32_t)chunk * kCH;
-        const int npts = min(kCH, (int)(pb - first));
-        wave_lds_fence();   // previous chunk's reads are done before the strip is overwritten
-        const int idx = stage_chunk<T, NC, D, M>(a, sorted, first, npts, origin, coefs_lds, st, lane);
-        if (lane < kCH && lane < npts) {
+    for (int item = wave; item < nitems; item += nwaves) {
+        const int sg = item % seg[0].n;
+        const int r2 = (item / seg[0].n) % R2;
+        const int r3 = item / (seg[0].n * R2);
+        const int bin0 = (seg[2].bin(r3) * g.nb[1] + seg[1].bin(r2)) * g.nb[0] + seg[0].lo[sg];
+        const uint32_t p0 = a.offsets[bin0];
+        const uint32_t p1 = a.offsets[bin0 + seg[0].len[sg]];
+        for (uint32_t pc = p0; pc < p1; pc += GP::PPW) {
+            const uint32_t p = pc + grp;
+            const bool have = p < p1;
+            const PointRec<T, D> rec = sorted[have ? p : p0];
+            int s[3] = {0, 0, 0};
+            T X[3] = {T(0), T(0), T(0)};
+            bool ok = have;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) st.vv[lane * NC + c] = vin[(int64_t)idx * NC + c];
-        }
-        wave_lds_fence();
+            for (int d = 0; d < D; ++d) {
+                const int c = cell_of(rec.r[d], g.Nover[d]);
+                X[d] = rec.r[d] - T(c);
+                int sd = c - (M - 1) - org[d];             // local index of the first stencil node
+                if (!wrapd[d]) {
+                    if (sd > neff[d] - 1) sd -= g.Nover[d];    // periodic image next to this tile
+                    if (sd < -(L - 1)) sd += g.Nover[d];
+                    ok = ok && (sd >= -(L - 1)) && (sd <= neff[d] - 1);
+                }
+                s[d] = sd;
+            }
+            const unsigned long long okmask = __ballot(ok);
+            if (okmask == 0ull) continue;                     // nothing of this chunk touches the tile
+            T vmine = T(0);
+            if (ok && q < NC) vmine = vin[(int64_t)rec.idx * NC + q];
+            wave_lds_fence();
+            we.eval_to_strip(a, X, strip, q);
+            wave_lds_fence();
 
-        for (int p0 = 0; p0 < npts; p0 += F::PPW) {
-            const int pt = p0 + gq;
-            if (pt < npts) {
-                const T* wv = st.wv + pt * (D * L);
-                int base = st.ss[pt * D + 0] * NC;
-                if constexpr (D >= 2) base += st.ss[pt * D + 1] * g.row_stride;
-                if constexpr (D >= 3) base += st.ss[pt * D + 2] * g.plane_stride;
 #pragma unroll
-                for (int ps = 0; ps < F::NPASS; ++ps) {
-                    if (act[ps]) {
-                        T w = st.vv[pt * NC + cmp[ps]] * wv[j1v[ps]];
-                        if constexpr (D >= 2) w *= wv[L + j2v[ps]];
-                        A* dst = tile + base + lane_off[ps];
-                        if constexpr (D >= 3) {
+            for (int gi = 0; gi < GP::PPW; ++gi) {
+                const int src = gi * GP::G;                    // first lane of the point's group
+                if (!((okmask >> src) & 1ull)) continue;
+                const int S1 = __builtin_amdgcn_readlane(s[0], src);
+                const int S2 = D >= 2 ? __builtin_amdgcn_readlane(s[1], src) : 0;
+                const int S3 = D >= 3 ? __builtin_amdgcn_readlane(s[2], src) : 0;
+                const T Vre = readlane_t(vmine, src);
+                const T Vim = CPLX ? readlane_t(vmine, src + (CPLX ? 1 : 0)) : T(0);
+                const T* sp = strip_wave + gi * (D * L);
+                // the 2M window values of dimension 3: identical in every lane (broadcast LDS reads)
+                T w3[L];
+                if constexpr (D >= 3) {
 #pragma unroll
-                            for (int j3 = 0; j3 < L; ++j3) lds_atomic_add(dst + j3 * g.plane_stride, (A)(w * wv[2 * L + j3]));
-                        } else {
-                            lds_atomic_add(dst, (A)w);
+                    for (int j = 0; j < L; ++j) w3[j] = sp[2 * L + j];
+                }
+                // valid planes: j3 in [lo3, hi3)
+                int lo3 = 0, hi3 = L;
+                if constexpr (D >= 3) {
+                    if (!wrapd[2]) {
+                        lo3 = max(0, -S3);
+                        hi3 = min(L, neff[2] - S3);
+                    }
+                }
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    int l1 = S1 + j1f[ps];
+                    if (WRAP && wrapd[0]) { if (l1 < 0) l1 += g.Nover[0]; if (l1 >= g.Nover[0]) l1 -= g.Nover[0]; }
+                    bool lane_ok = actf[ps] && (unsigned)l1 < (unsigned)neff[0];
+                    T w = sp[j1f[ps]] * (CPLX ? (cmpf[ps] ? Vim : Vre) : Vre);
+                    A* addr = tile + l1 * NC + cmpf[ps];
+                    if constexpr (D >= 2) {
+                        int l2 = S2 + j2f[ps];
+                        if (WRAP && wrapd[1]) { if (l2 < 0) l2 += g.Nover[1]; if (l2 >= g.Nover[1]) l2 -= g.Nover[1]; }
+                        lane_ok = lane_ok && (unsigned)l2 < (unsigned)neff[1];
+                        w *= sp[L + j2f[ps]];
+                        addr += l2 * ts.row_stride;
+                    }
+                    if constexpr (D <= 2) {
+                        if (lane_ok) lds_atomic_add(addr, (A)w);
+                    } else {
+                        if (lane_ok) {
+                            if (WRAP && wrapd[2]) {
+#pragma unroll
+                                for (int j3 = 0; j3 < L; ++j3) {
+                                    int l3 = S3 + j3;
+                                    if (l3 < 0) l3 += g.Nover[2];
+                                    if (l3 >= g.Nover[2]) l3 -= g.Nover[2];
+                                    lds_atomic_add(addr + l3 * ts.plane_stride, (A)(w * w3[j3]));
+                                }
+                            } else {
+                                A* pl = addr + (S3 + lo3) * ts.plane_stride;
+                                if (lo3 == 0 && hi3 == L) {          // the common case: all planes inside
+#pragma unroll
+                                    for (int j3 = 0; j3 < L; ++j3) {
+                                        lds_atomic_add(pl, (A)(w * w3[j3]));
+                                        pl += ts.plane_stride;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int j3 = 0; j3 < L; ++j3) {
+                                        if (j3 >= lo3 && j3 < hi3) {
+                                            lds_atomic_add(pl, (A)(w * w3[j3]));
+                                            pl += ts.plane_stride;
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                 }
@@ -247,36 +387,28 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     }
     __syncthreads();
 
-    // flush: tile -> global grid with float atomics (add_from_local_to_global_memory!, :406-434)
+    // store the finished interior: every grid cell is written exactly once (no zero fill needed)
     T* grid = a.grid[comp_id];
-    const int w_row = NC * g.P[0];
-    RowWalker rw(g, w_row, wave, nwaves, lane);
-    const int o1 = origin[0] - (M - 1), o2 = origin[1] - (M - 1), o3 = origin[2] - (M - 1);
-    for (; rw.valid(); rw.next(g)) {
+    const int w_row = NC * neff[0];
+    RowWalker rw(D >= 2 ? neff[1] : 1, D >= 3 ? neff[2] : 1, w_row, wave, nwaves, lane);
+    for (; rw.valid(); rw.next()) {
         int64_t rowbase = 0;
-        if constexpr (D >= 2) rowbase = (int64_t)wrap_index(o2 + rw.l2, g.Nover[1]);
-        if constexpr (D >= 3) rowbase += (int64_t)wrap_index(o3 + rw.l3, g.Nover[2]) * g.Nover[1];
-        rowbase *= (int64_t)g.Nover[0] * NC;
-        const A* src = tile + rw.l2 * g.row_stride + rw.l3 * g.plane_stride;
-        for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) {
-            const T v = (T)src[e];
-            if (v != T(0)) {
-                const int l1 = e / NC, c = e % NC;
-                const int g1 = wrap_index(o1 + l1, g.Nover[0]);
-                global_atomic_add(grid + rowbase + (int64_t)g1 * NC + c, v);
-            }
-        }
+        if constexpr (D >= 2) rowbase = org[1] + rw.l2;
+        if constexpr (D >= 3) rowbase += (int64_t)(org[2] + rw.l3) * g.Nover[1];
+        rowbase = (rowbase * g.Nover[0] + org[0]) * NC;
+        const A* src = tile + rw.l2 * ts.row_stride + rw.l3 * ts.plane_stride;
+        for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) grid[rowbase + e] = (T)src[e];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Interpolation
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool CPLX, int D, int M>
+template <typename T, bool CPLX, int D, int M, bool WRAP>
 __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
-    using F = Face<NC, D, M>;
+    using GP = Grp<NC, M>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -285,40 +417,62 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     const int nthreads = blockDim.x;
     const int nwaves = nthreads / kWave;
     const Geom& g = a.g;
+    const TileShape& ts = g.ip;
 
-    const int tile_id = xcd_remap(blockIdx.x, g.ntiles);
-    const uint32_t pa = a.offsets[tile_id];
-    const uint32_t pb = a.offsets[tile_id + 1];
-    if (pa == pb) return;
-
+    const int tile_id = xcd_remap(blockIdx.x, ts.ntiles);
     const int comp_id = blockIdx.y;
-    int t[3], origin[3];
-    {
-        int rem = tile_id;
-        t[0] = rem % g.nt[0]; rem /= g.nt[0];
-        t[1] = rem % g.nt[1]; rem /= g.nt[1];
-        t[2] = rem;
+    int t[3];
+    tile_coords(tile_id, ts, t);
+    int org[3], neff[3], P[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) origin[d] = t[d] * g.n[d];
+    for (int d = 0; d < 3; ++d) {
+        org[d] = t[d] * ts.n[d];
+        neff[d] = min(ts.n[d], g.Nover[d] - org[d]);
+        P[d] = d < D ? ts.n[d] + L - 1 : 1;
     }
 
-    const LdsLayout lay = lds_layout(g.tile_elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves);
+    // points of this tile: a box of bins, one contiguous run of the sorted array per (bin2, bin3)
+    int blo[3], bcnt[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        blo[d] = d < D ? org[d] >> g.blog[d] : 0;
+        bcnt[d] = d < D ? ((org[d] + neff[d] - 1) >> g.blog[d]) - blo[d] + 1 : 1;
+    }
+    const int nitems = bcnt[1] * bcnt[2];
+    // skip the tile load when the tile holds no points (flag in the dynamic LDS region: HIP's
+    // __syncthreads_or would add static LDS on top of the 160 KiB request)
+    {
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        int any = 0;
+        for (int item = tid; item < nitems; item += nthreads) {
+            const int bin0 = ((blo[2] + item / bcnt[1]) * g.nb[1] + blo[1] + item % bcnt[1]) * g.nb[0] + blo[0];
+            any |= a.offsets[bin0] != a.offsets[bin0 + bcnt[0]];
+        }
+        if (any) *flag = 1;
+        __syncthreads();
+        const int f = *flag;
+        __syncthreads();
+        if (!f) return;
+    }
+
+    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves);
     T* tile = reinterpret_cast<T*>(smem);
-    T* coefs_lds = reinterpret_cast<T*>(smem + lay.tile_bytes);
-    Stage<T, NC, D, M> st(smem + lay.tile_bytes + lay.coef_bytes + wave * lay.stage_bytes_per_wave);
+    T* strip_wave = reinterpret_cast<T*>(smem + lay.tile_bytes + wave * lay.strip_bytes_per_wave);
 
     // load the padded tile with periodic wrap (gridvalues_to_local_memory!, src/interpolation/gpu.jl:331-355)
     const T* grid = a.grid[comp_id];
     {
-        const int w_row = NC * g.P[0];
-        RowWalker rw(g, w_row, wave, nwaves, lane);
-        const int o1 = origin[0] - (M - 1), o2 = origin[1] - (M - 1), o3 = origin[2] - (M - 1);
-        for (; rw.valid(); rw.next(g)) {
+        const int w_row = NC * P[0];
+        RowWalker rw(P[1], P[2], w_row, wave, nwaves, lane);
+        const int o1 = org[0] - (M - 1), o2 = org[1] - (M - 1), o3 = org[2] - (M - 1);
+        for (; rw.valid(); rw.next()) {
             int64_t rowbase = 0;
             if constexpr (D >= 2) rowbase = (int64_t)wrap_index(o2 + rw.l2, g.Nover[1]);
             if constexpr (D >= 3) rowbase += (int64_t)wrap_index(o3 + rw.l3, g.Nover[2]) * g.Nover[1];
             rowbase *= (int64_t)g.Nover[0] * NC;
-            T* dst = tile + rw.l2 * g.row_stride + rw.l3 * g.plane_stride;
+            T* dst = tile + rw.l2 * ts.row_stride + rw.l3 * ts.plane_stride;
             for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) {
                 const int l1 = e / NC, c = e % NC;
                 const int g1 = wrap_index(o1 + l1, g.Nover[0]);
@@ -326,69 +480,63 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
             }
         }
     }
-    if (a.evalmode != NUFFT_EVAL_DIRECT)
-        for (int i = tid; i < D * (M + 4) * L; i += nthreads) coefs_lds[i] = a.coefs[i];
-    __syncthreads();
 
-    const int gq = lane / F::G, q = lane % F::G;
-    int lane_off[F::NPASS], j1v[F::NPASS], j2v[F::NPASS];
-    bool act[F::NPASS];
-#pragma unroll
-    for (int ps = 0; ps < F::NPASS; ++ps) {
-        const int e = q + ps * F::G;
-        act[ps] = e < F::FACE;
-        const int e1 = e % F::W1;
-        const int j2 = e / F::W1;
-        j1v[ps] = e1 / NC;
-        j2v[ps] = j2;
-        lane_off[ps] = j2 * g.row_stride + e1;
-    }
+    const int grp = lane / GP::G, q = lane % GP::G;
+    const bool lane_active = q < GP::W1;
+    const int comp = q % NC, j1 = (q / NC) % L;
+    T* strip = strip_wave + grp * (D * L);
+    WindowEval<T, NC, D, M> we;
+    we.init(a, q);
+    __syncthreads();
 
     const PointRec<T, D>* sorted = static_cast<const PointRec<T, D>*>(a.sorted);
     T* vout = a.vout[comp_id];
-    const int npts_tile = (int)(pb - pa);
-    const int nchunks = (npts_tile + kCH - 1) / kCH;
 
-    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-        const uint32_t first = pa + (uint32_t)chunk * kCH;
-        const int npts = min(kCH, (int)(pb - first));
-        wave_lds_fence();
-        const int idx = stage_chunk<T, NC, D, M>(a, sorted, first, npts, origin, coefs_lds, st, lane);
-        wave_lds_fence();
-
-        for (int p0 = 0; p0 < npts; p0 += F::PPW) {
-            const int pt = p0 + gq;
-            const bool pvalid = pt < npts;
-            const int ptc = pvalid ? pt : 0;
-            const T* wv = st.wv + ptc * (D * L);
-            int base = st.ss[ptc * D + 0] * NC;
-            if constexpr (D >= 2) base += st.ss[ptc * D + 1] * g.row_stride;
-            if constexpr (D >= 3) base += st.ss[ptc * D + 2] * g.plane_stride;
-            T acc = T(0);
+    for (int item = wave; item < nitems; item += nwaves) {
+        const int bin0 = ((blo[2] + item / bcnt[1]) * g.nb[1] + blo[1] + item % bcnt[1]) * g.nb[0] + blo[0];
+        const uint32_t p0 = a.offsets[bin0];
+        const uint32_t p1 = a.offsets[bin0 + bcnt[0]];
+        for (uint32_t pc = p0; pc < p1; pc += GP::PPW) {
+            const uint32_t p = pc + grp;
+            const bool have = p < p1;
+            const PointRec<T, D> rec = sorted[have ? p : p0];
+            int s[3] = {0, 0, 0};
+            T X[3] = {T(0), T(0), T(0)};
 #pragma unroll
-            for (int ps = 0; ps < F::NPASS; ++ps) {
-                if (act[ps] && pvalid) {
-                    const T* src = tile + base + lane_off[ps];
-                    T s;
-                    if constexpr (D >= 3) {
-                        s = T(0);
-#pragma unroll
-                        for (int j3 = 0; j3 < L; ++j3) s = fma(src[j3 * g.plane_stride], wv[2 * L + j3], s);
-                    } else {
-                        s = src[0];
-                    }
-                    T w = wv[j1v[ps]];
-                    if constexpr (D >= 2) w *= wv[L + j2v[ps]];
-                    acc = fma(s, w, acc);
-                }
+            for (int d = 0; d < D; ++d) {
+                const int c = cell_of(rec.r[d], g.Nover[d]);
+                X[d] = rec.r[d] - T(c);
+                s[d] = c - org[d];                 // first stencil node in padded-tile coordinates
             }
-            acc = group_sum<T, F::G, CPLX>(acc);
-            if (pvalid && q < NC) st.vv[pt * NC + q] = acc * a.prefactor;
-        }
-        wave_lds_fence();
-        if (lane < kCH && lane < npts) {
+            wave_lds_fence();
+            we.eval_to_strip(a, X, strip, q);
+            wave_lds_fence();
+            const T w1 = strip[j1];
+            const T* base = tile + (s[0] + j1) * NC + comp + s[1] * ts.row_stride + s[2] * ts.plane_stride;
+            T acc = T(0);
+            if (have && lane_active) {
+                if constexpr (D == 1) {
+                    acc = base[0];
+                } else if constexpr (D == 2) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) vout[(int64_t)idx * NC + c] = st.vv[lane * NC + c];
+                    for (int j2 = 0; j2 < L; ++j2) acc = fma(base[j2 * ts.row_stride], strip[L + j2], acc);
+                } else {
+                    T w2[L];
+#pragma unroll
+                    for (int j = 0; j < L; ++j) w2[j] = strip[L + j];
+#pragma unroll
+                    for (int j3 = 0; j3 < L; ++j3) {
+                        const T* plane = base + j3 * ts.plane_stride;
+                        T t2 = T(0);
+#pragma unroll
+                        for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * ts.row_stride], w2[j2], t2);
+                        acc = fma(t2, strip[2 * L + j3], acc);
+                    }
+                }
+                acc *= w1;
+            }
+            acc = group_sum<T, GP::G, CPLX>(acc);
+            if (have && q < NC) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
         }
     }
 }

@@ -6,28 +6,32 @@
 
 namespace nufft {
 
-const void* spread_kernel_f32r(int D, int M);
-const void* spread_kernel_f32c(int D, int M);
-const void* spread_kernel_f64r(int D, int M);
-const void* spread_kernel_f64c(int D, int M);
-const void* interp_kernel_f32r(int D, int M);
-const void* interp_kernel_f32c(int D, int M);
-const void* interp_kernel_f64r(int D, int M);
-const void* interp_kernel_f64c(int D, int M);
+const void* spread_kernel_f32r(int D, int M, bool wrap);
+const void* spread_kernel_f32c(int D, int M, bool wrap);
+const void* spread_kernel_f64r(int D, int M, bool wrap);
+const void* spread_kernel_f64c(int D, int M, bool wrap);
+const void* interp_kernel_f32r(int D, int M, bool wrap);
+const void* interp_kernel_f32c(int D, int M, bool wrap);
+const void* interp_kernel_f64r(int D, int M, bool wrap);
+const void* interp_kernel_f64c(int D, int M, bool wrap);
 
-static const void* pick(bool interp, int dtype, int is_complex, int D, int M) {
+static const void* pick(bool interp, int dtype, int is_complex, int D, int M, bool wrap) {
     if (interp) {
-        if (dtype == NUFFT_F32) return is_complex ? interp_kernel_f32c(D, M) : interp_kernel_f32r(D, M);
-        return is_complex ? interp_kernel_f64c(D, M) : interp_kernel_f64r(D, M);
+        if (dtype == NUFFT_F32) return is_complex ? interp_kernel_f32c(D, M, false) : interp_kernel_f32r(D, M, false);
+        return is_complex ? interp_kernel_f64c(D, M, false) : interp_kernel_f64r(D, M, false);
     }
-    if (dtype == NUFFT_F32) return is_complex ? spread_kernel_f32c(D, M) : spread_kernel_f32r(D, M);
-    return is_complex ? spread_kernel_f64c(D, M) : spread_kernel_f64r(D, M);
+    if (dtype == NUFFT_F32) return is_complex ? spread_kernel_f32c(D, M, wrap) : spread_kernel_f32r(D, M, wrap);
+    return is_complex ? spread_kernel_f64c(D, M, wrap) : spread_kernel_f64r(D, M, wrap);
 }
 
 static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, int lds_bytes) {
-    const void* fn = pick(interp, dtype, is_complex, D, M);
-    if (!fn) return hipErrorInvalidValue;
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    for (int wrap = 0; wrap < (interp ? 1 : 2); ++wrap) {
+        const void* fn = pick(interp, dtype, is_complex, D, M, wrap != 0);
+        if (!fn) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes) {
@@ -39,7 +43,9 @@ hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes
 
 template <typename T>
 static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t stream) {
-    const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M);
+    bool wrap = false;
+    for (int d = 0; d < a.D; ++d) wrap = wrap || a.g.sp.nt[d] == 1;
+    const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, wrap);
     if (!fn) return hipErrorInvalidValue;
     const int ncr = a.is_complex ? 2 : 1;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
@@ -61,7 +67,7 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         k.prefactor = (T)a.prefactor;
         k.evalmode = a.evalmode;
         void* params[] = {&k};
-        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.g.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
+        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
                                        params, (size_t)a.lds_bytes, stream);
         if (e != hipSuccess) return e;
     }

@@ -133,8 +133,8 @@ class PlanNUFFT:
                  kernel=None, ntransforms: int = 1, backend=ROCBackend(0),
                  kernel_evalmode=None, fftshift: bool = False, gpu_method: str = "shared_memory",
                  sort_points: bool = False, synchronise: bool = False, block_size=None,
-                 tile_dims: Optional[Sequence[int]] = None, lds_budget_bytes: int = 0,
-                 spread_threads: int = 0, interp_threads: int = 0):
+                 tile_dims: Optional[Sequence[int]] = None, interp_tile_dims: Optional[Sequence[int]] = None,
+                 bin_log2: int = 0, lds_budget_bytes: int = 0, spread_threads: int = 0, interp_threads: int = 0):
         if dims is None:           # PlanNUFFT(dims; ...) form: ComplexF64 by default (src/plan.jl:597-599)
             Z, dims = torch.complex128, Z
         if isinstance(dims, int):
@@ -201,6 +201,10 @@ class PlanNUFFT:
         if tile_dims is not None:
             for d, n in enumerate(tile_dims):
                 prm.tile_dims[d] = int(n)
+        if interp_tile_dims is not None:
+            for d, n in enumerate(interp_tile_dims):
+                prm.interp_tile_dims[d] = int(n)
+        prm.bin_log2 = int(bin_log2)
         prm.lds_budget_bytes = int(lds_budget_bytes)
         prm.spread_threads = int(spread_threads)
         prm.interp_threads = int(interp_threads)
@@ -301,7 +305,9 @@ class PlanNUFFT:
             f"  - uniform dimensions: {self.size}",
             f"  - simultaneous transforms: {self.ntransforms}",
             f"  - frequency order: {'increasing' if self.fftshift else 'FFTW'} (fftshift = {self.fftshift})",
-            f"  - block size: {tuple(i.tile_dims[d] for d in range(D))} (excluding 2M - 1 = {2 * i.half_support - 1} ghost cells in each direction)",
+            f"  - block size: spreading {tuple(i.spread_tile[d] for d in range(D))} (interior only), interpolation "
+            f"{tuple(i.interp_tile[d] for d in range(D))} (excluding 2M - 1 = {2 * i.half_support - 1} ghost cells in each direction), "
+            f"sort bins {tuple(i.bin_dims[d] for d in range(D))}",
             f"  - GPU method: :{self.gpu_method} (LDS {i.lds_bytes_spread} B spread / {i.lds_bytes_interp} B interp)",
         ]
         return "\n".join(lines)
@@ -479,14 +485,14 @@ def oversampled_grid(p: PlanNUFFT, component: int = 0, spectrum: bool = False) -
 
 
 def sort_result(p: PlanNUFFT):
-    """(pointperm, cumulative_npoints_per_block) of the bin sort as numpy arrays (0-based)."""
+    """(pointperm, cumulative number of points per sort bin) as numpy arrays (0-based)."""
     import numpy as np
     p._require_gpu()
     info = p.info()
     Np = int(info.num_points)
     nt = 1
     for d in range(p.ndim):
-        nt *= int(info.ntiles[d])
+        nt *= int(info.nbins[d])
     perm = np.empty(max(Np, 1), dtype=np.int32)
     offs = np.empty(nt + 1, dtype=np.uint32)
     _check(lib.nufft_get_sort_result(p._handle, perm.ctypes.data_as(C.POINTER(C.c_int32)), perm.size,

@@ -157,10 +157,10 @@ def test_spread_and_interp_stages_match_oracle(Z):
     assert _rel(got, ref2) < (1e-12 if Z == np.float64 else 2e-5)
 
 
-def test_bin_sort_is_a_permutation_grouped_by_tile():
+def test_bin_sort_is_a_permutation_grouped_by_bin():
     nufft = _nufft()
     dims, Np = (40, 36, 50), 20000
-    plan = nufft.PlanNUFFT(np.float64, dims, m=4, sigma=2.0, backend=nufft.ROCBackend(0), tile_dims=(8, 6, 10))
+    plan = nufft.PlanNUFFT(np.float64, dims, m=4, sigma=2.0, backend=nufft.ROCBackend(0))
     rng = np.random.default_rng(0)
     xs = [(rng.random(Np) * 5 - 2) * O.TWO_PI for _ in dims]
     nufft.set_points(plan, tuple(torch.from_numpy(x).cuda() for x in xs))
@@ -174,8 +174,8 @@ def test_bin_sort_is_a_permutation_grouped_by_tile():
     for d in range(3):
         i, _ = O.point_to_cell(O.to_unit_cell(xs[d]), Nover[d])
         i = np.minimum(i, Nover[d] - 1)
-        tile += mul * (i // info.tile_dims[d])
-        mul *= info.ntiles[d]
+        tile += mul * (i // info.bin_dims[d])
+        mul *= info.nbins[d]
     sorted_tiles = tile[perm]
     assert np.all(np.diff(sorted_tiles) >= 0)                           # grouped by tile, tiles ascending
     counts = np.bincount(tile, minlength=len(offs) - 1)

@@ -66,25 +66,27 @@ def test_host_plan_matches_oracle_plan_math(nufft, Z, dims, M, sigma):
         # exact power-of-two window normalisation: 2^k ~ 1 / max window value
         peak = np.sinh(o.betas[d]) / np.pi
         assert 0.5 <= peak * 2.0 ** info.window_scale_log2[d] <= 2.0
-    # tile geometry: covers the grid, fits gfx950's LDS, row stride holds a padded row
+    # bins and tiles: cover the grid, tile edges are multiples of the bin edge, everything fits gfx950's LDS
     for d in range(len(dims)):
-        assert info.tile_padded[d] == info.tile_dims[d] + 2 * M - 1
-        assert info.ntiles[d] * info.tile_dims[d] >= o.Nover[d] > (info.ntiles[d] - 1) * info.tile_dims[d]
-    ncomp = 1 if is_real else 2
-    assert info.tile_row_stride >= ncomp * info.tile_padded[0]
+        b = info.bin_dims[d]
+        assert b in (1, 2, 4, 8, 16) and info.nbins[d] == -(-o.Nover[d] // b)
+        for tile, nt in ((info.spread_tile, info.spread_ntiles), (info.interp_tile, info.interp_ntiles)):
+            assert nt[d] * tile[d] >= o.Nover[d] > (nt[d] - 1) * tile[d]
+            assert tile[d] % b == 0 or nt[d] == 1
+        # clipped spreading needs room for the halo next to the tile unless one tile spans the axis
+        assert info.spread_ntiles[d] == 1 or info.spread_tile[d] + 2 * M - 1 <= o.Nover[d]
     assert 0 < info.lds_bytes_spread <= 163840 and 0 < info.lds_bytes_interp <= 163840
 
 
 def test_tile_choice_on_the_headline_config(nufft):
-    """C2 uses a non-cubic tile with a bank-aware row stride; its halo amplification must beat
-    the reference's 12^3 cube at 64 KiB (19^3 / 12^3 = 3.97)."""
+    """on C2 both halo amplifications must beat the reference's 12^3 cube at 64 KiB
+    (19^3 / 12^3 = 3.97): point visits per point for the output-driven spreading tile, tile-load
+    amplification for the interpolation tile."""
     p = nufft.PlanNUFFT(np.float64, (256, 256, 256), backend=None)
     i = p.info()
-    n = [i.tile_dims[d] for d in range(3)]
-    P = [i.tile_padded[d] for d in range(3)]
-    amp = np.prod(P) / np.prod(n)
-    assert amp < 3.0
-    assert i.tile_row_stride % 16 == 8      # rows of 8 doubles land on disjoint LDS banks
+    for tile in (i.spread_tile, i.interp_tile):
+        n = np.array([tile[d] for d in range(3)], dtype=float)
+        assert np.prod((n + 7) / n) < 2.8
 
 
 def test_error_codes_of_plan_creation(nufft):
