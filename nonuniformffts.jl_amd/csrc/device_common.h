@@ -42,6 +42,7 @@ struct TileShape {
     int plane_stride;  // row_stride * rows per plane
     int elems;         // LDS reals of the tile
     int ntiles;
+    int max_items;     // upper bound of the work items (runs of the sorted array) of one tile
 };
 
 struct Geom {
@@ -107,17 +108,19 @@ constexpr __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / 
 // the grid's own precision.
 constexpr __host__ __device__ int lanes_per_point(int ncomp, int M) { return next_pow2(ncomp * 2 * M); }
 
+//   [tile | work-item table (p0, p1 pairs) + fetch counter | per-wave window strips]
 struct LdsLayout {
-    int tile_bytes, strip_bytes_per_wave, total;
+    int tile_bytes, items_bytes, strip_bytes_per_wave, total;
 };
 
 constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int tile_elem_bytes, int real_bytes, int D, int M,
-                                                   int ncomp, int nwaves) {
+                                                   int ncomp, int nwaves, int max_items) {
     LdsLayout l{};
     l.tile_bytes = round_up(tile_elems * tile_elem_bytes, 16);
+    l.items_bytes = round_up(max_items * 8 + 16, 16);
     const int ppw = kWave / lanes_per_point(ncomp, M);           // points a wave works on at once
     l.strip_bytes_per_wave = round_up(ppw * D * 2 * M * real_bytes, 16);
-    l.total = l.tile_bytes + nwaves * l.strip_bytes_per_wave;
+    l.total = l.tile_bytes + l.items_bytes + nwaves * l.strip_bytes_per_wave;
     return l;
 }
 

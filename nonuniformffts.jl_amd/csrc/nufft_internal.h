@@ -45,6 +45,7 @@ struct TileShapeHost {
     int rows[2] = {1, 1};              // LDS rows per plane, planes
     int64_t elems = 0;                 // LDS reals
     int64_t ntiles = 1;
+    int max_items = 1;                 // upper bound of the work items (runs of sorted points) per tile
 };
 
 struct TileGeom {

@@ -55,6 +55,7 @@ static TileShape make_shape(const nufft::TileShapeHost& h) {
     t.plane_stride = h.row_stride * h.rows[0];
     t.elems = (int)h.elems;
     t.ntiles = (int)h.ntiles;
+    t.max_items = h.max_items;
     return t;
 }
 
@@ -241,8 +242,10 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
                     "LDS is too small for the chosen problem (element type, half-support M, dimensions): "
                     "reduce M or the tile size");
     }
-    p->lds_spread = lds_layout((int)p->tile.sp.elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64).total;
-    p->lds_interp = lds_layout((int)p->tile.ip.elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64).total;
+    p->lds_spread = lds_layout((int)p->tile.sp.elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64, p->tile.sp.max_items).total;
+    p->lds_interp = lds_layout((int)p->tile.ip.elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64, p->tile.ip.max_items).total;
+    if (p->lds_spread > kLdsLimit || p->lds_interp > kLdsLimit)
+        return fail(NUFFT_ERR_LDS_TOO_SMALL, "LDS is too small for the chosen problem: work-item table does not fit");
     if (p->tile.nbins >= ((int64_t)1 << 31) - 2) return fail(NUFFT_ERR_UNSUPPORTED, "too many bins");
     return NUFFT_OK;
 }

@@ -173,7 +173,7 @@ static int strip_bytes(int D, int M, int ncomp, int real_bytes, int nwaves) {
     while (g < ncomp * 2 * M) g <<= 1;
     const int ppw = 64 / g;
     const int per_wave = (ppw * D * 2 * M * real_bytes + 15) / 16 * 16;
-    return nwaves * per_wave;
+    return nwaves * per_wave + 6144;      // + reserve for the work-item table (checked exactly afterwards)
 }
 
 // Candidate tile edges along one axis: multiples of the bin size that leave room for the clipped halo
@@ -197,7 +197,7 @@ int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes) {
     return s;
 }
 
-static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, const int64_t* Nover, const int n[3], bool padded) {
+static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, const int64_t* Nover, const int n[3], bool padded, int bin_log2) {
     const int halo = padded ? 2 * M - 1 : 0;
     int P[3] = {1, 1, 1};
     t.ntiles = 1;
@@ -211,6 +211,15 @@ static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, const int64_t*
     t.rows[0] = P[1];
     t.rows[1] = P[2];
     t.elems = (int64_t)t.row_stride * P[1] * P[2];
+    // upper bound of the contiguous runs of sorted points a tile works through
+    const int b = 1 << bin_log2;
+    int64_t items = padded ? 1 : 2;
+    for (int d = 1; d < D; ++d) {
+        const int64_t nb = (Nover[d] + b - 1) / b;
+        const int64_t rows = padded ? n[d] / b + 1 : n[d] / b + 4;
+        items *= std::min<int64_t>(nb, rows);
+    }
+    t.max_items = (int)items;
 }
 
 bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,
@@ -258,7 +267,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
             }
             if (bn[0] == 0) return false;
         }
-        fill_shape(g.sp, D, M, ncomp, Nover, bn, false);
+        fill_shape(g.sp, D, M, ncomp, Nover, bn, false, bin_log2);
     }
     // --- interpolation tile: padded, grid precision; cost = halo amplification of the tile load ---
     {
@@ -299,7 +308,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
             }
             if (bn[0] == 0) return false;
         }
-        fill_shape(g.ip, D, M, ncomp, Nover, bn, true);
+        fill_shape(g.ip, D, M, ncomp, Nover, bn, true, bin_log2);
     }
     return true;
 }

@@ -239,9 +239,11 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         wrapd[d] = WRAP && ts.nt[d] == 1;   // a single tile spans the axis: wrap instead of clip
     }
 
-    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves);
+    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves, ts.max_items);
     A* tile = reinterpret_cast<A*>(smem);
-    T* strip_wave = reinterpret_cast<T*>(smem + lay.tile_bytes + wave * lay.strip_bytes_per_wave);
+    uint2* items = reinterpret_cast<uint2*>(smem + lay.tile_bytes);
+    int* next_item = reinterpret_cast<int*>(items + ts.max_items);
+    T* strip_wave = reinterpret_cast<T*>(smem + lay.tile_bytes + lay.items_bytes + wave * lay.strip_bytes_per_wave);
 
     for (int i = tid; i < ts.elems; i += nthreads) tile[i] = A(0);
 
@@ -262,9 +264,10 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         cmpf[ps] = e1 % NC;
         j1f[ps] = e1 / NC;
     }
-    __syncthreads();
 
-    // bins whose points can touch this tile
+    // Work items: the bins whose points can touch this tile form, per (bin2, bin3) row, one or two
+    // contiguous runs of the sorted array.  All runs are looked up at once (one round of loads for
+    // the whole workgroup) into an LDS table, and waves then pull items from a shared counter.
     BinSegs seg[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -272,22 +275,40 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         else { seg[d].n = 1; seg[d].lo[0] = 0; seg[d].len[0] = 1; seg[d].lo[1] = 0; seg[d].len[1] = 0; }
     }
     const int R2 = seg[1].total(), R3 = seg[2].total();
-    const int nitems = R2 * R3 * seg[0].n;
+    const int nitems = min(R2 * R3 * seg[0].n, ts.max_items);
+    for (int item = tid; item < nitems; item += nthreads) {
+        const int sg = item % seg[0].n;
+        const int r2 = (item / seg[0].n) % R2;
+        const int r3 = item / (seg[0].n * R2);
+        const int bin0 = (seg[2].bin(r3) * g.nb[1] + seg[1].bin(r2)) * g.nb[0] + (sg ? seg[0].lo[1] : seg[0].lo[0]);
+        items[item] = make_uint2(a.offsets[bin0], a.offsets[bin0 + (sg ? seg[0].len[1] : seg[0].len[0])]);
+    }
+    if (tid == 0) *next_item = 0;
+    __syncthreads();
 
     const PointRec<T, D>* sorted = static_cast<const PointRec<T, D>*>(a.sorted);
     const T* vin = a.vin[comp_id];
 
-    for (int item = wave; item < nitems; item += nwaves) {
-        const int sg = item % seg[0].n;
-        const int r2 = (item / seg[0].n) % R2;
-        const int r3 = item / (seg[0].n * R2);
-        const int bin0 = (seg[2].bin(r3) * g.nb[1] + seg[1].bin(r2)) * g.nb[0] + seg[0].lo[sg];
-        const uint32_t p0 = a.offsets[bin0];
-        const uint32_t p1 = a.offsets[bin0 + seg[0].len[sg]];
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(next_item, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= nitems) break;
+        const uint2 pr = items[item];
+        const uint32_t p0 = pr.x, p1 = pr.y;
+        if (p0 >= p1) continue;
+        // software pipeline: the record of the next chunk is requested before the current chunk is
+        // processed, its value right after
+        PointRec<T, D> rec = sorted[min(p0 + (uint32_t)grp, p1 - 1)];
+        T vcur = T(0);
+        if (q < NC) vcur = vin[(int64_t)rec.idx * NC + q];
         for (uint32_t pc = p0; pc < p1; pc += GP::PPW) {
             const uint32_t p = pc + grp;
             const bool have = p < p1;
-            const PointRec<T, D> rec = sorted[have ? p : p0];
+            const uint32_t npc = pc + GP::PPW;
+            const bool more = npc < p1;
+            PointRec<T, D> recn = rec;
+            if (more) recn = sorted[min(npc + (uint32_t)grp, p1 - 1)];
             int s[3] = {0, 0, 0};
             T X[3] = {T(0), T(0), T(0)};
             bool ok = have;
@@ -304,9 +325,8 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                 s[d] = sd;
             }
             const unsigned long long okmask = __ballot(ok);
-            if (okmask == 0ull) continue;                     // nothing of this chunk touches the tile
-            T vmine = T(0);
-            if (ok && q < NC) vmine = vin[(int64_t)rec.idx * NC + q];
+            const T vmine = vcur;
+            if (okmask != 0ull) {                             // else nothing of this chunk touches the tile
             wave_lds_fence();
             we.eval_to_strip(a, X, strip, q);
             wave_lds_fence();
@@ -383,6 +403,9 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                     }
                 }
             }
+            }   // okmask != 0
+            if (more && q < NC) vcur = vin[(int64_t)recn.idx * NC + q];
+            rec = recn;
         }
     }
     __syncthreads();
@@ -438,28 +461,34 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         blo[d] = d < D ? org[d] >> g.blog[d] : 0;
         bcnt[d] = d < D ? ((org[d] + neff[d] - 1) >> g.blog[d]) - blo[d] + 1 : 1;
     }
-    const int nitems = bcnt[1] * bcnt[2];
-    // skip the tile load when the tile holds no points (flag in the dynamic LDS region: HIP's
-    // __syncthreads_or would add static LDS on top of the 160 KiB request)
+    const int nitems = min(bcnt[1] * bcnt[2], ts.max_items);
+
+    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves, ts.max_items);
+    T* tile = reinterpret_cast<T*>(smem);
+    uint2* items = reinterpret_cast<uint2*>(smem + lay.tile_bytes);
+    int* next_item = reinterpret_cast<int*>(items + ts.max_items);
+    T* strip_wave = reinterpret_cast<T*>(smem + lay.tile_bytes + lay.items_bytes + wave * lay.strip_bytes_per_wave);
+
+    // Work items: one contiguous run of the sorted array per (bin2, bin3) row of the tile, looked up
+    // once into an LDS table.  The tile load is skipped when the tile holds no points (the flag lives
+    // in the dynamic LDS region: HIP's __syncthreads_or would add static LDS to the 160 KiB request).
     {
-        int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) *flag = 0;
+        if (tid == 0) *next_item = 0;
         __syncthreads();
         int any = 0;
         for (int item = tid; item < nitems; item += nthreads) {
             const int bin0 = ((blo[2] + item / bcnt[1]) * g.nb[1] + blo[1] + item % bcnt[1]) * g.nb[0] + blo[0];
-            any |= a.offsets[bin0] != a.offsets[bin0 + bcnt[0]];
+            const uint2 pr = make_uint2(a.offsets[bin0], a.offsets[bin0 + bcnt[0]]);
+            items[item] = pr;
+            any |= pr.x != pr.y;
         }
-        if (any) *flag = 1;
+        if (any) *next_item = 1;
         __syncthreads();
-        const int f = *flag;
+        const int f = *next_item;
         __syncthreads();
         if (!f) return;
+        if (tid == 0) *next_item = 0;
     }
-
-    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves);
-    T* tile = reinterpret_cast<T*>(smem);
-    T* strip_wave = reinterpret_cast<T*>(smem + lay.tile_bytes + wave * lay.strip_bytes_per_wave);
 
     // load the padded tile with periodic wrap (gridvalues_to_local_memory!, src/interpolation/gpu.jl:331-355)
     const T* grid = a.grid[comp_id];
@@ -492,14 +521,21 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     const PointRec<T, D>* sorted = static_cast<const PointRec<T, D>*>(a.sorted);
     T* vout = a.vout[comp_id];
 
-    for (int item = wave; item < nitems; item += nwaves) {
-        const int bin0 = ((blo[2] + item / bcnt[1]) * g.nb[1] + blo[1] + item % bcnt[1]) * g.nb[0] + blo[0];
-        const uint32_t p0 = a.offsets[bin0];
-        const uint32_t p1 = a.offsets[bin0 + bcnt[0]];
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(next_item, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= nitems) break;
+        const uint2 pr = items[item];
+        const uint32_t p0 = pr.x, p1 = pr.y;
+        if (p0 >= p1) continue;
+        PointRec<T, D> rec = sorted[min(p0 + (uint32_t)grp, p1 - 1)];
         for (uint32_t pc = p0; pc < p1; pc += GP::PPW) {
             const uint32_t p = pc + grp;
             const bool have = p < p1;
-            const PointRec<T, D> rec = sorted[have ? p : p0];
+            const uint32_t npc = pc + GP::PPW;
+            PointRec<T, D> recn = rec;
+            if (npc < p1) recn = sorted[min(npc + (uint32_t)grp, p1 - 1)];     // prefetch the next chunk
             int s[3] = {0, 0, 0};
             T X[3] = {T(0), T(0), T(0)};
 #pragma unroll
@@ -537,6 +573,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
             }
             acc = group_sum<T, GP::G, CPLX>(acc);
             if (have && q < NC) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
+            rec = recn;
         }
     }
 }
