@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnufft_mi355x.so")
+LIB_PATH = os.environ.get("NUFFT_LIB_PATH") or os.path.join(_HERE, "libnufft_mi355x.so")   # override: ablation builds
 
 # error codes (include/nufft_mi355x.h)
 OK = 0

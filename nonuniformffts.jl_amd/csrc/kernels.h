@@ -66,4 +66,21 @@ struct DeconvArgs {
 hipError_t launch_deconv_truncate(const DeconvArgs& a, void* const* uhat_out, hipStream_t stream);
 hipError_t launch_deconv_pad(const DeconvArgs& a, const void* const* uhat_in, hipStream_t stream);
 
+// ---- pruned strided FFT passes (fft_lines.hip) ----------------------------------------------------
+struct FftLinePass {
+    const void* in;
+    void* out;
+    int64_t a_total, a_out;                 // valid contiguous indices; (backward) columns written, rest zero
+    int64_t in_stride_j, in_stride_c;       // in elements (complex)
+    int64_t out_stride_j, out_stride_c;
+    int nc, nk;
+    const int32_t* map;                     // kept index -> FFT index
+    const void* fa; int ka;                 // T[ka], factor by (a mod ka)
+    const void* fk;                         // T[nk], factor by kept index
+    const void* twiddle;                    // complex<T>[N]
+    double scale;
+};
+bool fft_lines_supported(int dtype, int64_t n);
+hipError_t launch_fft_lines(int dtype, int logn, bool forward, const FftLinePass& p, hipStream_t stream);
+
 }  // namespace nufft

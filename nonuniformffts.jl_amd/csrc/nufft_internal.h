@@ -118,6 +118,17 @@ struct nufft_plan {
     size_t scan_tmp_bytes = 0;
     int64_t workspace_bytes = 0;
 
+    // pruned FFT path (fft_lines.hip): dimension 1 by rocFFT (1-D batched r2c / c2r), higher dimensions by
+    // pruned strided passes fused with the deconvolution
+    bool pruned_fft = false;
+    rocfft_plan_t* fft1_fw = nullptr;
+    rocfft_plan_t* fft1_bw = nullptr;
+    void* d_tmp2 = nullptr;            // complex<T>[N_out1 * N_out2 * Ñ3] (3-D only)
+    void* d_tw_fw[3] = {nullptr, nullptr, nullptr};   // complex<T>[Ñ_d] twiddles exp(-2πi m/Ñ_d)
+    void* d_tw_bw[3] = {nullptr, nullptr, nullptr};
+    void* d_invphi[3] = {nullptr, nullptr, nullptr};  // T[N_out_d]: 1 / (ϕ̂_d 2^scale_exp_d)
+    void* d_one = nullptr;             // T[1] = 1
+
     // rocFFT
     rocfft_plan_t* fft_fw = nullptr;
     rocfft_plan_t* fft_bw = nullptr;

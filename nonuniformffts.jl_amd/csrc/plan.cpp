@@ -333,6 +333,57 @@ static int build_device(nufft_plan* p) {
         NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
     }
 
+    // pruned FFT path: real plans, D >= 2, every higher dimension a power of two in 64..1024
+    p->pruned_fft = !p->is_complex && D >= 2 && env_int("NUFFT_PRUNED_FFT", 1) != 0;
+    for (int d = 1; d < D && p->pruned_fft; ++d) p->pruned_fft = fft_lines_supported(p->dtype, p->Nover[d]);
+    if (p->pruned_fft) {
+        size_t len1[1] = {(size_t)p->Nover[0]};
+        size_t batch = (size_t)p->C;
+        for (int d = 1; d < D; ++d) batch *= (size_t)p->Nover[d];
+        NUFFT_ROCFFT(rocfft_plan_create(&p->fft1_fw, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec, 1, len1, batch, nullptr));
+        NUFFT_ROCFFT(rocfft_plan_create(&p->fft1_bw, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec, 1, len1, batch, nullptr));
+        size_t w1 = 0, w2 = 0;
+        NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft1_fw, &w1));
+        NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft1_bw, &w2));
+        if (std::max(w1, w2) > p->fft_work_bytes) {
+            if (p->d_fft_work) { (void)hipFree(p->d_fft_work); p->workspace_bytes -= (int64_t)p->fft_work_bytes; p->d_fft_work = nullptr; }
+            p->fft_work_bytes = std::max(w1, w2);
+            if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes))) return rc;
+            NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
+        }
+        for (int d = 0; d < D; ++d) {
+            std::vector<double> inv(p->phihat[d].size());
+            for (size_t i = 0; i < inv.size(); ++i) {
+                const double v = p->dtype == NUFFT_F32 ? (double)(float)p->phihat[d][i] : p->phihat[d][i];
+                inv[i] = 1.0 / std::ldexp(v, p->scale_exp[d]);
+            }
+            rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_invphi[d], inv) : upload<double>(p, &p->d_invphi[d], inv);
+            if (rc) return rc;
+        }
+        {
+            std::vector<double> one(1, 1.0);
+            rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_one, one) : upload<double>(p, &p->d_one, one);
+            if (rc) return rc;
+        }
+        for (int d = 1; d < D; ++d) {
+            const int64_t n = p->Nover[d];
+            std::vector<double> twf(2 * (size_t)n), twb(2 * (size_t)n);
+            for (int64_t m = 0; m < n; ++m) {
+                const double ang = 2.0 * M_PI * (double)m / (double)n;
+                twf[2 * m] = std::cos(ang); twf[2 * m + 1] = -std::sin(ang);
+                twb[2 * m] = std::cos(ang); twb[2 * m + 1] = std::sin(ang);
+            }
+            rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_tw_fw[d], twf) : upload<double>(p, &p->d_tw_fw[d], twf);
+            if (rc) return rc;
+            rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_tw_bw[d], twb) : upload<double>(p, &p->d_tw_bw[d], twb);
+            if (rc) return rc;
+        }
+        if (D == 3) {
+            const size_t elems = (size_t)p->Nout[0] * p->Nout[1] * p->Nover[2];
+            if ((rc = dev_alloc(p, &p->d_tmp2, elems * 2 * real_bytes(p)))) return rc;
+        }
+    }
+
     // kernels: allow the large dynamic LDS allocations
     NUFFT_HIP(prepare_spread(p->dtype, p->is_complex, D, p->M, (int)p->lds_spread));
     NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp));
@@ -356,7 +407,10 @@ static void release(nufft_plan* p) {
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
         fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted);
-        fr(p->d_scan_tmp); fr(p->d_fft_work);
+        fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
+        for (int d = 0; d < 3; ++d) { fr(p->d_tw_fw[d]); fr(p->d_tw_bw[d]); fr(p->d_invphi[d]); }
+        if (p->fft1_fw) (void)rocfft_plan_destroy(p->fft1_fw);
+        if (p->fft1_bw) (void)rocfft_plan_destroy(p->fft1_bw);
         if (p->fft_fw) (void)rocfft_plan_destroy(p->fft_fw);
         if (p->fft_bw) (void)rocfft_plan_destroy(p->fft_bw);
         if (p->fft_info) (void)rocfft_execution_info_destroy(p->fft_info);
@@ -444,6 +498,99 @@ static int fft_exec(nufft_plan* p, bool forward, hipStream_t stream) {
         out[0] = p->d_us;
         NUFFT_ROCFFT(rocfft_execute(p->fft_bw, in, out, p->fft_info));
     }
+    return NUFFT_OK;
+}
+
+static int ilog2(int64_t n) {
+    int l = 0;
+    while (((int64_t)1 << l) < n) ++l;
+    return l;
+}
+
+// ---- pruned FFT path (see fft_lines.hip) ---------------------------------------------------------
+// type 1, stage "FFT": rocFFT r2c along dim 1 and, for D = 3, the pruned pass along dim 2 into tmp2.
+static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
+    NUFFT_ROCFFT(rocfft_execution_info_set_stream(p->fft_info, stream));
+    void* in[1] = {p->d_us};
+    void* out[1] = {p->d_uhat};
+    NUFFT_ROCFFT(rocfft_execute(p->fft1_fw, in, out, p->fft_info));
+    return NUFFT_OK;
+}
+
+static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hipStream_t stream) {
+    const size_t cb = 2 * real_bytes(p);
+    const int64_t S1 = p->Nspec[0], K1 = p->Nout[0];
+    FftLinePass q{};
+    q.map = p->d_index_map[dim];
+    q.nk = (int)p->Nout[dim];
+    q.twiddle = p->d_tw_fw[dim];
+    const bool last = dim == p->D - 1;
+    if (dim == 1) {
+        q.in = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * cb;
+        q.a_total = q.a_out = K1;
+        q.in_stride_j = S1;
+        q.in_stride_c = S1 * p->Nover[1];
+        q.nc = p->D == 3 ? (int)p->Nover[2] : 1;
+        q.out_stride_j = K1;
+        q.out_stride_c = K1 * p->Nout[1];
+        q.out = last ? user_out : p->d_tmp2;
+    } else {
+        q.in = p->d_tmp2;
+        q.a_total = q.a_out = K1 * p->Nout[1];
+        q.in_stride_j = K1 * p->Nout[1];
+        q.in_stride_c = 0;
+        q.nc = 1;
+        q.out_stride_j = K1 * p->Nout[1];
+        q.out_stride_c = 0;
+        q.out = user_out;
+    }
+    if (last) {
+        // deconvolution + normalisation fused into the last pass: normfactor / (ϕ̂1 ϕ̂_last) (ϕ̂2 was applied by pass 2)
+        q.fa = p->d_invphi[0]; q.ka = (int)K1;
+        q.fk = p->d_invphi[dim];
+        q.scale = 1.0;
+        for (int d = 0; d < p->D; ++d) q.scale *= 2.0 * M_PI / (double)p->Nover[d];
+    } else {
+        q.fa = p->d_one; q.ka = 1;
+        q.fk = p->d_invphi[dim];
+        q.scale = 1.0;
+    }
+    NUFFT_HIP(launch_fft_lines(p->dtype, ilog2(p->Nover[dim]), true, q, stream));
+    return NUFFT_OK;
+}
+
+static int pruned_backward_pass(nufft_plan* p, int c, int dim, const void* user_in, hipStream_t stream) {
+    const size_t cb = 2 * real_bytes(p);
+    const int64_t S1 = p->Nspec[0], K1 = p->Nout[0];
+    FftLinePass q{};
+    q.map = p->d_index_map[dim];
+    q.nk = (int)p->Nout[dim];
+    q.twiddle = p->d_tw_bw[dim];
+    q.scale = 1.0;
+    const bool first = dim == p->D - 1;       // the pass that reads the caller's array
+    if (dim == 2) {
+        q.in = user_in;
+        q.a_total = q.a_out = K1 * p->Nout[1];
+        q.in_stride_j = K1 * p->Nout[1];
+        q.in_stride_c = 0;
+        q.nc = 1;
+        q.out = p->d_tmp2;
+        q.out_stride_j = K1 * p->Nout[1];
+        q.out_stride_c = 0;
+    } else {
+        q.in = first ? user_in : p->d_tmp2;
+        q.a_total = K1;
+        q.a_out = S1;                          // columns k1 >= N_out1 of the oversampled spectrum are zeros
+        q.in_stride_j = K1;
+        q.in_stride_c = K1 * p->Nout[1];
+        q.nc = p->D == 3 ? (int)p->Nover[2] : 1;
+        q.out = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * cb;
+        q.out_stride_j = S1;
+        q.out_stride_c = S1 * p->Nover[1];
+    }
+    if (first) { q.fa = p->d_invphi[0]; q.ka = (int)K1; } else { q.fa = p->d_one; q.ka = 1; }
+    q.fk = p->d_invphi[dim];
+    NUFFT_HIP(launch_fft_lines(p->dtype, ilog2(p->Nover[dim]), false, q, stream));
     return NUFFT_OK;
 }
 
@@ -650,6 +797,11 @@ int nufft_fft_forward(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_FFT, stream);
+    if (p->pruned_fft) {
+        if ((rc = pruned_forward_fft(p, stream))) return rc;
+        if (p->D == 3 && p->C == 1) return pruned_forward_pass(p, 0, 1, nullptr, stream);
+        return NUFFT_OK;      // C > 1: tmp2 is reused per component, both passes run in the deconvolution stage
+    }
     return fft_exec(p, true, stream);
 }
 
@@ -662,6 +814,13 @@ int nufft_deconvolve_truncate(nufft_plan* p, void* const* uhat_out, void* stream
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_DECONV, stream);
+    if (p->pruned_fft) {
+        for (int c = 0; c < p->C; ++c) {
+            if (p->D == 3 && p->C > 1 && (rc = pruned_forward_pass(p, c, 1, nullptr, stream))) return rc;
+            if ((rc = pruned_forward_pass(p, c, p->D - 1, uhat_out[c], stream))) return rc;
+        }
+        return NUFFT_OK;
+    }
     DeconvArgs a = deconv_args(p);
     a.normfactor = 1.0;
     for (int d = 0; d < p->D; ++d) a.normfactor *= 2.0 * M_PI / (double)p->Nover[d];   // src/NonuniformFFTs.jl:181
@@ -678,6 +837,14 @@ int nufft_deconvolve_pad(nufft_plan* p, const void* const* uhat_in, void* stream
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_DECONV, stream);
+    if (p->pruned_fft) {
+        // zero-padding + deconvolution are fused into the pruned inverse passes; tmp2 is reused per component
+        for (int c = 0; c < p->C; ++c) {
+            if (p->D == 3 && (rc = pruned_backward_pass(p, c, 2, uhat_in[c], stream))) return rc;
+            if ((rc = pruned_backward_pass(p, c, 1, uhat_in[c], stream))) return rc;
+        }
+        return NUFFT_OK;
+    }
     DeconvArgs a = deconv_args(p);
     NUFFT_HIP(launch_deconv_pad(a, uhat_in, stream));
     return NUFFT_OK;
@@ -689,6 +856,13 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_FFT, stream);
+    if (p->pruned_fft) {
+        NUFFT_ROCFFT(rocfft_execution_info_set_stream(p->fft_info, stream));
+        void* in[1] = {p->d_uhat};
+        void* out[1] = {p->d_us};
+        NUFFT_ROCFFT(rocfft_execute(p->fft1_bw, in, out, p->fft_info));
+        return NUFFT_OK;
+    }
     return fft_exec(p, false, stream);
 }
 

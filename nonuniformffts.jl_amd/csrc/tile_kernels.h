@@ -26,6 +26,10 @@
 #include "device_common.h"
 #include "nufft_mi355x.h"
 
+#ifndef NUFFT_W3_READLANE
+#define NUFFT_W3_READLANE 1
+#endif
+
 namespace nufft {
 
 template <typename T>
@@ -138,7 +142,15 @@ struct WindowEval {
 
 template <typename T>
 __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
+#if defined(NUFFT_ABL_NO_ATOMIC)
+    {                                         // ablation build: keep operands alive, no LDS traffic
+        const unsigned lo = (unsigned)(unsigned long long)p;
+        const float f = (float)v;
+        asm volatile("" ::"v"(lo), "v"(f));
+    }
+#else
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 
 // Row walker for tile <-> global traffic: a wave instruction covers RPW rows of the tile
@@ -328,9 +340,12 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
             const T vmine = vcur;
             if (okmask != 0ull) {                             // else nothing of this chunk touches the tile
             wave_lds_fence();
+#if !defined(NUFFT_ABL_NO_EVAL)
             we.eval_to_strip(a, X, strip, q);
+#endif
             wave_lds_fence();
 
+#if !defined(NUFFT_ABL_NO_VISIT)
 #pragma unroll
             for (int gi = 0; gi < GP::PPW; ++gi) {
                 const int src = gi * GP::G;                    // first lane of the point's group
@@ -344,15 +359,25 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                 // the 2M window values of dimension 3: identical in every lane (broadcast LDS reads)
                 T w3[L];
                 if constexpr (D >= 3) {
+#if NUFFT_W3_READLANE
+                    const T w3l = sp[2 * L + (lane % L)];       // one LDS read, then scalar broadcasts
+#pragma unroll
+                    for (int j = 0; j < L; ++j) w3[j] = readlane_t(w3l, j);
+#else
 #pragma unroll
                     for (int j = 0; j < L; ++j) w3[j] = sp[2 * L + j];
+#endif
                 }
-                // valid planes: j3 in [lo3, hi3)
-                int lo3 = 0, hi3 = L;
+                // valid planes as a bit mask (bit j3 set: plane S3 + j3 lies inside the tile).  One scalar
+                // unit serves the whole CU, so the per-plane control is kept to a bit test + branch.
+                unsigned planes = (1u << L) - 1u;
+                int first3 = 0;
                 if constexpr (D >= 3) {
                     if (!wrapd[2]) {
-                        lo3 = max(0, -S3);
-                        hi3 = min(L, neff[2] - S3);
+                        const int lo3 = max(0, -S3);
+                        const int hi3 = min(L, neff[2] - S3);
+                        planes = ((1u << hi3) - 1u) & ~((1u << lo3) - 1u);
+                        first3 = lo3;
                     }
                 }
 #pragma unroll
@@ -382,20 +407,12 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                                     lds_atomic_add(addr + l3 * ts.plane_stride, (A)(w * w3[j3]));
                                 }
                             } else {
-                                A* pl = addr + (S3 + lo3) * ts.plane_stride;
-                                if (lo3 == 0 && hi3 == L) {          // the common case: all planes inside
+                                A* pl = addr + (S3 + first3) * ts.plane_stride;
 #pragma unroll
-                                    for (int j3 = 0; j3 < L; ++j3) {
+                                for (int j3 = 0; j3 < L; ++j3) {
+                                    if (planes & (1u << j3)) {
                                         lds_atomic_add(pl, (A)(w * w3[j3]));
                                         pl += ts.plane_stride;
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int j3 = 0; j3 < L; ++j3) {
-                                        if (j3 >= lo3 && j3 < hi3) {
-                                            lds_atomic_add(pl, (A)(w * w3[j3]));
-                                            pl += ts.plane_stride;
-                                        }
                                     }
                                 }
                             }
@@ -403,6 +420,9 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                     }
                 }
             }
+#else
+            asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(vmine));
+#endif
             }   // okmask != 0
             if (more && q < NC) vcur = vin[(int64_t)recn.idx * NC + q];
             rec = recn;

@@ -88,6 +88,12 @@ CASES = [
     (np.complex64, (16, 16, 16), 8, 2.0, O.FAST_APPROXIMATION, 1),
     (np.float64, (12, 16, 10), 10, 2.0, O.FAST_APPROXIMATION, 1),
     (np.float64, (30, 30, 30), 3, 2.0, O.DIRECT, 1),              # odd half-support
+    # power-of-two oversampled grids: the pruned FFT passes (fft_lines.hip) replace rocFFT's dims 2, 3
+    (np.float64, (32, 32, 32), 4, 2.0, O.DIRECT, 1),
+    (np.float64, (31, 31, 31), 4, 2.0, O.FAST_APPROXIMATION, 2),  # odd N_out, two transforms
+    (np.float32, (32, 64, 32), 4, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float64, (64, 128), 6, 2.0, O.DIRECT, 1),                 # 2-D: 128 x 256
+    (np.float64, (48, 128, 32), 4, 2.0, O.DIRECT, 1),             # dim 1 not a power of two (96), dims 2, 3 are
 ]
 
 
