@@ -59,7 +59,7 @@ def algorithmic_bytes(Np, Nover, Nout):
         "spread_kernel": 3 * G + P,
         "spread_kernel_min": G + P,
         "interp_kernel": G + P,                        # R(G) + R(coords) + W(values)
-        "type1_exec": 3 * G + P + (G + S) + 2 * Oo,    # zero + spread, FFT (single-pass ideal), deconv
+        "type1_exec": 3 * G + P + (G + S) + 2 * Oo,    # zero + spread, FFT (single-pass ideal), deconv (SURVEY 5.96 GB)
         "type2_exec": (S + 2 * Oo) + (S + G) + (G + P),
         "set_points": 2.0 * Np * 3 * 8,
     }
