@@ -100,7 +100,8 @@ def main():
     gather_stream = torch.cuda.Stream(device=dev) if distributed and not a.no_gather else None
     gather_list = None
     if gather_stream is not None and rank == 0:
-        gather_list = [[torch.empty_like(uhat[0]) for _ in range(world)] for _ in range(2)]
+        # complex spectra travel as their (re, im) real views (same bytes; every backend supports reals)
+        gather_list = [[torch.empty_like(torch.view_as_real(uhat[0])) for _ in range(world)] for _ in range(2)]
     gather_done = [None, None]
 
     def stream_ptr():
@@ -132,7 +133,7 @@ def main():
             gather_stream.wait_event(done)
             with torch.cuda.stream(gather_stream):
                 import torch.distributed as dist
-                dist.gather(out, gather_list[k % 2] if rank == 0 else None, dst=0)   # stream-ordered, host does not block
+                dist.gather(torch.view_as_real(out), gather_list[k % 2] if rank == 0 else None, dst=0)   # stream-ordered, host does not block
                 e = torch.cuda.Event()
                 e.record()
                 gather_done[k % 2] = e

@@ -107,3 +107,51 @@ def test_repeatability_and_reuse(case):
     exact = torch.complex((v[:n] * torch.cos(phase)).sum(), -(v[:n] * torch.sin(phase)).sum())
     assert float((us[3, 250, 5] - exact).abs() / exact.abs()) < 1e-5
     nufft.set_points(plan, xs)                    # restore for other tests
+
+
+def test_config_c3_complexf32_m8_1024_cubed_spot_check():
+    """BASELINE config C3 shape: 3-D, Ns = 512^3, ComplexF32, m = 8 (oversampled 1024^3, 8.6 GB grid; LDS pressure).
+    Np is reduced to 2e7 to keep the test short; exact spot checks of type-1 modes and type-2 points in Float64.
+    The reference's un-normalised Float32 window overflows at this (D, M) — see DESIGN.md §2."""
+    from nufft_pkg import nufft
+    Ns, Np, M8 = 512, 20_000_000, 8
+    plan = nufft.PlanNUFFT(torch.complex64, (Ns, Ns, Ns), m=M8, sigma=2.0, backend=nufft.ROCBackend(0),
+                           kernel_evalmode=nufft.FastApproximation())
+    assert plan.oversampled_dims == (1024, 1024, 1024)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xs = tuple(torch.rand(Np, dtype=torch.float32, device="cuda", generator=g) * (2 * np.pi) for _ in range(3))
+    v = torch.complex(torch.randn(Np, dtype=torch.float32, device="cuda", generator=g),
+                      torch.randn(Np, dtype=torch.float32, device="cuda", generator=g))
+    nufft.set_points(plan, xs)
+    u = torch.empty(plan.shape, dtype=torch.complex64, device="cuda")
+    nufft.exec_type1(u, plan, v)
+    assert bool(torch.isfinite(torch.view_as_real(u)).all())
+    k = torch.arange(Ns, dtype=torch.float64, device="cuda")
+    k = torch.where(k >= (Ns + 1) // 2, k - Ns, k)
+    x64 = [x.double() for x in xs]
+    v64 = v.to(torch.complex128)
+    rng = np.random.default_rng(3)
+    num = den = 0.0
+    for _ in range(12):
+        i1, i2, i3 = (int(rng.integers(0, Ns)) for _ in range(3))
+        phase = k[i1] * x64[0] + k[i2] * x64[1] + k[i3] * x64[2]
+        exact = (v64 * torch.polar(torch.ones_like(phase), -phase)).sum()
+        num += float((u[i3, i2, i1].to(torch.complex128) - exact).abs() ** 2)
+        den += float(exact.abs() ** 2)
+    # Float32 data: the bound is the Float32 round-off of coordinates and sums, not the m = 8 window (1e-14)
+    assert np.sqrt(num / den) < 2e-4
+    # type 2 back from a smooth random spectrum: spot-check points
+    w = torch.complex(torch.randn(plan.shape, dtype=torch.float32, device="cuda", generator=g),
+                      torch.randn(plan.shape, dtype=torch.float32, device="cuda", generator=g))
+    out = torch.empty(Np, dtype=torch.complex64, device="cuda")
+    nufft.exec_type2(out, plan, w)
+    w64 = w.to(torch.complex128)
+    num = den = 0.0
+    for j in rng.integers(0, Np, 6):
+        e1 = torch.polar(torch.ones_like(k), k * x64[0][j])
+        e2 = torch.polar(torch.ones_like(k), k * x64[1][j])
+        e3 = torch.polar(torch.ones_like(k), k * x64[2][j])
+        exact = torch.einsum("cba,c,b,a->", w64, e3, e2, e1)
+        num += float((out[j].to(torch.complex128) - exact).abs() ** 2)
+        den += float(exact.abs() ** 2)
+    assert np.sqrt(num / den) < 2e-4
