@@ -408,11 +408,19 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                                 }
                             } else {
                                 A* pl = addr + (S3 + first3) * ts.plane_stride;
+                                if (planes == (1u << L) - 1u) {      // all planes inside: no per-plane control
 #pragma unroll
-                                for (int j3 = 0; j3 < L; ++j3) {
-                                    if (planes & (1u << j3)) {
+                                    for (int j3 = 0; j3 < L; ++j3) {
                                         lds_atomic_add(pl, (A)(w * w3[j3]));
                                         pl += ts.plane_stride;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int j3 = 0; j3 < L; ++j3) {
+                                        if (planes & (1u << j3)) {
+                                            lds_atomic_add(pl, (A)(w * w3[j3]));
+                                            pl += ts.plane_stride;
+                                        }
                                     }
                                 }
                             }
