@@ -88,7 +88,9 @@ struct FftLineArgs {
 };
 
 // One radix-R Stockham stage of a line held in LDS (in place, wave-synchronous).
-template <typename T, int N, int R, int SIGN>
+// TWS: the twiddle table holds the roots of unity of order N * TWS (TWS = 2 for the half-length complex FFT
+// inside a real transform, whose table is shared with the real/complex split step).
+template <typename T, int N, int R, int SIGN, int TWS = 1>
 __device__ __forceinline__ void stage(typename Cplx2<T>::type* line, const typename Cplx2<T>::type* tw, int p, int lane) {
     using C = typename Cplx2<T>::type;
     constexpr int NB = N / R;                         // butterflies per line
@@ -106,7 +108,7 @@ __device__ __forceinline__ void stage(typename Cplx2<T>::type* line, const typen
             if (p > 1) {
                 const int step = k * (N / (p * R));   // w_{pR}^{k t} = w_N^{k t N / (p R)}
 #pragma unroll
-                for (int t = 1; t < R; ++t) u[b][t] = cmul(u[b][t], tw[(step * t) & (N - 1)]);
+                for (int t = 1; t < R; ++t) u[b][t] = cmul(u[b][t], tw[((step * t) & (N - 1)) * TWS]);
             }
             if constexpr (R == 8) dft8<SIGN, T>(u[b]);
             else if constexpr (R == 4) dft4<SIGN>(u[b]);
@@ -125,15 +127,15 @@ __device__ __forceinline__ void stage(typename Cplx2<T>::type* line, const typen
     wave_lds_fence();
 }
 
-template <typename T, int LOGN, int SIGN>
+template <typename T, int LOGN, int SIGN, int TWS = 1>
 __device__ __forceinline__ void fft_line(typename Cplx2<T>::type* line, const typename Cplx2<T>::type* tw, int lane) {
     constexpr int N = 1 << LOGN;
     int p = 1;
     constexpr int N8 = LOGN / 3;
 #pragma unroll
-    for (int s = 0; s < N8; ++s) { stage<T, N, 8, SIGN>(line, tw, p, lane); p *= 8; }
-    if constexpr (LOGN % 3 == 2) stage<T, N, 4, SIGN>(line, tw, p, lane);
-    if constexpr (LOGN % 3 == 1) stage<T, N, 2, SIGN>(line, tw, p, lane);
+    for (int s = 0; s < N8; ++s) { stage<T, N, 8, SIGN, TWS>(line, tw, p, lane); p *= 8; }
+    if constexpr (LOGN % 3 == 2) stage<T, N, 4, SIGN, TWS>(line, tw, p, lane);
+    if constexpr (LOGN % 3 == 1) stage<T, N, 2, SIGN, TWS>(line, tw, p, lane);
 }
 
 // FWD: full input (N along j), pruned output (nk along k').  BWD: pruned input, full output.
@@ -217,6 +219,132 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dimension 1 of real plans: r2c / c2r of contiguous lines with a *compact* spectrum (only the K1 = N1/2 + 1
+// kept modes are stored: row length K1 instead of Ñ1/2 + 1).  A real line of N = 2M samples is transformed as
+// one M-point complex FFT of z[n] = x[2n] + i x[2n+1] plus the usual even/odd split.
+// ---------------------------------------------------------------------------------------------------
+struct RealLineArgs {
+    const void* in;
+    void* out;
+    int64_t nlines;
+    int k1;                 // kept modes per line
+    const void* twiddle;    // complex<T>[N]: exp(SIGN 2πi m / N), N = 2M
+};
+
+template <typename T, int LOGM, bool FWD, int TL>
+__global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) {
+    using C = typename Cplx2<T>::type;
+    constexpr int M = 1 << LOGM;
+    constexpr int N = 2 * M;
+    constexpr int LINE = M + (M >> 4) + 1;
+    constexpr int XBUF = FWD ? 0 : (M + 2);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C* tw = reinterpret_cast<C*>(smem);                       // [N]
+    C* lines = tw + N;                                        // [TL][LINE + XBUF]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    const C* twg = static_cast<const C*>(a.twiddle);
+    for (int i = tid; i < N; i += TL * kWave) tw[i] = twg[i];
+    __syncthreads();
+    const int64_t line_id = (int64_t)blockIdx.x * TL + wave;
+    if (line_id >= a.nlines) return;
+    C* line = lines + wave * (LINE + XBUF);
+    if (FWD) {
+        const C* zin = reinterpret_cast<const C*>(static_cast<const T*>(a.in) + line_id * N);
+        for (int n = lane; n < M; n += kWave) line[lpad(n)] = zin[n];
+        wave_lds_fence();
+        fft_line<T, LOGM, -1, 2>(line, tw, lane);
+        C* xout = static_cast<C*>(a.out) + line_id * a.k1;
+        for (int k = lane; k < a.k1; k += kWave) {
+            const C zk = line[lpad(k & (M - 1))];
+            C zm = line[lpad((M - k) & (M - 1))];
+            zm.y = -zm.y;                                      // conj(Z[M - k])
+            const C e = cadd(zk, zm), d = csub(zk, zm);
+            // X[k] = (e - i w^k d) / 2,  w = exp(-2πi/N)
+            const C wd = cmul(tw[k], d);
+            C x;
+            x.x = T(0.5) * (e.x + wd.y);
+            x.y = T(0.5) * (e.y - wd.x);
+            xout[k] = x;
+        }
+    } else {
+        C* xb = line + LINE;                                   // X[0..M], zero beyond the kept modes
+        const C* xin = static_cast<const C*>(a.in) + line_id * a.k1;
+        for (int k = lane; k <= M; k += kWave) {
+            C v; v.x = T(0); v.y = T(0);
+            if (k < a.k1) v = xin[k];
+            // a c2r transform ignores the imaginary parts of the self-conjugate modes k = 0 and k = N/2
+            // (FFTW / rocFFT / numpy.irfft semantics: the result is the real part of the Hermitian sum)
+            if (k == 0 || k == M) v.y = T(0);
+            xb[k] = v;
+        }
+        wave_lds_fence();
+        for (int k = lane; k < M; k += kWave) {
+            const C xk = xb[k];
+            C xm = xb[M - k];
+            xm.y = -xm.y;                                      // conj(X[M - k])
+            const C e = cadd(xk, xm);
+            const C o = cmul(tw[k], csub(xk, xm));             // w^k (X[k] - conj(X[M-k])),  w = exp(+2πi/N)
+            C z;                                               // Z[k] = E'[k] + i O'[k]
+            z.x = e.x - o.y;
+            z.y = e.y + o.x;
+            line[lpad(k)] = z;
+        }
+        wave_lds_fence();
+        fft_line<T, LOGM, 1, 2>(line, tw, lane);
+        C* zout = reinterpret_cast<C*>(static_cast<T*>(a.out) + line_id * N);
+        for (int n = lane; n < M; n += kWave) zout[n] = line[lpad(n)];
+    }
+}
+
+template <typename T, int LOGM, bool FWD>
+static hipError_t launch_real_logm(const RealLineArgs& a, hipStream_t stream) {
+    using C = typename Cplx2<T>::type;
+    constexpr int M = 1 << LOGM;
+    constexpr int LINE = M + (M >> 4) + 1;
+    constexpr int XBUF = FWD ? 0 : (M + 2);
+    constexpr int TL = (sizeof(C) * (16 * (LINE + XBUF) + 2 * M) <= 150 * 1024) ? 16 : 8;
+    const size_t lds = sizeof(C) * (size_t)(TL * (LINE + XBUF) + 2 * M);
+    auto fn = real_lines_kernel<T, LOGM, FWD, TL>;
+    static bool prepared = false;
+    if (!prepared) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        prepared = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)((a.nlines + TL - 1) / TL)), dim3(TL * kWave), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename T, bool FWD>
+static hipError_t launch_real_t(int logm, const RealLineArgs& a, hipStream_t stream) {
+    switch (logm) {
+        case 6: return launch_real_logm<T, 6, FWD>(a, stream);
+        case 7: return launch_real_logm<T, 7, FWD>(a, stream);
+        case 8: return launch_real_logm<T, 8, FWD>(a, stream);
+        case 9: return launch_real_logm<T, 9, FWD>(a, stream);
+        case 10: return launch_real_logm<T, 10, FWD>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool real_lines_supported(int dtype, int64_t n) {
+    (void)dtype;
+    if (n < 128 || n > 2048) return false;
+    return (n & (n - 1)) == 0;
+}
+
+hipError_t launch_real_lines(int dtype, int logn, bool forward, const void* in, void* out, int64_t nlines, int k1,
+                             const void* twiddle, hipStream_t stream) {
+    RealLineArgs a;
+    a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.twiddle = twiddle;
+    const int logm = logn - 1;
+    if (dtype == NUFFT_F32) return forward ? launch_real_t<float, true>(logm, a, stream) : launch_real_t<float, false>(logm, a, stream);
+    return forward ? launch_real_t<double, true>(logm, a, stream) : launch_real_t<double, false>(logm, a, stream);
 }
 
 template <typename T, int LOGN, bool FWD>

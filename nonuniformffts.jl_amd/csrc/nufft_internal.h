@@ -121,6 +121,7 @@ struct nufft_plan {
     // pruned FFT path (fft_lines.hip): dimension 1 by rocFFT (1-D batched r2c / c2r), higher dimensions by
     // pruned strided passes fused with the deconvolution
     bool pruned_fft = false;
+    bool compact_dim1 = false;         // dimension 1 by real_lines_kernel with a compact spectrum (row length N_out1)
     rocfft_plan_t* fft1_fw = nullptr;
     rocfft_plan_t* fft1_bw = nullptr;
     void* d_tmp2 = nullptr;            // complex<T>[N_out1 * N_out2 * Ñ3] (3-D only)

@@ -365,7 +365,8 @@ static int build_device(nufft_plan* p) {
             rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_one, one) : upload<double>(p, &p->d_one, one);
             if (rc) return rc;
         }
-        for (int d = 1; d < D; ++d) {
+        p->compact_dim1 = real_lines_supported(p->dtype, p->Nover[0]) && env_int("NUFFT_COMPACT_DIM1", 1) != 0;
+        for (int d = p->compact_dim1 ? 0 : 1; d < D; ++d) {
             const int64_t n = p->Nover[d];
             std::vector<double> twf(2 * (size_t)n), twb(2 * (size_t)n);
             for (int64_t m = 0; m < n; ++m) {
@@ -510,6 +511,24 @@ static int ilog2(int64_t n) {
 // ---- pruned FFT path (see fft_lines.hip) ---------------------------------------------------------
 // type 1, stage "FFT": rocFFT r2c along dim 1 and, for D = 3, the pruned pass along dim 2 into tmp2.
 static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
+    if (p->compact_dim1) {
+        int64_t nlines = p->C;
+        for (int d = 1; d < p->D; ++d) nlines *= p->Nover[d];
+        // components are contiguous both in us (Ñ1 reals per line) and in the compact spectrum (N_out1 per line);
+        // the per-component offset of the compact spectrum is nlines_per_component * N_out1 <= spec_elems
+        if (p->C == 1) {
+            NUFFT_HIP(launch_real_lines(p->dtype, ilog2(p->Nover[0]), true, p->d_us, p->d_uhat, nlines, (int)p->Nout[0], p->d_tw_fw[0], stream));
+        } else {
+            const int64_t per = nlines / p->C;
+            const size_t rb = real_bytes(p);
+            for (int c = 0; c < p->C; ++c) {
+                const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
+                void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
+                NUFFT_HIP(launch_real_lines(p->dtype, ilog2(p->Nover[0]), true, in, out, per, (int)p->Nout[0], p->d_tw_fw[0], stream));
+            }
+        }
+        return NUFFT_OK;
+    }
     NUFFT_ROCFFT(rocfft_execution_info_set_stream(p->fft_info, stream));
     void* in[1] = {p->d_us};
     void* out[1] = {p->d_uhat};
@@ -519,7 +538,8 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
 
 static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hipStream_t stream) {
     const size_t cb = 2 * real_bytes(p);
-    const int64_t S1 = p->Nspec[0], K1 = p->Nout[0];
+    const int64_t K1 = p->Nout[0];
+    const int64_t S1 = p->compact_dim1 ? K1 : p->Nspec[0];      // row length of the dimension-1 spectrum
     FftLinePass q{};
     q.map = p->d_index_map[dim];
     q.nk = (int)p->Nout[dim];
@@ -561,7 +581,8 @@ static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hi
 
 static int pruned_backward_pass(nufft_plan* p, int c, int dim, const void* user_in, hipStream_t stream) {
     const size_t cb = 2 * real_bytes(p);
-    const int64_t S1 = p->Nspec[0], K1 = p->Nout[0];
+    const int64_t K1 = p->Nout[0];
+    const int64_t S1 = p->compact_dim1 ? K1 : p->Nspec[0];      // compact: no zero columns are written
     FftLinePass q{};
     q.map = p->d_index_map[dim];
     q.nk = (int)p->Nout[dim];
@@ -856,6 +877,17 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_FFT, stream);
+    if (p->pruned_fft && p->compact_dim1) {
+        int64_t per = 1;
+        for (int d = 1; d < p->D; ++d) per *= p->Nover[d];
+        const size_t rb = real_bytes(p);
+        for (int c = 0; c < p->C; ++c) {
+            const void* in = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
+            void* out = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
+            NUFFT_HIP(launch_real_lines(p->dtype, ilog2(p->Nover[0]), false, in, out, per, (int)p->Nout[0], p->d_tw_bw[0], stream));
+        }
+        return NUFFT_OK;
+    }
     if (p->pruned_fft) {
         NUFFT_ROCFFT(rocfft_execution_info_set_stream(p->fft_info, stream));
         void* in[1] = {p->d_uhat};
