@@ -124,6 +124,45 @@ constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int tile_elem
     return l;
 }
 
+// Compile-time interpolation tile for large grids (every edge shorter than the axis), 1024 threads and
+// the full 160 KiB of LDS: with constant row/plane strides all 2M x 2M LDS reads of a point use immediate
+// offsets from one base address.  Same cost model as the run-time search in plan_math.cpp (halo
+// amplification of the tile load); n[0] == 0: nothing fits with 4-cell bins.
+// LDS row stride (in reals) of a tile whose wave instructions touch `stencil_inner` contiguous reals in
+// each of several consecutive rows: the rows land on disjoint banks when the stride is congruent to the
+// stencil width modulo the 128-byte half of the bank period.
+constexpr __host__ __device__ int padded_row_stride(int inner_elems, int stencil_inner, int real_bytes) {
+    const int period = 128 / real_bytes;
+    if (stencil_inner >= period) return inner_elems;
+    int s = inner_elems;
+    while (s % period != stencil_inner % period) ++s;
+    return s;
+}
+
+struct FixedTileDims { int n[3]; int row_stride; };
+constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, int ncomp, int D, int M) {
+    const int L = 2 * M, halo = L - 1, b = 4, nwaves = 16;
+    const int ppw = kWave / lanes_per_point(ncomp, M);
+    const int strips = nwaves * round_up(ppw * D * L * elem_bytes, 16) + 6144;
+    const long avail = (163840 - 256 - strips) / elem_bytes;
+    const int cap = D == 1 ? 8192 : 96;
+    FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0};
+    double best_cost = 1e300;
+    for (int n3 = (D >= 3 ? b : 1); n3 <= (D >= 3 ? cap : 1); n3 += b)
+        for (int n2 = (D >= 2 ? b : 1); n2 <= (D >= 2 ? cap : 1); n2 += b)
+            for (int n1 = b; n1 <= cap; n1 += b) {
+                const int rs = ncomp * (n1 + halo);      // rows unpadded: LDS capacity beats bank alignment here
+                const long elems = (long)rs * (D >= 2 ? n2 + halo : 1) * (D >= 3 ? n3 + halo : 1);
+                if (elems > avail) break;
+                double cost = (double)(n1 + halo) / n1;
+                if (D >= 2) cost *= (double)(n2 + halo) / n2;
+                if (D >= 3) cost *= (double)(n3 + halo) / n3;
+                cost -= 1e-6 * n1;
+                if (cost < best_cost) { best_cost = cost; best.n[0] = n1; best.n[1] = n2; best.n[2] = n3; best.row_stride = rs; }
+            }
+    return best;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Window evaluation (backwards Kaiser-Bessel)
 // ---------------------------------------------------------------------------------------------

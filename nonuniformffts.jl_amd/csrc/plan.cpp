@@ -231,6 +231,17 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     env_tile("NUFFT_INTERP_TILE", forced_ip);
     int bin_log2 = in->bin_log2 > 0 ? in->bin_log2 : env_int("NUFFT_BIN_LOG2", 2);
     if (bin_log2 < 1 || bin_log2 > 4) return fail(NUFFT_ERR_INVALID_ARG, "bin_log2 must be in 1..4");
+    // Default configuration on a large grid: take the compile-time interpolation tile, whose kernel
+    // variant has constant LDS strides (fixed_interp_tile, device_common.h).
+    int fixed_ip[4] = {0, 0, 0, 0};
+    if (forced_ip[0] <= 0 && bin_log2 <= 2 && p->interp_threads == 1024 && budget == kLdsLimit - 256 &&
+        env_int("NUFFT_INTERP_FIXED", 1)) {
+        interp_fixed_dims(p->dtype, p->is_complex, p->D, p->M, fixed_ip);
+        bool ok = fixed_ip[0] > 0;
+        for (int d = 0; d < p->D && ok; ++d) ok = fixed_ip[d] < p->Nover[d];
+        if (ok) for (int d = 0; d < 3; ++d) forced_ip[d] = fixed_ip[d];
+        else fixed_ip[0] = 0;
+    }
     // Tile edges are multiples of the bin edge; when even one bin plus halo overflows the LDS (large M,
     // complex Float64) retry with smaller bins down to single cells.
     bool found = false;
@@ -242,6 +253,9 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
                     "LDS is too small for the chosen problem (element type, half-support M, dimensions): "
                     "reduce M or the tile size");
     }
+    p->interp_fixed = fixed_ip[0] > 0;
+    for (int d = 0; d < p->D; ++d) p->interp_fixed = p->interp_fixed && p->tile.ip.n[d] == fixed_ip[d];
+    p->interp_fixed = p->interp_fixed && p->tile.ip.row_stride == fixed_ip[3];
     p->lds_spread = lds_layout((int)p->tile.sp.elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64, p->tile.sp.max_items).total;
     p->lds_interp = lds_layout((int)p->tile.ip.elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64, p->tile.ip.max_items).total;
     if (p->lds_spread > kLdsLimit || p->lds_interp > kLdsLimit)
@@ -460,6 +474,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
         for (int d = 0; d < p->D; ++d) a.prefactor *= 2.0 * M_PI / (double)p->Nover[d];
     }
     a.threads = interp ? p->interp_threads : p->spread_threads;
+    a.fixed_tile = interp && p->interp_fixed;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
     a.ntiles = (int)(interp ? p->tile.ip.ntiles : p->tile.sp.ntiles);
     return a;

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <limits>
 
+#include "device_common.h"
 #include "nufft_internal.h"
 
 namespace nufft {
@@ -190,14 +191,10 @@ static void edge_candidates(int64_t N, int b, int M, int cap, std::vector<int>& 
 // when the stride is congruent to the stencil width modulo the 128-byte bank period.
 int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes) {
     static const bool no_pad = std::getenv("NUFFT_LDS_NO_PAD") != nullptr;
-    const int period = 128 / real_bytes;
-    if (no_pad || stencil_inner >= period) return inner_elems;
-    int s = inner_elems;
-    while (s % period != stencil_inner % period) ++s;
-    return s;
+    return no_pad ? inner_elems : padded_row_stride(inner_elems, stencil_inner, real_bytes);
 }
 
-static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, const int64_t* Nover, const int n[3], bool padded, int bin_log2) {
+static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, int real_bytes, const int64_t* Nover, const int n[3], bool padded, int bin_log2) {
     const int halo = padded ? 2 * M - 1 : 0;
     int P[3] = {1, 1, 1};
     t.ntiles = 1;
@@ -267,7 +264,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
             }
             if (bn[0] == 0) return false;
         }
-        fill_shape(g.sp, D, M, ncomp, Nover, bn, false, bin_log2);
+        fill_shape(g.sp, D, M, ncomp, real_bytes, Nover, bn, false, bin_log2);
     }
     // --- interpolation tile: padded, grid precision; cost = halo amplification of the tile load ---
     {
@@ -308,7 +305,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
             }
             if (bn[0] == 0) return false;
         }
-        fill_shape(g.ip, D, M, ncomp, Nover, bn, true, bin_log2);
+        fill_shape(g.ip, D, M, ncomp, real_bytes, Nover, bn, true, bin_log2);
     }
     return true;
 }

@@ -7,18 +7,32 @@ namespace nufft {
 
 using TileKernelPtr = void (*)(TileArgs<NUFFT_T>);
 
+#if defined(NUFFT_FIXED_DIMS_GETTER)
+// The 5th template flag of the interpolation kernel selects the compile-time tile; instantiate it only
+// where such a tile exists (fixed_interp_tile().n[0] > 0).
+template <int D, int M, bool FLAG>
+static TileKernelPtr inst() {
+    constexpr bool ok = !FLAG || fixed_interp_tile((int)sizeof(NUFFT_T), NUFFT_CPLX ? 2 : 1, D, M).n[0] > 0;
+    if constexpr (ok) return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, M, FLAG>;
+    else return nullptr;
+}
+#else
+template <int D, int M, bool FLAG>
+static TileKernelPtr inst() { return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, M, FLAG>; }
+#endif
+
 template <int D, bool WRAP>
 static TileKernelPtr pick_m(int M) {
     switch (M) {
-        case 2: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 2, WRAP>;
-        case 3: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 3, WRAP>;
-        case 4: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 4, WRAP>;
-        case 5: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 5, WRAP>;
-        case 6: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 6, WRAP>;
-        case 7: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 7, WRAP>;
-        case 8: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 8, WRAP>;
-        case 9: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 9, WRAP>;
-        case 10: return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, 10, WRAP>;
+        case 2: return inst<D, 2, WRAP>();
+        case 3: return inst<D, 3, WRAP>();
+        case 4: return inst<D, 4, WRAP>();
+        case 5: return inst<D, 5, WRAP>();
+        case 6: return inst<D, 6, WRAP>();
+        case 7: return inst<D, 7, WRAP>();
+        case 8: return inst<D, 8, WRAP>();
+        case 9: return inst<D, 9, WRAP>();
+        case 10: return inst<D, 10, WRAP>();
         default: return nullptr;
     }
 }
@@ -42,5 +56,13 @@ const void* NUFFT_GETTER(int D, int M, bool wrap) {
         default: return nullptr;
     }
 }
+
+#if defined(NUFFT_FIXED_DIMS_GETTER)
+void NUFFT_FIXED_DIMS_GETTER(int D, int M, int* n) {
+    const FixedTileDims fd = fixed_interp_tile((int)sizeof(NUFFT_T), NUFFT_CPLX ? 2 : 1, D, M);
+    for (int d = 0; d < 3; ++d) n[d] = fd.n[d];
+    n[3] = fd.row_stride;
+}
+#endif
 
 }  // namespace nufft

@@ -89,12 +89,11 @@ __device__ __forceinline__ BinSegs bin_segments(int lo, int hi, int N, int blog,
 // Window evaluation of one wave: the G lanes of a group evaluate the D*2M values of their point and
 // exchange them through the wave's LDS strip.  Coefficients of the piecewise polynomial stay in
 // registers (the lane's (dimension, j) role per slot never changes).
-template <typename T, int NC, int D, int M>
+template <typename T, int NC, int D, int M, int GS = Grp<NC, M>::G>
 struct WindowEval {
-    using GP = Grp<NC, M>;
     static constexpr int L = 2 * M;
     static constexpr int NV = D * L;
-    static constexpr int NSLOT = (NV + GP::G - 1) / GP::G;
+    static constexpr int NSLOT = (NV + GS - 1) / GS;
     static constexpr int NP = M + 4;
     T cs[NSLOT][NP];
     int dsel[NSLOT], jsel[NSLOT];
@@ -104,7 +103,7 @@ struct WindowEval {
     __device__ __forceinline__ void init(const TileArgs<T>& a, int q) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            const int k = q + s * GP::G;
+            const int k = q + s * GS;
             has[s] = k < NV;
             const int kk = has[s] ? k : 0;
             dsel[s] = kk / L;
@@ -135,7 +134,7 @@ struct WindowEval {
 #pragma unroll
                 for (int c = NP - 2; c >= 0; --c) val = fma(xx, val, cs[s][c]);
             }
-            if (has[s]) strip[q + s * GP::G] = val;
+            if (has[s]) strip[q + s * GS] = val;
         }
     }
 };
@@ -455,11 +454,15 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
 // ---------------------------------------------------------------------------------------------
 // Interpolation
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool CPLX, int D, int M, bool WRAP>
+// FIXED: the tile shape is the compile-time one of fixed_interp_tile() (the host launches this variant
+// only when the plan's tile equals it), which turns the LDS strides into immediates.
+template <typename T, bool CPLX, int D, int M, bool FIXED>
 __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
     using GP = Grp<NC, M>;
+    constexpr FixedTileDims FD = fixed_interp_tile((int)sizeof(T), NC, D, M);
+    static_assert(!FIXED || FD.n[0] > 0, "no compile-time tile for this instantiation");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -477,10 +480,13 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     int org[3], neff[3], P[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        org[d] = t[d] * ts.n[d];
-        neff[d] = min(ts.n[d], g.Nover[d] - org[d]);
-        P[d] = d < D ? ts.n[d] + L - 1 : 1;
+        const int nd = FIXED ? FD.n[d] : ts.n[d];
+        org[d] = t[d] * nd;
+        neff[d] = min(nd, g.Nover[d] - org[d]);
+        P[d] = d < D ? nd + L - 1 : 1;
     }
+    const int RS = FIXED ? FD.row_stride : ts.row_stride;
+    const int PS = FIXED ? FD.row_stride * (FD.n[1] + L - 1) : ts.plane_stride;
 
     // points of this tile: a box of bins, one contiguous run of the sorted array per (bin2, bin3)
     int blo[3], bcnt[3];
@@ -520,23 +526,50 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
 
     // load the padded tile with periodic wrap (gridvalues_to_local_memory!, src/interpolation/gpu.jl:331-355)
     const T* grid = a.grid[comp_id];
+#if !defined(NUFFT_ABL_INTERP_NOLOAD)
     {
+        // U rows per wave are in flight at once: all global loads of a batch are issued before the first
+        // LDS store waits for them (one row at a time leaves the load latency fully exposed — with one
+        // workgroup per CU nothing else hides it).
+        constexpr int U = 8;
         const int w_row = NC * P[0];
         RowWalker rw(P[1], P[2], w_row, wave, nwaves, lane);
         const int o1 = org[0] - (M - 1), o2 = org[1] - (M - 1), o3 = org[2] - (M - 1);
-        for (; rw.valid(); rw.next()) {
-            int64_t rowbase = 0;
-            if constexpr (D >= 2) rowbase = (int64_t)wrap_index(o2 + rw.l2, g.Nover[1]);
-            if constexpr (D >= 3) rowbase += (int64_t)wrap_index(o3 + rw.l3, g.Nover[2]) * g.Nover[1];
-            rowbase *= (int64_t)g.Nover[0] * NC;
-            T* dst = tile + rw.l2 * ts.row_stride + rw.l3 * ts.plane_stride;
-            for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) {
+        while (rw.valid()) {
+            const T* src[U];
+            T* dst[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = rw.valid();
+                int64_t rowbase = 0;
+                if constexpr (D >= 2) rowbase = (int64_t)wrap_index(o2 + rw.l2, g.Nover[1]);
+                if constexpr (D >= 3) rowbase += (int64_t)wrap_index(o3 + min(rw.l3, P[2] - 1), g.Nover[2]) * g.Nover[1];
+                src[u] = grid + rowbase * ((int64_t)g.Nover[0] * NC);
+                dst[u] = tile + rw.l2 * RS + rw.l3 * PS;
+                rw.next();
+            }
+            auto copy = [&](int e) {
                 const int l1 = e / NC, c = e % NC;
-                const int g1 = wrap_index(o1 + l1, g.Nover[0]);
-                dst[e] = grid[rowbase + (int64_t)g1 * NC + c];
+                const int goff = wrap_index(o1 + l1, g.Nover[0]) * NC + c;
+                T v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = ok[u] ? src[u][goff] : T(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ok[u]) dst[u][e] = v[u];
+            };
+            if (w_row <= kWave) {            // one lane per real of the row: straight-line code
+                if (rw.lane_in_row < w_row) copy(rw.lane_in_row);
+            } else {
+                for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) copy(e);
             }
         }
     }
+#endif
+#if defined(NUFFT_ABL_INTERP_NOPTS)
+    if (a.evalmode >= 0) return;
+#endif
 
     const int grp = lane / GP::G, q = lane % GP::G;
     const bool lane_active = q < GP::W1;
@@ -548,6 +581,11 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
 
     const PointRec<T, D>* sorted = static_cast<const PointRec<T, D>*>(a.sorted);
     T* vout = a.vout[comp_id];
+    // The point loop wants run-time strides even in the FIXED variant: with immediates the compiler pairs
+    // the reads of rows j2, j2 + 1 into ds_read2_b64, whose two addresses share banks when the row
+    // stride is not bank-aligned (measured 30 % slower on f64 / M = 4).
+    int RSp = RS, PSp = PS;
+    asm volatile("" : "+s"(RSp), "+s"(PSp));
 
     for (;;) {
         int item = 0;
@@ -573,32 +611,41 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
                 s[d] = c - org[d];                 // first stencil node in padded-tile coordinates
             }
             wave_lds_fence();
+#if !defined(NUFFT_ABL_NO_EVAL)
             we.eval_to_strip(a, X, strip, q);
+#endif
             wave_lds_fence();
             const T w1 = strip[j1];
-            const T* base = tile + (s[0] + j1) * NC + comp + s[1] * ts.row_stride + s[2] * ts.plane_stride;
+#if defined(NUFFT_ABL_INTERP_SAMEADDR)
+            for (int d = 0; d < D; ++d) s[d] = __builtin_amdgcn_readfirstlane(s[d]);
+#endif
+            const T* base = tile + (s[0] + j1) * NC + comp + s[1] * RSp + s[2] * PSp;
             T acc = T(0);
+#if defined(NUFFT_ABL_INTERP_NOREAD)
+            if (have && lane_active) acc = base[0] * w1;
+#else
             if (have && lane_active) {
                 if constexpr (D == 1) {
                     acc = base[0];
                 } else if constexpr (D == 2) {
 #pragma unroll
-                    for (int j2 = 0; j2 < L; ++j2) acc = fma(base[j2 * ts.row_stride], strip[L + j2], acc);
+                    for (int j2 = 0; j2 < L; ++j2) acc = fma(base[j2 * RSp], strip[L + j2], acc);
                 } else {
                     T w2[L];
 #pragma unroll
                     for (int j = 0; j < L; ++j) w2[j] = strip[L + j];
 #pragma unroll
                     for (int j3 = 0; j3 < L; ++j3) {
-                        const T* plane = base + j3 * ts.plane_stride;
+                        const T* plane = base + j3 * PSp;
                         T t2 = T(0);
 #pragma unroll
-                        for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * ts.row_stride], w2[j2], t2);
+                        for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * RSp], w2[j2], t2);
                         acc = fma(t2, strip[2 * L + j3], acc);
                     }
                 }
                 acc *= w1;
             }
+#endif
             acc = group_sum<T, GP::G, CPLX>(acc);
             if (have && q < NC) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
             rec = recn;

@@ -15,18 +15,33 @@ const void* interp_kernel_f32c(int D, int M, bool wrap);
 const void* interp_kernel_f64r(int D, int M, bool wrap);
 const void* interp_kernel_f64c(int D, int M, bool wrap);
 
-static const void* pick(bool interp, int dtype, int is_complex, int D, int M, bool wrap) {
+void interp_fixed_dims_f32r(int D, int M, int* n);
+void interp_fixed_dims_f32c(int D, int M, int* n);
+void interp_fixed_dims_f64r(int D, int M, int* n);
+void interp_fixed_dims_f64c(int D, int M, int* n);
+
+void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n) {
+    n[0] = n[1] = n[2] = n[3] = 0;
+    if (M < 2 || M > 10 || D < 1 || D > 3) return;
+    if (dtype == NUFFT_F32) is_complex ? interp_fixed_dims_f32c(D, M, n) : interp_fixed_dims_f32r(D, M, n);
+    else is_complex ? interp_fixed_dims_f64c(D, M, n) : interp_fixed_dims_f64r(D, M, n);
+}
+
+// `flag`: spreading = single-tile axis (wrap variant); interpolation = compile-time tile.
+static const void* pick(bool interp, int dtype, int is_complex, int D, int M, bool flag) {
+    const bool wrap = flag;
     if (interp) {
-        if (dtype == NUFFT_F32) return is_complex ? interp_kernel_f32c(D, M, false) : interp_kernel_f32r(D, M, false);
-        return is_complex ? interp_kernel_f64c(D, M, false) : interp_kernel_f64r(D, M, false);
+        if (dtype == NUFFT_F32) return is_complex ? interp_kernel_f32c(D, M, flag) : interp_kernel_f32r(D, M, flag);
+        return is_complex ? interp_kernel_f64c(D, M, flag) : interp_kernel_f64r(D, M, flag);
     }
     if (dtype == NUFFT_F32) return is_complex ? spread_kernel_f32c(D, M, wrap) : spread_kernel_f32r(D, M, wrap);
     return is_complex ? spread_kernel_f64c(D, M, wrap) : spread_kernel_f64r(D, M, wrap);
 }
 
 static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, int lds_bytes) {
-    for (int wrap = 0; wrap < (interp ? 1 : 2); ++wrap) {
+    for (int wrap = 0; wrap < 2; ++wrap) {
         const void* fn = pick(interp, dtype, is_complex, D, M, wrap != 0);
+        if (!fn && interp && wrap) continue;       // no compile-time tile for this instantiation
         if (!fn) return hipErrorInvalidValue;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -45,7 +60,7 @@ template <typename T>
 static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t stream) {
     bool wrap = false;
     for (int d = 0; d < a.D; ++d) wrap = wrap || a.g.sp.nt[d] == 1;
-    const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, wrap);
+    const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, interp ? a.fixed_tile != 0 : wrap);
     if (!fn) return hipErrorInvalidValue;
     const int ncr = a.is_complex ? 2 : 1;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
