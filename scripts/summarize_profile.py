@@ -58,6 +58,17 @@ def main():
                 continue
             out.append(f"| `{short(n)}` | {f:.3f} | {2 * f:.3f} | {w:.3f} | {2 * f + w:.3f} |")
         out.append("")
+    if pmc:
+        import json
+        traffic = {}
+        for n in sorted(set(pmc.get("fetch", {})) | set(pmc.get("write", {}))):
+            f = pmc.get("fetch", {}).get(n, 0.0) * 1024
+            w = pmc.get("write", {}).get(n, 0.0) * 1024
+            traffic[short(n)] = {"fetch_size_bytes_raw": f, "read_bytes_corrected": 2 * f, "write_bytes": w,
+                                 "hbm_bytes_per_launch": 2 * f + w}
+        with open(prefix + "_traffic.json", "w") as fh:
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, "
+                                 "FETCH_SIZE x2 gfx950 correction (MI355X_MICROARCH.md)", "kernels": traffic}, fh, indent=1)
     with open(prefix + ".md", "w") as fh:
         fh.write("\n".join(out) + "\n")
     if stats:
