@@ -48,7 +48,12 @@ enum {
 
 /* ---- enums --------------------------------------------------------------------------- */
 enum { NUFFT_F32 = 0, NUFFT_F64 = 1 };                         /* real(Z) of the plan            */
-enum { NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL = 0 };             /* default_kernel(::ROCBackend)   */
+enum {                                                          /* the four kernels of src/Kernels */
+    NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL = 0,  /* default_kernel(::ROCBackend), kaiser_bessel_backwards.jl */
+    NUFFT_KERNEL_KAISER_BESSEL           = 1,  /* KaiserBesselKernel, kaiser_bessel.jl                     */
+    NUFFT_KERNEL_GAUSSIAN                = 2,  /* GaussianKernel, gaussian.jl                              */
+    NUFFT_KERNEL_BSPLINE                 = 3   /* BSplineKernel, bspline.jl                                */
+};
 enum { NUFFT_EVAL_DIRECT = 0, NUFFT_EVAL_FAST_APPROXIMATION = 1 }; /* Kernels.EvaluationMode     */
 enum { NUFFT_METHOD_SHARED_MEMORY = 0 };                       /* gpu_method = :shared_memory    */
 enum { NUFFT_POINT_TRANSFORM_IDENTITY = 0 };                   /* point_transform = identity     */
@@ -93,7 +98,10 @@ typedef struct nufft_params {
     int32_t interp_threads;  /* workgroup size of the interpolation kernel                         */
     int32_t interp_tile_dims[3]; /* interpolation tile interior (cells)                            */
     int32_t bin_log2;        /* log2 of the bin edge of the point sort (default 2: 4^D cells)      */
-    int32_t reserved[4];
+    int32_t reserved0;
+    double  kernel_param;    /* KaiserBesselKernel(β) / BackwardsKaiserBesselKernel(β) / GaussianKernel(ℓ):
+                                explicit shape parameter; 0 -> the optimal one for (M, σ)              */
+    int32_t reserved[2];
 } nufft_params;
 
 /* What show(::PlanNUFFT) prints (src/plan.jl:362-392) plus sizes a caller needs. */
@@ -103,7 +111,7 @@ typedef struct nufft_info {
     int64_t N_over[3];       /* oversampled grid dims  (src/plan.jl:485-498)                       */
     int64_t N_out[3];        /* size(p): dims of the uniform arrays (src/plan.jl:426)              */
     double  sigma;           /* actual sigma = max(N_over / N) (src/plan.jl:500)                   */
-    double  beta[3];         /* kernel shape parameter per dimension                               */
+    double  beta[3];         /* kernel shape parameter per dimension (β; ℓ/Δx for the Gaussian; 0: B-spline) */
     int32_t bin_dims[3];     /* cells per sort bin                                                 */
     int32_t nbins[3];        /* bins per dimension                                                 */
     int32_t spread_tile[3];  /* spreading tile: interior cells held in LDS (no halo)               */
@@ -116,7 +124,8 @@ typedef struct nufft_info {
     int64_t num_points;      /* Np of the last set_points                                          */
     int32_t npoly;           /* M + 4 polynomial coefficients per sub-interval                     */
     int32_t window_scale_log2[3]; /* device windows and phi_hat are scaled by 2^k_d (exact) */
-    int32_t reserved[4];
+    int32_t kernel;          /* NUFFT_KERNEL_*                                                     */
+    int32_t reserved[3];
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */

@@ -9,7 +9,7 @@ The directory name contains a dot, so load it with ``nufft_pkg.py`` at the repo 
 """
 from ._lib import LIB_PATH, lib  # noqa: F401  (fails loudly if the extension is missing)
 from .plan import (  # noqa: F401
-    BackwardsKaiserBesselKernel, DimensionMismatch, Direct, FastApproximation, HalfSupport,
+    BackwardsKaiserBesselKernel, BSplineKernel, GaussianKernel, KaiserBesselKernel, DimensionMismatch, Direct, FastApproximation, HalfSupport,
     NUFFTCallbacks, PlanNUFFT, ROCBackend, default_kernel, default_kernel_evalmode, exec_type1,
     exec_type1_, exec_type2, exec_type2_, interpolate, oversampled_grid, set_points, set_points_,
     sort_result, spread_from_points,
@@ -17,6 +17,6 @@ from .plan import (  # noqa: F401
 
 __all__ = [
     "PlanNUFFT", "NUFFTCallbacks", "HalfSupport", "Direct", "FastApproximation",
-    "BackwardsKaiserBesselKernel", "ROCBackend", "DimensionMismatch",
+    "BackwardsKaiserBesselKernel", "KaiserBesselKernel", "GaussianKernel", "BSplineKernel", "ROCBackend", "DimensionMismatch",
     "set_points", "exec_type1", "exec_type2", "set_points_", "exec_type1_", "exec_type2_",
 ]

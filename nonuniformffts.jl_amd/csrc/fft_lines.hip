@@ -240,10 +240,9 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
     constexpr int M = 1 << LOGM;
     constexpr int N = 2 * M;
     constexpr int LINE = M + (M >> 4) + 1;
-    constexpr int XBUF = FWD ? 0 : (M + 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     C* tw = reinterpret_cast<C*>(smem);                       // [N]
-    C* lines = tw + N;                                        // [TL][LINE + XBUF]
+    C* lines = tw + N;                                        // [TL][LINE]
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
     __syncthreads();
     const int64_t line_id = (int64_t)blockIdx.x * TL + wave;
     if (line_id >= a.nlines) return;
-    C* line = lines + wave * (LINE + XBUF);
+    C* line = lines + wave * LINE;
     if (FWD) {
         const C* zin = reinterpret_cast<const C*>(static_cast<const T*>(a.in) + line_id * N);
         for (int n = lane; n < M; n += kWave) line[lpad(n)] = zin[n];
@@ -272,27 +271,31 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
             xout[k] = x;
         }
     } else {
-        C* xb = line + LINE;                                   // X[0..M], zero beyond the kept modes
+        // Z[k] = E'[k] + i O'[k] with E' = X[k] + conj(X[M-k]), O' = w^k (X[k] - conj(X[M-k])), w = exp(+2πi/N).
+        // The partner of k is M - k: Z[M-k] = conj(E'[k]) + i conj(O'[k]), so one lane builds both from two
+        // global loads and no staging copy of X is needed in LDS (X is zero beyond the kept modes).
         const C* xin = static_cast<const C*>(a.in) + line_id * a.k1;
-        for (int k = lane; k <= M; k += kWave) {
-            C v; v.x = T(0); v.y = T(0);
-            if (k < a.k1) v = xin[k];
+        for (int k = lane; k <= M / 2; k += kWave) {
+            C xk, xm;
+            xk.x = xk.y = xm.x = xm.y = T(0);
+            if (k < a.k1) xk = xin[k];
+            if (M - k < a.k1) xm = xin[M - k];
             // a c2r transform ignores the imaginary parts of the self-conjugate modes k = 0 and k = N/2
             // (FFTW / rocFFT / numpy.irfft semantics: the result is the real part of the Hermitian sum)
-            if (k == 0 || k == M) v.y = T(0);
-            xb[k] = v;
-        }
-        wave_lds_fence();
-        for (int k = lane; k < M; k += kWave) {
-            const C xk = xb[k];
-            C xm = xb[M - k];
+            if (k == 0) { xk.y = T(0); xm.y = T(0); }
             xm.y = -xm.y;                                      // conj(X[M - k])
             const C e = cadd(xk, xm);
-            const C o = cmul(tw[k], csub(xk, xm));             // w^k (X[k] - conj(X[M-k])),  w = exp(+2πi/N)
-            C z;                                               // Z[k] = E'[k] + i O'[k]
+            const C o = cmul(tw[k], csub(xk, xm));
+            C z;
             z.x = e.x - o.y;
             z.y = e.y + o.x;
             line[lpad(k)] = z;
+            if (k > 0 && k < M / 2) {
+                C zp;                                          // conj(e) + i conj(o)
+                zp.x = e.x + o.y;
+                zp.y = o.x - e.y;
+                line[lpad(M - k)] = zp;
+            }
         }
         wave_lds_fence();
         fft_line<T, LOGM, 1, 2>(line, tw, lane);
@@ -306,9 +309,8 @@ static hipError_t launch_real_logm(const RealLineArgs& a, hipStream_t stream) {
     using C = typename Cplx2<T>::type;
     constexpr int M = 1 << LOGM;
     constexpr int LINE = M + (M >> 4) + 1;
-    constexpr int XBUF = FWD ? 0 : (M + 2);
-    constexpr int TL = (sizeof(C) * (16 * (LINE + XBUF) + 2 * M) <= 150 * 1024) ? 16 : 8;
-    const size_t lds = sizeof(C) * (size_t)(TL * (LINE + XBUF) + 2 * M);
+    constexpr int TL = (sizeof(C) * (16 * LINE + 2 * M) <= 150 * 1024) ? 16 : 8;
+    const size_t lds = sizeof(C) * (size_t)(TL * LINE + 2 * M);
     auto fn = real_lines_kernel<T, LOGM, FWD, TL>;
     static bool prepared = false;
     if (!prepared) {

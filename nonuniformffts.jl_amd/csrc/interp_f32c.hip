@@ -3,6 +3,5 @@
 #define NUFFT_CPLX true
 #define NUFFT_KERNEL interp_tile_kernel
 #define NUFFT_GETTER interp_kernel_f32c
-#define NUFFT_HAS_WRAP_VARIANT 1      // flag = compile-time tile (FIXED)
 #define NUFFT_FIXED_DIMS_GETTER interp_fixed_dims_f32c
 #include "tile_inst.h"

@@ -30,12 +30,13 @@ hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np,
 // ---- spreading / interpolation (spread_*.hip, interp_*.hip) -------------------------------------
 struct TileKernelArgs {
     int dtype, is_complex, D, M, evalmode, C;
+    int kernel;                // NUFFT_KERNEL_*
     Geom g;
     const void* sorted;        // PointRec<T, D>[np]
     const uint32_t* offsets;   // [nbins + 1]
     const void* coefs;         // T[D][npoly][2M]
-    double beta[3];
-    double beta_over_pi[3];    // (β/π) * 2^scale_exp, see plan.cpp
+    double beta[3];            // first window parameter per dimension (β; Δx for the Gaussian)
+    double beta_over_pi[3];    // second one: BKB (β/π) 2^k, KB 2^k, Gaussian τ (see WindowEval, plan.cpp)
     void* grid;                // C grids, contiguous, Z[Nover...]
     int64_t grid_stride;       // elements of Z between components
     const void* const* values_in;   // spread: C device vectors Z[np]
@@ -52,8 +53,9 @@ void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n);
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
 hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);
 // Sets the dynamic-LDS attribute of every instantiation that may be launched for this configuration.
-hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes);
-hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes);
+hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes, bool other);
+hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes, bool other);
+bool needs_other_eval(int kernel, int evalmode);
 
 // ---- deconvolution (deconv.hip) ------------------------------------------------------------------
 struct DeconvArgs {

@@ -26,6 +26,11 @@ void set_error(const std::string& msg);
 int64_t nextprod235(int64_t n);
 int64_t oversampled_size(int64_t N, double sigma, bool real_first_dim);
 double bkb_beta(int M, double sigma_d);
+double kb_beta(int M, double sigma_d);
+double gaussian_ell(int M, double sigma_d);
+void kb_poly_coefficients(int M, double beta, std::vector<double>& cs);
+void fourier_coefficients_kernel(int kernel, const std::vector<double>& ks, int M, int64_t Nover, double param,
+                                 std::vector<double>& phihat);
 double bkb_function(double y, double beta);
 double bessel_i0(double x);
 // cs[k * 2M + j]: coefficient of x^k on sub-interval j (j = 0 is the rightmost one).
@@ -88,6 +93,9 @@ struct nufft_plan {
     int64_t Nspec[3] = {1, 1, 1};      // dims of the oversampled spectrum (r2c halves dim 0)
     double sigma = 2.0;
     double beta[3] = {0, 0, 0};
+    int kernel = 0;                    // NUFFT_KERNEL_*
+    double tau[3] = {0, 0, 0};         // Gaussian: 2 (ℓ Δx)²
+    double eval_p0[3] = {0, 0, 0};     // window parameters handed to the kernels (see WindowEval)
     int scale_exp[3] = {0, 0, 0};      // device windows and phi_hat carry a factor 2^scale_exp[d]
     double beta_over_pi_scaled[3] = {0, 0, 0};   // (β/π rounded to T) * 2^scale_exp[d]
     int npoly = 8;

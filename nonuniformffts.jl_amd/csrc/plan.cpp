@@ -152,7 +152,11 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
 
     if (p->dtype != NUFFT_F32 && p->dtype != NUFFT_F64) return fail(NUFFT_ERR_INVALID_ARG, "dtype must be NUFFT_F32 or NUFFT_F64");
     if (p->D < 1 || p->D > 3) return fail(NUFFT_ERR_UNSUPPORTED, "ndim must be 1, 2 or 3");
-    if (in->kernel != NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) return fail(NUFFT_ERR_UNSUPPORTED, "only BackwardsKaiserBesselKernel is built");
+    if (in->kernel < NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL || in->kernel > NUFFT_KERNEL_BSPLINE)
+        return fail(NUFFT_ERR_UNSUPPORTED, "kernel must be one of NUFFT_KERNEL_* (BackwardsKaiserBessel, KaiserBessel, Gaussian, BSpline)");
+    p->kernel = in->kernel;
+    if (in->kernel_param < 0.0 || (in->kernel_param != 0.0 && p->kernel == NUFFT_KERNEL_BSPLINE))
+        return fail(NUFFT_ERR_INVALID_ARG, "kernel_param must be positive (and BSplineKernel has no parameter)");
     if (p->evalmode != NUFFT_EVAL_DIRECT && p->evalmode != NUFFT_EVAL_FAST_APPROXIMATION)
         return fail(NUFFT_ERR_INVALID_ARG, "evalmode must be Direct (0) or FastApproximation (1)");
     if (in->gpu_method != NUFFT_METHOD_SHARED_MEMORY) return fail(NUFFT_ERR_INVALID_ARG, "expected gpu_method = :shared_memory");
@@ -176,25 +180,58 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         p->sigma = std::max(p->sigma, (double)p->Nover[d] / (double)p->N[d]);
         p->Nspec[d] = r2c ? p->Nover[d] / 2 + 1 : p->Nover[d];
     }
-    p->npoly = p->M + 4;
+    p->npoly = (p->kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL || p->kernel == NUFFT_KERNEL_KAISER_BESSEL) ? p->M + 4 : 0;
     for (int d = 0; d < p->D; ++d) {
         const bool r2c = !p->is_complex && d == 0;
         double sigma_d = (double)p->Nover[d] / (double)p->N[d];               // src/plan.jl:503
         if (p->dtype == NUFFT_F32) sigma_d = (double)(float)sigma_d;
-        double beta = bkb_beta(p->M, sigma_d);
+        // optimal_kernel(kernel, T, h, Ñ, σ): shape parameter in the plan's precision, or the caller's
+        // (kaiser_bessel_backwards.jl:123-136, kaiser_bessel.jl:151-165, gaussian.jl:107-116, bspline.jl:86-88)
+        double beta = 0.0;
+        if (in->kernel_param > 0.0) beta = in->kernel_param;
+        else if (p->kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) beta = bkb_beta(p->M, sigma_d);
+        else if (p->kernel == NUFFT_KERNEL_KAISER_BESSEL) beta = kb_beta(p->M, sigma_d);
+        else if (p->kernel == NUFFT_KERNEL_GAUSSIAN) beta = gaussian_ell(p->M, sigma_d);
         if (p->dtype == NUFFT_F32) beta = (double)(float)beta;
         p->beta[d] = beta;
         // Power-of-two normalisation of the window: the BKB window peaks at sinh(β)/π ≈ e^β/2π (4e15 at
-        // M = 8), so products of D window values overflow Float32 (and 1/ϕ̂^D underflows) in the
-        // reference's formulation.  Scaling window and ϕ̂ by the same 2^k is exact in binary floating
-        // point, leaves every result bit-identical where the reference is finite, and keeps all
-        // intermediates O(1).
-        p->scale_exp[d] = -(int)std::lround(std::log2(std::sinh(beta) / M_PI));
-        {
+        // M = 8; the KB window at I0(β)), so products of D window values overflow Float32 (and 1/ϕ̂^D
+        // underflows) in the reference's formulation.  Scaling window and ϕ̂ by the same 2^k is exact in
+        // binary floating point, leaves every result bit-identical where the reference is finite, and
+        // keeps all intermediates O(1).  The Gaussian and B-spline windows peak at <= 1: k = 0.
+        p->scale_exp[d] = 0;
+        p->coefs[d].clear();
+        double fourier_param = beta;
+        if (p->kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) {
+            p->scale_exp[d] = -(int)std::lround(std::log2(std::sinh(beta) / M_PI));
             const double bop = p->dtype == NUFFT_F32 ? (double)((float)beta / (float)M_PI) : beta / M_PI;
+            p->eval_p0[d] = beta;
             p->beta_over_pi_scaled[d] = std::ldexp(bop, p->scale_exp[d]);
+            bkb_poly_coefficients(p->M, beta, p->coefs[d]);
+        } else if (p->kernel == NUFFT_KERNEL_KAISER_BESSEL) {
+            p->scale_exp[d] = -(int)std::lround(std::log2(bessel_i0(beta)));
+            p->eval_p0[d] = beta;
+            p->beta_over_pi_scaled[d] = std::ldexp(1.0, p->scale_exp[d]);
+            kb_poly_coefficients(p->M, beta, p->coefs[d]);
+        } else if (p->kernel == NUFFT_KERNEL_GAUSSIAN) {
+            const double dx = 2.0 * M_PI / (double)p->Nover[d];
+            double sg = beta * dx;
+            double tau = 2.0 * sg * sg;
+            if (p->dtype == NUFFT_F32) {           // σ = α Δx; τ = 2σ² in T (gaussian.jl:76-80)
+                const float dxf = 2.0f * (float)M_PI / (float)p->Nover[d];
+                const float sgf = (float)beta * dxf;
+                tau = (double)(2.0f * sgf * sgf);
+                p->eval_p0[d] = (double)dxf;
+            } else {
+                p->eval_p0[d] = dx;
+            }
+            p->tau[d] = tau;
+            p->beta_over_pi_scaled[d] = tau;
+            fourier_param = tau;
+        } else {
+            p->eval_p0[d] = 0.0;
+            p->beta_over_pi_scaled[d] = 1.0;
         }
-        bkb_poly_coefficients(p->M, beta, p->coefs[d]);
         std::vector<double> ks;
         wavenumbers(p->N[d], r2c, ks);
         p->Nout[d] = (int64_t)ks.size();
@@ -203,7 +240,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
             const size_t n = ks.size(), sh = n / 2;
             for (size_t i = 0; i < n; ++i) kk[(i + sh) % n] = ks[i];
         }
-        fourier_coefficients(kk, p->M, p->Nover[d], beta, p->phihat[d]);
+        fourier_coefficients_kernel(p->kernel, kk, p->M, p->Nover[d], fourier_param, p->phihat[d]);
         non_oversampled_indices(ks, p->Nspec[d], p->fftshift, p->index_map[d]);
     }
 
@@ -278,6 +315,7 @@ static int build_device(nufft_plan* p) {
         std::vector<double> all;
         for (int d = 0; d < D; ++d)
             for (double c : p->coefs[d]) all.push_back(std::ldexp(c, p->scale_exp[d]));
+        if (all.empty()) all.push_back(0.0);      // kernels without a polynomial form (Gaussian, B-spline)
         (void)L;
         rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_coefs, all) : upload<double>(p, &p->d_coefs, all);
         if (rc) return rc;
@@ -400,8 +438,9 @@ static int build_device(nufft_plan* p) {
     }
 
     // kernels: allow the large dynamic LDS allocations
-    NUFFT_HIP(prepare_spread(p->dtype, p->is_complex, D, p->M, (int)p->lds_spread));
-    NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp));
+    const bool other = needs_other_eval(p->kernel, p->evalmode);
+    NUFFT_HIP(prepare_spread(p->dtype, p->is_complex, D, p->M, (int)p->lds_spread, other));
+    NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp, other));
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
         hipEvent_t a, b;
@@ -457,13 +496,14 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.D = p->D;
     a.M = p->M;
     a.evalmode = p->evalmode;
+    a.kernel = p->kernel;
     a.C = p->C;
     a.g = make_geom(p);
     a.sorted = p->d_sorted;
     a.offsets = p->d_offsets;
     a.coefs = p->d_coefs;
     for (int d = 0; d < 3; ++d) {
-        a.beta[d] = p->beta[d];
+        a.beta[d] = p->eval_p0[d];
         a.beta_over_pi[d] = p->beta_over_pi_scaled[d];
     }
     a.grid = p->d_us;
@@ -737,6 +777,7 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->workspace_bytes = p->workspace_bytes;
     o->num_points = p->Np;
     o->npoly = p->npoly;
+    o->kernel = p->kernel;
     return NUFFT_OK;
 }
 

@@ -65,6 +65,24 @@ double bessel_i0(double x) {
     return sum;
 }
 
+// KaiserBesselKernel, src/Kernels/kaiser_bessel.jl:151-165
+double kb_beta(int M, double sigma_d) {
+    const double a = M * (2.0 - 1.0 / sigma_d);
+    const double gamma = std::sqrt(1.0 - 0.8 / (a * a));
+    return M_PI * a * gamma;
+}
+
+// phi(y) = I0(beta sqrt(1 - y^2)), src/Kernels/kaiser_bessel.jl:128-130
+double kb_function(double y, double beta) {
+    const double z = 1.0 - y * y;
+    return bessel_i0(beta * std::sqrt(z > 0.0 ? z : 0.0));
+}
+
+// GaussianKernel: ell / dx, src/Kernels/gaussian.jl:107-116
+double gaussian_ell(int M, double sigma_d) {
+    return std::sqrt(sigma_d * M / (2.0 * sigma_d - 1.0) / M_PI);
+}
+
 // Solves the (npoly x npoly) Vandermonde system by Gaussian elimination with partial pivoting
 // (solve_polynomial_coefficients!, src/Kernels/piecewise_polynomial.jl:23-41).
 static void solve_dense(std::vector<double>& A, std::vector<double>& b, int n) {
@@ -93,7 +111,7 @@ static void solve_dense(std::vector<double>& A, std::vector<double>& b, int n) {
 
 // solve_piecewise_polynomial_coefficients, src/Kernels/piecewise_polynomial.jl:50-74 with
 // Npoly = M + 4 (src/Kernels/kaiser_bessel_backwards.jl:98).
-void bkb_poly_coefficients(int M, double beta, std::vector<double>& cs) {
+void poly_coefficients(int M, double beta, double (*f)(double, double), std::vector<double>& cs) {
     const int L = 2 * M;
     const int np = M + 4;
     cs.assign((size_t)np * L, 0.0);
@@ -108,12 +126,16 @@ void bkb_poly_coefficients(int M, double beta, std::vector<double>& cs) {
                 A[(size_t)i * np + k] = pw;
                 pw *= xs[i];
             }
-            ys[i] = bkb_function(h + xs[i] * delta, beta);
+            ys[i] = f(h + xs[i] * delta, beta);
         }
         solve_dense(A, ys, np);
         for (int k = 0; k < np; ++k) cs[(size_t)k * L + (j - 1)] = ys[k];
     }
 }
+
+void bkb_poly_coefficients(int M, double beta, std::vector<double>& cs) { poly_coefficients(M, beta, bkb_function, cs); }
+// Npoly = M + 4 as well, src/Kernels/kaiser_bessel.jl:127-130
+void kb_poly_coefficients(int M, double beta, std::vector<double>& cs) { poly_coefficients(M, beta, kb_function, cs); }
 
 // init_wavenumbers, src/plan.jl:558-566
 void wavenumbers(int64_t N, bool r2c, std::vector<double>& ks) {
@@ -135,6 +157,28 @@ void fourier_coefficients(const std::vector<double>& ks, int M, int64_t Nover, d
         const double q = w * ks[i];
         const double s = std::sqrt(beta * beta - q * q);
         phihat[i] = w * bessel_i0(s);
+    }
+}
+
+// evaluate_fourier_func of the other kernels: src/Kernels/kaiser_bessel.jl:167-174,
+// src/Kernels/gaussian.jl:118-123 (param = tau), src/Kernels/bspline.jl:121-129.
+void fourier_coefficients_kernel(int kernel, const std::vector<double>& ks, int M, int64_t Nover, double param,
+                                 std::vector<double>& phihat) {
+    if (kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) { fourier_coefficients(ks, M, Nover, param, phihat); return; }
+    const double dx = 2.0 * M_PI / (double)Nover;
+    phihat.resize(ks.size());
+    for (size_t i = 0; i < ks.size(); ++i) {
+        const double k = ks[i];
+        if (kernel == NUFFT_KERNEL_KAISER_BESSEL) {
+            const double w = M * dx, q = w * k;
+            const double s = std::sqrt(param * param - q * q);
+            phihat[i] = 2.0 * w * std::sinh(s) / s;
+        } else if (kernel == NUFFT_KERNEL_GAUSSIAN) {
+            phihat[i] = std::exp(-param * k * k / 4.0) * std::sqrt(M_PI * param);
+        } else {
+            const double kh = k * dx / 2.0;
+            phihat[i] = (k == 0.0 ? 1.0 : std::pow(std::sin(kh) / kh, 2 * M)) * dx;
+        }
     }
 }
 

@@ -3,5 +3,4 @@
 #define NUFFT_CPLX true
 #define NUFFT_KERNEL spread_tile_kernel
 #define NUFFT_GETTER spread_kernel_f32c
-#define NUFFT_HAS_WRAP_VARIANT 1
 #include "tile_inst.h"

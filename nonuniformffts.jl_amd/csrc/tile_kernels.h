@@ -45,6 +45,7 @@ struct TileArgs {
     T* vout[kMaxCompPerLaunch];           // interp
     T prefactor;
     int evalmode;
+    int kernel;                           // NUFFT_KERNEL_*; beta / bop per kernel: see WindowEval
 };
 
 template <int NC, int M>
@@ -89,12 +90,59 @@ __device__ __forceinline__ BinSegs bin_segments(int lo, int hi, int N, int blog,
 // Window evaluation of one wave: the G lanes of a group evaluate the D*2M values of their point and
 // exchange them through the wave's LDS strip.  Coefficients of the piecewise polynomial stay in
 // registers (the lane's (dimension, j) role per slot never changes).
-template <typename T, int NC, int D, int M, int GS = Grp<NC, M>::G>
+//
+// OTHERK = false (the hot instantiations): BackwardsKaiserBessel Direct (sinh form) and every
+// polynomial evaluation (FastApproximation of both Kaiser-Bessel kernels).  OTHERK = true: the
+// remaining kernel x mode combinations of the reference —
+//   KaiserBessel Direct   I0(beta sqrt(1 - y^2))                 src/Kernels/kaiser_bessel.jl:197-210
+//   Gaussian Direct       exp(-((M-1-j+X) dx)^2 / tau)           src/Kernels/gaussian.jl:141-153
+//   Gaussian Fast         fast Gaussian gridding a cs[m] b^(+-m) src/Kernels/gaussian.jl:125-139,155-192
+//   BSpline (both modes)  order-2M recursion                     src/Kernels/bspline.jl:99-119,140-193
+// Per-dimension parameters in TileArgs: BKB beta, (beta/pi) 2^k; KB beta, 2^k; Gaussian dx, tau.
+template <typename T>
+__device__ __forceinline__ T dev_bessel_i0(T x) {
+    // power series, all terms positive (stands in for Bessels.besseli0 / the branch-free version of
+    // ext/NonuniformFFTsAMDGPUExt.jl:32-44)
+    const T q = T(0.25) * x * x;
+    const T eps = sizeof(T) == 8 ? T(1e-17) : T(1e-9);
+    T term = T(1), sum = T(1);
+    for (int k = 1; k < 400; ++k) {
+        term *= q / (T(k) * T(k));
+        sum += term;
+        if (term < eps * sum) break;
+    }
+    return sum;
+}
+
+template <typename T, int M>
+__device__ __forceinline__ T dev_bspline_value(T x, int jsel) {
+    constexpr int K = 2 * M;
+    T bs[K];
+    bs[0] = T(1);
+#pragma unroll
+    for (int q = 2; q <= K; ++q) {
+        const T alpha = T(1) / T(q - 1);
+        T ds[K - 1];
+        T xx = x;
+#pragma unroll
+        for (int j = 0; j < q - 1; ++j) { ds[j] = alpha * xx; xx += T(1); }
+        bs[q - 1] = (T(1) - ds[q - 2]) * bs[q - 2];
+#pragma unroll
+        for (int j = q - 2; j >= 1; --j) bs[j] = (T(1) - ds[j - 1]) * bs[j - 1] + ds[j] * bs[j];
+        bs[0] = ds[0] * bs[0];
+    }
+    T val = bs[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) val = jsel == j ? bs[j] : val;
+    return val;
+}
+
+template <typename T, int NC, int D, int M, int GS = Grp<NC, M>::G, bool OTHERK = false>
 struct WindowEval {
     static constexpr int L = 2 * M;
     static constexpr int NV = D * L;
     static constexpr int NSLOT = (NV + GS - 1) / GS;
-    static constexpr int NP = M + 4;
+    static constexpr int NP = OTHERK ? 1 : M + 4;
     T cs[NSLOT][NP];
     int dsel[NSLOT], jsel[NSLOT];
     bool has[NSLOT];
@@ -110,7 +158,14 @@ struct WindowEval {
             jsel[s] = kk % L;
             beta_s[s] = a.beta[dsel[s]];
             bop_s[s] = a.bop[dsel[s]];
-            if (a.evalmode != NUFFT_EVAL_DIRECT) {
+            if constexpr (OTHERK) {
+                cs[s][0] = T(0);
+                if (a.kernel == NUFFT_KERNEL_GAUSSIAN) {      // cs[|m|] = exp(-(m dx)^2 / tau), gaussian.jl:81-84
+                    const int m = jsel[s] - (M - 1);
+                    const T xm = T(m < 0 ? -m : m) * beta_s[s];
+                    cs[s][0] = exp(-(xm * xm) / bop_s[s]);
+                }
+            } else if (a.evalmode != NUFFT_EVAL_DIRECT) {
 #pragma unroll
                 for (int c = 0; c < NP; ++c) cs[s][c] = a.coefs[(dsel[s] * NP + c) * L + jsel[s]];
             } else {
@@ -126,7 +181,32 @@ struct WindowEval {
         for (int s = 0; s < NSLOT; ++s) {
             const T x = dsel[s] == 0 ? X[0] : (dsel[s] == 1 ? X[1] : X[2]);
             T val;
-            if (a.evalmode == NUFFT_EVAL_DIRECT) {
+            if constexpr (OTHERK) {
+                const int j = jsel[s];
+                if (a.kernel == NUFFT_KERNEL_KAISER_BESSEL) {
+                    const T y = (T(M - 1 - j) + x) / T(M);
+                    const T z = T(1) - y * y;
+                    val = dev_bessel_i0<T>(beta_s[s] * sqrt(z > T(0) ? z : T(0))) * bop_s[s];
+                } else if (a.kernel == NUFFT_KERNEL_GAUSSIAN) {
+                    const T dx = beta_s[s], tau = bop_s[s];
+                    if (a.evalmode == NUFFT_EVAL_DIRECT) {
+                        const T ys = (T(M - 1 - j) + x) * dx;
+                        val = exp(-(ys * ys) / tau);
+                    } else {
+                        const T Xp = x * dx;
+                        const T av = exp(-(Xp * Xp) / tau);
+                        const T bv = exp(T(2) * Xp * dx / tau);
+                        const int m = j - (M - 1);
+                        const int am = m < 0 ? -m : m;
+                        T bpow = T(1);
+                        for (int i = 0; i < (am < M - 1 ? am : M - 1); ++i) bpow *= bv;
+                        const T ac = av * cs[s][0];
+                        val = m == 0 ? av : (m < 0 ? ac / bpow : (m < M ? ac * bpow : ac * bpow * bv));
+                    }
+                } else {
+                    val = dev_bspline_value<T, M>(T(1) - x, j);
+                }
+            } else if (a.evalmode == NUFFT_EVAL_DIRECT) {
                 val = bkb_direct<T, M>(x, jsel[s], beta_s[s], bop_s[s]);
             } else {
                 const T xx = T(2) * x - T(1);
@@ -219,7 +299,7 @@ __device__ __forceinline__ double readlane_t(double x, int l) {
 // by a scalar branch.  WRAP = some axis is spanned by a single tile (small grids): stencil indices
 // then wrap around that axis instead of being clipped; the hot instantiation (WRAP = false) carries
 // none of that code.
-template <typename T, bool CPLX, int D, int M, bool WRAP>
+template <typename T, bool CPLX, int D, int M, bool WRAP, bool OTHERK = false>
 __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
@@ -261,7 +341,7 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     // evaluation roles
     const int grp = lane / GP::G, q = lane % GP::G;
     T* strip = strip_wave + grp * (D * L);
-    WindowEval<T, NC, D, M> we;
+    WindowEval<T, NC, D, M, GP::G, OTHERK> we;
     we.init(a, q);
     // accumulation roles
     int j1f[NPASS], j2f[NPASS], cmpf[NPASS];
@@ -456,7 +536,7 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
 // ---------------------------------------------------------------------------------------------
 // FIXED: the tile shape is the compile-time one of fixed_interp_tile() (the host launches this variant
 // only when the plan's tile equals it), which turns the LDS strides into immediates.
-template <typename T, bool CPLX, int D, int M, bool FIXED>
+template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK = false>
 __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
@@ -575,7 +655,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     const bool lane_active = q < GP::W1;
     const int comp = q % NC, j1 = (q / NC) % L;
     T* strip = strip_wave + grp * (D * L);
-    WindowEval<T, NC, D, M> we;
+    WindowEval<T, NC, D, M, GP::G, OTHERK> we;
     we.init(a, q);
     __syncthreads();
 

@@ -6,14 +6,14 @@
 
 namespace nufft {
 
-const void* spread_kernel_f32r(int D, int M, bool wrap);
-const void* spread_kernel_f32c(int D, int M, bool wrap);
-const void* spread_kernel_f64r(int D, int M, bool wrap);
-const void* spread_kernel_f64c(int D, int M, bool wrap);
-const void* interp_kernel_f32r(int D, int M, bool wrap);
-const void* interp_kernel_f32c(int D, int M, bool wrap);
-const void* interp_kernel_f64r(int D, int M, bool wrap);
-const void* interp_kernel_f64c(int D, int M, bool wrap);
+const void* spread_kernel_f32r(int D, int M, bool flag, bool other);
+const void* spread_kernel_f32c(int D, int M, bool flag, bool other);
+const void* spread_kernel_f64r(int D, int M, bool flag, bool other);
+const void* spread_kernel_f64c(int D, int M, bool flag, bool other);
+const void* interp_kernel_f32r(int D, int M, bool flag, bool other);
+const void* interp_kernel_f32c(int D, int M, bool flag, bool other);
+const void* interp_kernel_f64r(int D, int M, bool flag, bool other);
+const void* interp_kernel_f64c(int D, int M, bool flag, bool other);
 
 void interp_fixed_dims_f32r(int D, int M, int* n);
 void interp_fixed_dims_f32c(int D, int M, int* n);
@@ -28,19 +28,27 @@ void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n) {
 }
 
 // `flag`: spreading = single-tile axis (wrap variant); interpolation = compile-time tile.
-static const void* pick(bool interp, int dtype, int is_complex, int D, int M, bool flag) {
-    const bool wrap = flag;
+// `other`: window evaluation of the non-default kernels (see needs_other_eval).
+static const void* pick(bool interp, int dtype, int is_complex, int D, int M, bool flag, bool other) {
     if (interp) {
-        if (dtype == NUFFT_F32) return is_complex ? interp_kernel_f32c(D, M, flag) : interp_kernel_f32r(D, M, flag);
-        return is_complex ? interp_kernel_f64c(D, M, flag) : interp_kernel_f64r(D, M, flag);
+        if (dtype == NUFFT_F32) return is_complex ? interp_kernel_f32c(D, M, flag, other) : interp_kernel_f32r(D, M, flag, other);
+        return is_complex ? interp_kernel_f64c(D, M, flag, other) : interp_kernel_f64r(D, M, flag, other);
     }
-    if (dtype == NUFFT_F32) return is_complex ? spread_kernel_f32c(D, M, wrap) : spread_kernel_f32r(D, M, wrap);
-    return is_complex ? spread_kernel_f64c(D, M, wrap) : spread_kernel_f64r(D, M, wrap);
+    if (dtype == NUFFT_F32) return is_complex ? spread_kernel_f32c(D, M, flag, other) : spread_kernel_f32r(D, M, flag, other);
+    return is_complex ? spread_kernel_f64c(D, M, flag, other) : spread_kernel_f64r(D, M, flag, other);
 }
 
-static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, int lds_bytes) {
+// The polynomial evaluation (FastApproximation of both Kaiser-Bessel kernels) and the sinh form of the
+// backwards Kaiser-Bessel kernel live in the default instantiations; everything else in the OTHERK ones.
+bool needs_other_eval(int kernel, int evalmode) {
+    if (kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) return false;
+    if (kernel == NUFFT_KERNEL_KAISER_BESSEL) return evalmode == NUFFT_EVAL_DIRECT;
+    return true;
+}
+
+static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, int lds_bytes, bool other) {
     for (int wrap = 0; wrap < 2; ++wrap) {
-        const void* fn = pick(interp, dtype, is_complex, D, M, wrap != 0);
+        const void* fn = pick(interp, dtype, is_complex, D, M, wrap != 0, other);
         if (!fn && interp && wrap) continue;       // no compile-time tile for this instantiation
         if (!fn) return hipErrorInvalidValue;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -49,18 +57,19 @@ static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, 
     return hipSuccess;
 }
 
-hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes) {
-    return prepare(false, dtype, is_complex, D, M, lds_bytes);
+hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes, bool other) {
+    return prepare(false, dtype, is_complex, D, M, lds_bytes, other);
 }
-hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes) {
-    return prepare(true, dtype, is_complex, D, M, lds_bytes);
+hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes, bool other) {
+    return prepare(true, dtype, is_complex, D, M, lds_bytes, other);
 }
 
 template <typename T>
 static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t stream) {
     bool wrap = false;
     for (int d = 0; d < a.D; ++d) wrap = wrap || a.g.sp.nt[d] == 1;
-    const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, interp ? a.fixed_tile != 0 : wrap);
+    const bool other = needs_other_eval(a.kernel, a.evalmode);
+    const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, interp ? (a.fixed_tile != 0 && !other) : wrap, other);
     if (!fn) return hipErrorInvalidValue;
     const int ncr = a.is_complex ? 2 : 1;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
@@ -81,6 +90,7 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         }
         k.prefactor = (T)a.prefactor;
         k.evalmode = a.evalmode;
+        k.kernel = a.kernel;
         void* params[] = {&k};
         hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
                                        params, (size_t)a.lds_bytes, stream);

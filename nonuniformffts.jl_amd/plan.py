@@ -48,7 +48,28 @@ class FastApproximation:
 
 @dataclass(frozen=True)
 class BackwardsKaiserBesselKernel:
+    """src/Kernels/kaiser_bessel_backwards.jl (default kernel); ``beta`` overrides the optimal β."""
     beta: Optional[float] = None
+
+
+@dataclass(frozen=True)
+class KaiserBesselKernel:
+    """src/Kernels/kaiser_bessel.jl; ``beta`` overrides the optimal β."""
+    beta: Optional[float] = None
+
+
+@dataclass(frozen=True)
+class GaussianKernel:
+    """src/Kernels/gaussian.jl; ``ell`` = ℓ/Δx overrides the optimal width."""
+    ell: Optional[float] = None
+
+
+@dataclass(frozen=True)
+class BSplineKernel:
+    """src/Kernels/bspline.jl (order 2M, no shape parameter)."""
+
+
+_KERNEL_IDS = {BackwardsKaiserBesselKernel: 0, KaiserBesselKernel: 1, GaussianKernel: 2, BSplineKernel: 3}
 
 
 @dataclass(frozen=True)
@@ -147,10 +168,10 @@ class PlanNUFFT:
             sigma = σ
         M = m.M if isinstance(m, HalfSupport) else int(m)
         kernel = default_kernel(backend) if kernel is None else kernel
-        if not isinstance(kernel, BackwardsKaiserBesselKernel):
-            raise ValueError("only BackwardsKaiserBesselKernel is available in this backend")
-        if kernel.beta is not None:
-            raise ValueError("a user-set β is not supported by this backend yet")
+        if isinstance(kernel, type):
+            kernel = kernel()
+        if type(kernel) not in _KERNEL_IDS:
+            raise ValueError("kernel must be BackwardsKaiserBesselKernel, KaiserBesselKernel, GaussianKernel or BSplineKernel")
         kernel_evalmode = default_kernel_evalmode(backend) if kernel_evalmode is None else kernel_evalmode
         if isinstance(kernel_evalmode, type):
             kernel_evalmode = kernel_evalmode()
@@ -182,7 +203,9 @@ class PlanNUFFT:
             prm.N[d] = n
         prm.half_support = M
         prm.sigma = float(sigma)
-        prm.kernel = 0
+        prm.kernel = _KERNEL_IDS[type(kernel)]
+        kparam = getattr(kernel, "beta", None) if not isinstance(kernel, GaussianKernel) else kernel.ell
+        prm.kernel_param = 0.0 if kparam is None else float(kparam)
         prm.evalmode = _lib.EVAL_DIRECT if isinstance(kernel_evalmode, Direct) else _lib.EVAL_FAST_APPROXIMATION
         prm.ntransforms = self._ntransforms
         prm.fftshift = int(self.fftshift)
@@ -299,7 +322,7 @@ class PlanNUFFT:
         lines = [
             f"{D}-dimensional PlanNUFFT with input type {self.Z}:",
             f"  - backend: {self.backend}",
-            f"  - kernel: BackwardsKaiserBesselKernel(β = {i.beta[0]}) with half-support M = {i.half_support}",
+            f"  - kernel: {type(self.kernel).__name__}(shape parameter = {i.beta[0]}) with half-support M = {i.half_support}",
             f"  - kernel evaluation mode: {self.kernel_evalmode}",
             f"  - oversampling factor: σ = {i.sigma}",
             f"  - uniform dimensions: {self.size}",

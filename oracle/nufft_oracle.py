@@ -40,6 +40,12 @@ TWO_PI = 2.0 * math.pi
 DIRECT = 0
 FAST_APPROXIMATION = 1
 
+# spreading kernels (values of NUFFT_KERNEL_* in include/nufft_mi355x.h)
+KERNEL_BKB = 0          # BackwardsKaiserBesselKernel (default), src/Kernels/kaiser_bessel_backwards.jl
+KERNEL_KB = 1           # KaiserBesselKernel, src/Kernels/kaiser_bessel.jl
+KERNEL_GAUSSIAN = 2     # GaussianKernel, src/Kernels/gaussian.jl
+KERNEL_BSPLINE = 3      # BSplineKernel, src/Kernels/bspline.jl
+
 
 # --------------------------------------------------------------------------------------
 # Plan-time parameter math
@@ -151,6 +157,90 @@ def bkb_fourier(ks: np.ndarray, M: int, Nover: int, beta: float) -> np.ndarray:
     return w * _bessel_i0(s)
 
 
+# ---- KaiserBesselKernel (src/Kernels/kaiser_bessel.jl) -----------------------------------------
+
+def kb_beta(M: int, sigma_d: float) -> float:
+    """beta = pi a gamma, a = M (2 - 1/sigma), gamma = sqrt(1 - 0.8 / a^2)
+    (src/Kernels/kaiser_bessel.jl:151-165)."""
+    a = M * (2.0 - 1.0 / sigma_d)
+    gamma = math.sqrt(1.0 - 0.8 / (a * a))
+    return math.pi * a * gamma
+
+
+def kb_function(y, beta):
+    """phi(y) = I0(beta sqrt(1 - y^2)) on |y| <= 1 (src/Kernels/kaiser_bessel.jl:128-130,197-210)."""
+    y = np.asarray(y, dtype=np.float64)
+    return _bessel_i0(beta * np.sqrt(np.maximum(1.0 - y * y, 0.0)))
+
+
+def kb_poly_coefficients(M: int, beta: float) -> np.ndarray:
+    """Npoly = M + 4, src/Kernels/kaiser_bessel.jl:127-130."""
+    return piecewise_poly_coefficients(lambda y: kb_function(y, beta), M, M + 4)
+
+
+def kb_fourier(ks: np.ndarray, M: int, Nover: int, beta: float) -> np.ndarray:
+    """phi_hat(k) = 2 w sinh(s) / s, s = sqrt(beta^2 - (w k)^2), w = M dx
+    (src/Kernels/kaiser_bessel.jl:167-174)."""
+    w = M * (TWO_PI / Nover)
+    q = w * np.asarray(ks, dtype=np.float64)
+    s = np.sqrt(beta * beta - q * q)
+    return 2.0 * w * np.sinh(s) / s
+
+
+# ---- GaussianKernel (src/Kernels/gaussian.jl) --------------------------------------------------
+
+def gaussian_ell(M: int, sigma_d: float) -> float:
+    """ell / dx = sqrt(sigma M / (2 sigma - 1) / pi), Potts & Steidl eq. (5.9)
+    (src/Kernels/gaussian.jl:107-116)."""
+    return math.sqrt(sigma_d * M / (2.0 * sigma_d - 1.0) / math.pi)
+
+
+def gaussian_tau(ell: float, Nover: int) -> float:
+    """tau = 2 (ell dx)^2 (src/Kernels/gaussian.jl:76-80)."""
+    sg = ell * (TWO_PI / Nover)
+    return 2.0 * sg * sg
+
+
+def gaussian_fourier(ks: np.ndarray, tau: float) -> np.ndarray:
+    """phi_hat(k) = exp(-tau k^2 / 4) sqrt(pi tau) (src/Kernels/gaussian.jl:118-123)."""
+    k = np.asarray(ks, dtype=np.float64)
+    return np.exp(-tau * k * k / 4.0) * math.sqrt(math.pi * tau)
+
+
+# ---- BSplineKernel (src/Kernels/bspline.jl) ----------------------------------------------------
+
+def bspline_evaluate_all(x, k: int):
+    """All k = 2M B-splines of order k that are non-zero at x in (0, 1], uniform unit knots, in the
+    reference's output order (src/Kernels/bspline.jl:140-193: the generated recursion with
+    alpha = 1 / (q - 1); ``bsplines_evaluate_step`` :176-193).  x: array (Np,) -> (Np, k)."""
+    x = np.asarray(x)
+    T = x.dtype.type
+    bs = [np.ones_like(x)]
+    for q in range(2, k + 1):
+        alpha = T(1) / T(q - 1)
+        ds = []
+        xx = x.copy()
+        for _ in range(q - 1):
+            ds.append((alpha * xx).astype(x.dtype))
+            xx = xx + T(1)
+        new = [ds[0] * bs[0]]
+        for j in range(2, q):
+            new.append((T(1) - ds[j - 2]) * bs[j - 2] + ds[j - 1] * bs[j - 1])
+        new.append((T(1) - ds[q - 2]) * bs[q - 2])
+        bs = new
+    return np.stack(bs, axis=1)
+
+
+def bspline_fourier(ks: np.ndarray, M: int, Nover: int) -> np.ndarray:
+    """phi_hat(k) = (sin(kh) / kh)^(2M) dt, kh = k dt / 2; dt at k = 0 (src/Kernels/bspline.jl:121-129)."""
+    dt = TWO_PI / Nover
+    k = np.asarray(ks, dtype=np.float64)
+    kh = k * dt / 2.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sinc = np.where(k == 0, 1.0, np.sin(kh) / np.where(k == 0, 1.0, kh))
+    return np.where(k == 0, 1.0, sinc ** (2 * M)) * dt
+
+
 def non_oversampled_indices(ks: np.ndarray, Nover_axis: int, fftshift: bool = False) -> np.ndarray:
     """0-based index map from the output wavenumbers to the oversampled axis
     (src/NonuniformFFTs.jl:318-348)."""
@@ -206,9 +296,11 @@ def _invpow(x, D):
 
 @dataclass
 class OraclePlan:
-    """Host-side restatement of ``_PlanNUFFT`` (src/plan.jl:467-541) for the
-    BackwardsKaiserBesselKernel (default kernel on CPU and ROC, src/NonuniformFFTs.jl:52,
-    ext/NonuniformFFTsAMDGPUExt.jl:54)."""
+    """Host-side restatement of ``_PlanNUFFT`` (src/plan.jl:467-541).  ``kernel`` selects one of the
+    four spreading kernels (default: BackwardsKaiserBesselKernel, the default kernel on CPU and ROC,
+    src/NonuniformFFTs.jl:52, ext/NonuniformFFTsAMDGPUExt.jl:54); ``kernel_param`` overrides the shape
+    parameter (beta for the two Kaiser-Bessel kernels, ell / dx for the Gaussian), as
+    ``KaiserBesselKernel(beta)`` etc. do in the reference."""
     Ns: Tuple[int, ...]
     is_real: bool = True           # Z <: Real
     dtype: type = np.float64       # real(Z)
@@ -217,10 +309,13 @@ class OraclePlan:
     evalmode: int = FAST_APPROXIMATION
     ntransforms: int = 1
     fftshift: bool = False
+    kernel: int = KERNEL_BKB
+    kernel_param: Optional[float] = None
     # derived
     Nover: Tuple[int, ...] = field(init=False)
     ks: list = field(init=False)
-    betas: list = field(init=False)
+    betas: list = field(init=False)      # shape parameter per dimension (beta; ell / dx for the Gaussian; 0 for B-splines)
+    taus: list = field(init=False)       # Gaussian: tau = 2 (ell dx)^2
     coefs: list = field(init=False)
     phihat: list = field(init=False)
     index_map: list = field(init=False)
@@ -240,15 +335,35 @@ class OraclePlan:
                 raise ValueError(
                     f"data size is too small: sigma*N = {Nt} < {2 * self.M} = 2M")
         self.ks = init_wavenumbers(self.Ns, self.is_real)
-        self.betas, self.coefs, self.phihat, self.index_map = [], [], [], []
+        self.betas, self.taus, self.coefs, self.phihat, self.index_map = [], [], [], [], []
         for d in range(D):
             sigma_d = float(rdt.type(self.Nover[d] / self.Ns[d]))      # src/plan.jl:503
-            beta = float(rdt.type(bkb_beta(self.M, sigma_d)))
-            self.betas.append(beta)
-            self.coefs.append(bkb_poly_coefficients(self.M, beta))
             k = self.ks[d]
             kk = np.fft.fftshift(k) if self.fftshift else k             # src/plan.jl:509-514
-            self.phihat.append(bkb_fourier(kk, self.M, self.Nover[d], beta))
+            tau = 0.0
+            if self.kernel == KERNEL_BKB:
+                beta = float(rdt.type(bkb_beta(self.M, sigma_d) if self.kernel_param is None else self.kernel_param))
+                cs = bkb_poly_coefficients(self.M, beta)
+                ph = bkb_fourier(kk, self.M, self.Nover[d], beta)
+            elif self.kernel == KERNEL_KB:
+                beta = float(rdt.type(kb_beta(self.M, sigma_d) if self.kernel_param is None else self.kernel_param))
+                cs = kb_poly_coefficients(self.M, beta)
+                ph = kb_fourier(kk, self.M, self.Nover[d], beta)
+            elif self.kernel == KERNEL_GAUSSIAN:
+                beta = float(rdt.type(gaussian_ell(self.M, sigma_d) if self.kernel_param is None else self.kernel_param))
+                tau = float(rdt.type(gaussian_tau(beta, self.Nover[d])))
+                cs = np.zeros((0, 2 * self.M))
+                ph = gaussian_fourier(kk, tau)
+            elif self.kernel == KERNEL_BSPLINE:
+                beta = 0.0
+                cs = np.zeros((0, 2 * self.M))
+                ph = bspline_fourier(kk, self.M, self.Nover[d])
+            else:
+                raise ValueError(f"unknown kernel {self.kernel}")
+            self.betas.append(beta)
+            self.taus.append(tau)
+            self.coefs.append(cs)
+            self.phihat.append(ph)
             n_axis = self.Nover[d] // 2 + 1 if (self.is_real and d == 0) else self.Nover[d]
             self.index_map.append(non_oversampled_indices(k, n_axis, self.fftshift))
 
@@ -300,8 +415,9 @@ def evaluate_window(plan: OraclePlan, d: int, x: np.ndarray):
     """Cell index (0-based) and the 2M window values of every point along dimension d.
     Values j = 0..2M-1 belong to grid nodes i - M + 1 + j (0-based), i.e. the reference's
     1-based ``(i - M + 1):(i + M)`` (src/Kernels/Kernels.jl:162-164).
-    Direct: src/Kernels/kaiser_bessel_backwards.jl:158-175.
-    FastApproximation: :147-156 + src/Kernels/piecewise_polynomial.jl:76-92."""
+    BackwardsKaiserBessel Direct: src/Kernels/kaiser_bessel_backwards.jl:158-175;
+    FastApproximation (both Kaiser-Bessel kernels): :147-156 + src/Kernels/piecewise_polynomial.jl:76-92.
+    The other kernels are dispatched below with their own citations."""
     M = plan.M
     T = x.dtype.type
     i, r = point_to_cell(x, plan.Nover[d])
@@ -309,6 +425,37 @@ def evaluate_window(plan: OraclePlan, d: int, x: np.ndarray):
     # out of bounds there.  Keep the point in the last cell with X = 1 (same window by continuity).
     i = np.minimum(i, plan.Nover[d] - 1)
     X = (r - i.astype(x.dtype)).astype(x.dtype)          # in [0, 1]
+    if plan.kernel == KERNEL_BSPLINE:
+        # src/Kernels/bspline.jl:99-119: x' = i - r (1-based i) = 1 - X; same recursion in both modes
+        return i, bspline_evaluate_all((T(1) - X).astype(x.dtype), 2 * M).astype(x.dtype)
+    if plan.kernel == KERNEL_GAUSSIAN:
+        dx = T(TWO_PI) / T(plan.Nover[d])
+        tau = T(plan.taus[d])
+        if plan.evalmode == DIRECT:                       # src/Kernels/gaussian.jl:141-153
+            js = np.arange(1, 2 * M + 1, dtype=x.dtype)
+            ys = (T(M) - js[None, :] + X[:, None]) * dx
+            return i, np.exp(-(ys * ys) / tau).astype(x.dtype)
+        # fast Gaussian gridding, src/Kernels/gaussian.jl:125-139,155-192: a = exp(-X^2 / tau),
+        # b = exp(2 X dx / tau) with X = x - (i - 1) dx in physical units, cs[m] = exp(-(m dx)^2 / tau)
+        Xp = (x - i.astype(x.dtype) * dx).astype(x.dtype)
+        a = np.exp(-(Xp * Xp) / tau).astype(x.dtype)
+        b = np.exp(T(2) * Xp * dx / tau).astype(x.dtype)
+        m = np.arange(1, M + 1, dtype=x.dtype)
+        cs = np.exp(-((m * dx) ** 2) / tau).astype(x.dtype)
+        vals = np.empty((len(x), 2 * M), dtype=x.dtype)
+        vals[:, M - 1] = a
+        bpow = np.ones_like(b)
+        for mm in range(1, M):
+            bpow = bpow * b
+            vals[:, M - 1 - mm] = a * cs[mm - 1] / bpow
+            vals[:, M - 1 + mm] = a * cs[mm - 1] * bpow
+        vals[:, 2 * M - 1] = a * cs[M - 1] * bpow * b
+        return i, vals
+    if plan.kernel == KERNEL_KB and plan.evalmode == DIRECT:    # src/Kernels/kaiser_bessel.jl:197-210
+        js = np.arange(1, 2 * M + 1, dtype=x.dtype)
+        ys = (T(M) - js[None, :] + X[:, None]) / T(M)
+        zs = np.maximum(T(1) - ys * ys, T(0))
+        return i, _bessel_i0((T(plan.betas[d]) * np.sqrt(zs)).astype(np.float64)).astype(x.dtype)
     if plan.evalmode == DIRECT:
         js = np.arange(1, 2 * M + 1, dtype=x.dtype)
         ys = (T(M) - js[None, :] + X[:, None]) / T(M)

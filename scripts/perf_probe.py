@@ -30,6 +30,7 @@ ap.add_argument("--mode", default="direct")
 ap.add_argument("--c", type=int, default=1)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--dist", default="uniform")
+ap.add_argument("--kernel", default="bkb", choices=["bkb", "kb", "gaussian", "bspline"])
 a = ap.parse_args()
 
 Z = {"f64": torch.float64, "f32": torch.float32, "c64": torch.complex64, "c128": torch.complex128}[a.z]
@@ -49,7 +50,9 @@ if a.threads:
 if a.lds:
     kw["lds_budget_bytes"] = a.lds
 mode = nufft.Direct() if a.mode == "direct" else nufft.FastApproximation()
-plan = nufft.PlanNUFFT(Z, dims, m=a.m, sigma=a.sigma, ntransforms=a.c, kernel_evalmode=mode,
+kernel = {"bkb": nufft.BackwardsKaiserBesselKernel, "kb": nufft.KaiserBesselKernel, "gaussian": nufft.GaussianKernel,
+          "bspline": nufft.BSplineKernel}[a.kernel]()
+plan = nufft.PlanNUFFT(Z, dims, m=a.m, sigma=a.sigma, ntransforms=a.c, kernel_evalmode=mode, kernel=kernel,
                        backend=nufft.ROCBackend(0), synchronise=True, **kw)
 info = plan.info()
 print(f"plan: Nover={plan.oversampled_dims} bins={[info.bin_dims[d] for d in range(a.dim)]} "

@@ -42,7 +42,11 @@ def _f32_overflows(Z, dims, M):
     return np.dtype(Z) in (np.dtype(np.float32), np.dtype(np.complex64)) and len(dims) * M >= 21
 
 
-def _make_case(Z, dims, M, sigma, evalmode, C, Np, seed, **kw):
+_KERNEL_OBJ = {O.KERNEL_BKB: "BackwardsKaiserBesselKernel", O.KERNEL_KB: "KaiserBesselKernel",
+               O.KERNEL_GAUSSIAN: "GaussianKernel", O.KERNEL_BSPLINE: "BSplineKernel"}
+
+
+def _make_case(Z, dims, M, sigma, evalmode, C, Np, seed, kernel=O.KERNEL_BKB, kernel_param=None, **kw):
     nufft = _nufft()
     Z = np.dtype(Z)
     is_real = Z.kind == "f"
@@ -55,10 +59,14 @@ def _make_case(Z, dims, M, sigma, evalmode, C, Np, seed, **kw):
     else:
         vs = [(rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Z) for _ in range(C)]
     mode = nufft.Direct() if evalmode == O.DIRECT else nufft.FastApproximation()
-    plan = nufft.PlanNUFFT(Z, dims, m=M, sigma=sigma, ntransforms=C, kernel_evalmode=mode,
+    kcls = getattr(nufft, _KERNEL_OBJ[kernel])
+    kobj = kcls() if kernel_param is None else kcls(kernel_param)
+    plan = nufft.PlanNUFFT(Z, dims, m=M, sigma=sigma, ntransforms=C, kernel_evalmode=mode, kernel=kobj,
                            backend=nufft.ROCBackend(0), **kw)
-    To = np.float64 if _f32_overflows(Z, dims, M) else T.type
-    oplan = O.OraclePlan(dims, is_real=is_real, dtype=To, M=M, sigma=sigma, evalmode=evalmode, ntransforms=C)
+    big_window = kernel in (O.KERNEL_BKB, O.KERNEL_KB)
+    To = np.float64 if (big_window and _f32_overflows(Z, dims, M)) else T.type
+    oplan = O.OraclePlan(dims, is_real=is_real, dtype=To, M=M, sigma=sigma, evalmode=evalmode, ntransforms=C,
+                         kernel=kernel, kernel_param=kernel_param)
     return nufft, plan, oplan, xs, vs
 
 
@@ -97,10 +105,52 @@ CASES = [
 ]
 
 
+# The other spreading kernels: every kernel x evaluation mode of the reference
+# (test/accuracy.jl:252-283 loops over the same four kernels), all element types, D = 1..3.
+KERNEL_CASES = [
+    # kernel, Z, dims, M, sigma, evalmode, C
+    (O.KERNEL_KB, np.float64, (35, 64, 40), 4, 1.5, O.DIRECT, 1),
+    (O.KERNEL_KB, np.float64, (35, 64, 40), 4, 1.5, O.FAST_APPROXIMATION, 1),
+    (O.KERNEL_KB, np.complex64, (24, 20, 30), 4, 2.0, O.DIRECT, 1),
+    (O.KERNEL_KB, np.complex128, (37, 41), 8, 1.25, O.DIRECT, 2),
+    (O.KERNEL_KB, np.float32, (100,), 2, 2.0, O.FAST_APPROXIMATION, 1),
+    (O.KERNEL_KB, np.float64, (16, 12, 14), 10, 2.0, O.DIRECT, 1),
+    (O.KERNEL_GAUSSIAN, np.float64, (35, 64, 40), 4, 2.0, O.DIRECT, 1),
+    (O.KERNEL_GAUSSIAN, np.float64, (35, 64, 40), 4, 2.0, O.FAST_APPROXIMATION, 1),
+    (O.KERNEL_GAUSSIAN, np.complex128, (24, 20, 30), 7, 2.0, O.FAST_APPROXIMATION, 2),
+    (O.KERNEL_GAUSSIAN, np.float32, (64, 48), 3, 2.0, O.DIRECT, 1),
+    (O.KERNEL_GAUSSIAN, np.complex64, (128,), 5, 1.5, O.FAST_APPROXIMATION, 1),
+    (O.KERNEL_GAUSSIAN, np.float64, (16, 12, 14), 10, 2.0, O.FAST_APPROXIMATION, 1),
+    (O.KERNEL_BSPLINE, np.float64, (35, 64, 40), 4, 2.0, O.DIRECT, 1),
+    (O.KERNEL_BSPLINE, np.float64, (32, 32, 32), 4, 2.0, O.FAST_APPROXIMATION, 1),
+    (O.KERNEL_BSPLINE, np.complex128, (24, 20, 30), 6, 2.0, O.DIRECT, 2),
+    (O.KERNEL_BSPLINE, np.float32, (64, 48), 2, 2.0, O.FAST_APPROXIMATION, 1),
+    (O.KERNEL_BSPLINE, np.complex64, (100,), 3, 1.25, O.DIRECT, 1),
+    (O.KERNEL_BSPLINE, np.float64, (16, 12, 14), 10, 2.0, O.DIRECT, 1),
+]
+
+
+@pytest.mark.parametrize("kernel,Z,dims,M,sigma,evalmode,C", KERNEL_CASES)
+def test_other_kernels_match_oracle(kernel, Z, dims, M, sigma, evalmode, C):
+    _check_type1_type2(Z, dims, M, sigma, evalmode, C, kernel=kernel)
+
+
+def test_explicit_kernel_parameters_match_oracle():
+    """KaiserBesselKernel(β), BackwardsKaiserBesselKernel(β), GaussianKernel(ℓ) (test/accuracy.jl:285-297)."""
+    beta = 2 * np.pi * (2 - 1 / 2.0)
+    _check_type1_type2(np.float64, (48, 40), 2, 2.0, O.DIRECT, 1, kernel=O.KERNEL_KB, kernel_param=beta)
+    _check_type1_type2(np.float64, (48, 40), 2, 2.0, O.FAST_APPROXIMATION, 1, kernel=O.KERNEL_BKB, kernel_param=beta)
+    _check_type1_type2(np.complex128, (48, 40), 4, 2.0, O.FAST_APPROXIMATION, 1, kernel=O.KERNEL_GAUSSIAN, kernel_param=1.05)
+
+
 @pytest.mark.parametrize("Z,dims,M,sigma,evalmode,C", CASES)
 def test_type1_type2_match_oracle(Z, dims, M, sigma, evalmode, C):
+    _check_type1_type2(Z, dims, M, sigma, evalmode, C)
+
+
+def _check_type1_type2(Z, dims, M, sigma, evalmode, C, **kw):
     Np = 2000
-    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, sigma, evalmode, C, Np, seed=42)
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, sigma, evalmode, C, Np, seed=42, **kw)
     dev = plan.device
     xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
     vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
@@ -115,7 +165,7 @@ def test_type1_type2_match_oracle(Z, dims, M, sigma, evalmode, C):
     ref = ref if C > 1 else [ref]
     # Float32 against the Float64 oracle also sees the Float32 rounding of the coordinates (phase error
     # ~ k_max * 2π * 6e-8), hence the looser bound in that one situation.
-    tol = 2e-4 if _f32_overflows(Z, dims, M) else _rtol(Z)
+    tol = 2e-4 if (np.dtype(oplan.dtype) == np.float64 and plan_real_dtype(Z) == np.float32) else _rtol(Z)
     for c in range(C):
         assert _rel(us[c].cpu().numpy(), ref[c]) < tol
 

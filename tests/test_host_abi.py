@@ -78,6 +78,44 @@ def test_host_plan_matches_oracle_plan_math(nufft, Z, dims, M, sigma):
     assert 0 < info.lds_bytes_spread <= 163840 and 0 < info.lds_bytes_interp <= 163840
 
 
+@pytest.mark.parametrize("Z", [np.float64, np.complex64])
+@pytest.mark.parametrize("kname,kid,param", [("KaiserBesselKernel", O.KERNEL_KB, None), ("KaiserBesselKernel", O.KERNEL_KB, 14.0),
+                                              ("GaussianKernel", O.KERNEL_GAUSSIAN, None), ("GaussianKernel", O.KERNEL_GAUSSIAN, 1.1),
+                                              ("BSplineKernel", O.KERNEL_BSPLINE, None),
+                                              ("BackwardsKaiserBesselKernel", O.KERNEL_BKB, 13.5)])
+def test_host_plan_math_of_the_other_kernels(nufft, Z, kname, kid, param):
+    """Shape parameter, Fourier coefficients and polynomial coefficients of every kernel of the reference
+    (src/Kernels/*.jl `optimal_kernel`, `evaluate_fourier_func`) against the oracle's restatement."""
+    Z = np.dtype(Z)
+    T = np.float32 if Z == np.dtype(np.complex64) else np.float64
+    dims, M, sigma = (40, 36), 4, 1.5
+    kcls = getattr(nufft, kname)
+    p = nufft.PlanNUFFT(Z, dims, m=M, sigma=sigma, kernel=kcls() if param is None else kcls(param), backend=None)
+    o = O.OraclePlan(dims, is_real=Z.kind == "f", dtype=T, M=M, sigma=sigma, kernel=kid, kernel_param=param)
+    info = p.info()
+    assert info.kernel == kid
+    for d in range(2):
+        assert abs(info.beta[d] - o.betas[d]) <= 1e-15 * max(o.betas[d], 1.0)
+        rtol = 1e-13 if T == np.float64 else 5e-7          # Float32 plans: tau / beta are rounded to Float32 first
+        assert np.allclose(p.fourier_coefficients(d), o.phihat[d], rtol=rtol, atol=0)
+        cs = p.polynomial_coefficients(d)
+        assert cs.shape == o.coefs[d].shape
+        if cs.size:
+            assert np.max(np.abs(cs - o.coefs[d])) < 1e-12 * np.max(np.abs(o.coefs[d]))
+        peak = {O.KERNEL_BKB: np.sinh(o.betas[d]) / np.pi, O.KERNEL_KB: float(np.i0(o.betas[d]))}.get(kid, 1.0)
+        assert 0.5 <= peak * 2.0 ** info.window_scale_log2[d] <= 2.0
+
+
+def test_kernel_argument_errors(nufft):
+    lib = nufft.lib
+    h = C.c_void_p()
+    N = (C.c_int64 * 3)(64, 64, 64)
+    rc = lib.nufft_plan_create(C.byref(h), 1, 0, 3, N, 4, 2.0, 7, 0, 1, 0, 0, -1)       # unknown kernel id
+    assert rc == nufft._lib.ERR_UNSUPPORTED and not h.value
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.float64, (64,), kernel="gaussian", backend=None)
+
+
 def test_tile_choice_on_the_headline_config(nufft):
     """on C2 both halo amplifications must beat the reference's 12^3 cube at 64 KiB
     (19^3 / 12^3 = 3.97): point visits per point for the output-driven spreading tile, tile-load
@@ -101,7 +139,7 @@ def test_error_codes_of_plan_creation(nufft):
     assert lib.nufft_plan_create(C.byref(h), 7, 0, 3, N, 4, 2.0, 0, 0, 1, 0, 0, -1) == nufft._lib.ERR_INVALID_ARG
     assert lib.nufft_plan_create(C.byref(h), 1, 0, 4, N, 4, 2.0, 0, 0, 1, 0, 0, -1) == nufft._lib.ERR_UNSUPPORTED
     assert lib.nufft_plan_create(C.byref(h), 1, 0, 3, N, 11, 2.0, 0, 0, 1, 0, 0, -1) == nufft._lib.ERR_UNSUPPORTED
-    assert lib.nufft_plan_create(C.byref(h), 1, 0, 3, N, 4, 2.0, 3, 0, 1, 0, 0, -1) == nufft._lib.ERR_UNSUPPORTED
+    assert lib.nufft_plan_create(C.byref(h), 1, 0, 3, N, 4, 2.0, 4, 0, 1, 0, 0, -1) == nufft._lib.ERR_UNSUPPORTED   # kernel id
     assert lib.nufft_plan_create(C.byref(h), 1, 0, 3, N, 4, 2.0, 0, 5, 1, 0, 0, -1) == nufft._lib.ERR_INVALID_ARG
     # a host-only plan has no device path: every device entry point refuses, nothing is launched
     assert lib.nufft_plan_create(C.byref(h), 1, 0, 3, N, 4, 2.0, 0, 0, 1, 0, 0, -1) == 0
