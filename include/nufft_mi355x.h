@@ -56,7 +56,11 @@ enum {                                                          /* the four kern
 };
 enum { NUFFT_EVAL_DIRECT = 0, NUFFT_EVAL_FAST_APPROXIMATION = 1 }; /* Kernels.EvaluationMode     */
 enum { NUFFT_METHOD_SHARED_MEMORY = 0 };                       /* gpu_method = :shared_memory    */
-enum { NUFFT_POINT_TRANSFORM_IDENTITY = 0 };                   /* point_transform = identity     */
+enum {
+    NUFFT_POINT_TRANSFORM_IDENTITY = 0, /* point_transform = identity (src/plan.jl:476)                    */
+    NUFFT_POINT_TRANSFORM_NFFT     = 1  /* _transform_point_convention, src/abstractNFFTs.jl:147-155:
+                                           x in [-1/2, 1/2), opposite sign of the exponent (plan_nfft)     */
+};
 
 /* Stage identifiers (nufft_get_stage_times), in the order of the reference's TimerOutputs
  * labels: src/blocking/gpu.jl:93-139, src/NonuniformFFTs.jl:157-186,246-283. */

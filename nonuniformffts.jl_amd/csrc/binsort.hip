@@ -22,6 +22,7 @@ struct BinArgs {
     const T* x[3];
     int64_t np;
     Geom g;
+    int point_transform;       // NUFFT_POINT_TRANSFORM_*
 };
 
 // Linear index of the fine bin of point p (dimension 1 fastest); the analogue of block_index,
@@ -31,7 +32,7 @@ __device__ __forceinline__ uint32_t tile_of_point(const BinArgs<T, D>& a, int64_
     uint32_t bin = 0, mul = 1;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        const T xf = fold_to_unit_cell(a.x[d][p]);
+        const T xf = transform_and_fold(a.x[d][p], a.point_transform);
         r[d] = to_grid_units(xf, a.g.Nover[d]);
         const int i = cell_of(r[d], a.g.Nover[d]);
         bin += mul * (uint32_t)(i >> a.g.blog[d]);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs<T, D> a, const
         PointRec<T, D> rec;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const T xf = fold_to_unit_cell(a.x[d][p]);
+            const T xf = transform_and_fold(a.x[d][p], a.point_transform);
             rec.r[d] = to_grid_units(xf, a.g.Nover[d]);
         }
         rec.idx = (int32_t)p;
@@ -76,6 +77,7 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
     for (int d = 0; d < 3; ++d) a.x[d] = d < D ? static_cast<const T*>(s.coords[d]) : nullptr;
     a.np = s.np;
     a.g = s.g;
+    a.point_transform = s.point_transform;
     hipError_t e = hipMemsetAsync(s.counts, 0, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
     if (e != hipSuccess) return e;
     if (s.np > 0) {

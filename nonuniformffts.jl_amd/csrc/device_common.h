@@ -2,6 +2,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include "nufft_mi355x.h"
 #include <cstdint>
 
 namespace nufft {
@@ -61,6 +63,23 @@ __device__ __forceinline__ T fold_to_unit_cell(T x) {
     T r = fmod(x, L);
     r = (r == T(0)) ? T(0) : r;      // -0.0 -> +0.0
     return (r < T(0)) ? (L + r) : r;
+}
+
+// _transform_point_convention, reference src/abstractNFFTs.jl:147-155: AbstractNFFTs locations
+// x ∈ [-1/2, 1/2) and opposite sign of the exponent -> this package's x ∈ [0, 2π).  Applied before the
+// fold (point_transform_fold = to_unit_cell ∘ point_transform, src/set_points.jl:46-50).
+template <typename T>
+__device__ __forceinline__ T nfft_point_convention(T x) {
+    const T L = TwoPi<T>::value;
+    T t = L * x;
+    t = -t;
+    return t < T(0) ? t + L : t;
+}
+
+template <typename T>
+__device__ __forceinline__ T transform_and_fold(T x, int point_transform) {
+    if (point_transform == NUFFT_POINT_TRANSFORM_NFFT) x = nfft_point_convention(x);
+    return fold_to_unit_cell(x);
 }
 
 // point_to_cell, reference src/Kernels/Kernels.jl:121-126: r = (x / L) * N in this order.

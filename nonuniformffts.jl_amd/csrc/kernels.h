@@ -12,6 +12,7 @@ namespace nufft {
 // ---- bin sort (binsort.hip) ------------------------------------------------------------------
 struct SortArgs {
     int dtype, D;
+    int point_transform;   // NUFFT_POINT_TRANSFORM_*
     int64_t np;
     const void* coords[3];
     Geom g;

@@ -94,6 +94,7 @@ struct nufft_plan {
     double sigma = 2.0;
     double beta[3] = {0, 0, 0};
     int kernel = 0;                    // NUFFT_KERNEL_*
+    int point_transform = 0;           // NUFFT_POINT_TRANSFORM_*
     double tau[3] = {0, 0, 0};         // Gaussian: 2 (ℓ Δx)²
     double eval_p0[3] = {0, 0, 0};     // window parameters handed to the kernels (see WindowEval)
     int scale_exp[3] = {0, 0, 0};      // device windows and phi_hat carry a factor 2^scale_exp[d]

@@ -160,7 +160,9 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     if (p->evalmode != NUFFT_EVAL_DIRECT && p->evalmode != NUFFT_EVAL_FAST_APPROXIMATION)
         return fail(NUFFT_ERR_INVALID_ARG, "evalmode must be Direct (0) or FastApproximation (1)");
     if (in->gpu_method != NUFFT_METHOD_SHARED_MEMORY) return fail(NUFFT_ERR_INVALID_ARG, "expected gpu_method = :shared_memory");
-    if (in->point_transform != NUFFT_POINT_TRANSFORM_IDENTITY) return fail(NUFFT_ERR_UNSUPPORTED, "only point_transform = identity is built");
+    if (in->point_transform != NUFFT_POINT_TRANSFORM_IDENTITY && in->point_transform != NUFFT_POINT_TRANSFORM_NFFT)
+        return fail(NUFFT_ERR_UNSUPPORTED, "point_transform must be identity or the AbstractNFFTs convention (closures cannot cross the ABI)");
+    p->point_transform = in->point_transform;
     if (p->M < kMinM || p->M > kMaxM) return fail(NUFFT_ERR_UNSUPPORTED, "half-support M must be in 2..10");
     if (!(p->sigma_req >= 1.0)) return fail(NUFFT_ERR_INVALID_ARG, "sigma must be >= 1");
 
@@ -829,6 +831,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     SortArgs s{};
     s.dtype = p->dtype;
     s.D = p->D;
+    s.point_transform = p->point_transform;
     s.np = np;
     for (int d = 0; d < 3; ++d) s.coords[d] = d < p->D ? coords[d] : nullptr;
     s.g = make_geom(p);

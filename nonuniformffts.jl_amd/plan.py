@@ -17,6 +17,7 @@ Error mapping: Julia ``ArgumentError`` -> ``ValueError``; ``DimensionMismatch`` 
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple, Union
 
@@ -89,6 +90,14 @@ class NUFFTCallbacks:
                 "apply them outside the transform")
 
 
+def transform_point_convention(x):
+    """``_transform_point_convention`` (src/abstractNFFTs.jl:147-155) for host-side use; passing this
+    function (or ``"nfft"``) as ``point_transform`` selects the device implementation of the same map."""
+    twopi = 2 * math.pi
+    x = -(twopi * x)
+    return torch.where(x < 0, x + twopi, x) if isinstance(x, torch.Tensor) else (x + twopi if x < 0 else x)
+
+
 def default_kernel(backend=None):
     """ext/NonuniformFFTsAMDGPUExt.jl:54."""
     return BackwardsKaiserBesselKernel()
@@ -153,7 +162,7 @@ class PlanNUFFT:
                  m: Union[int, HalfSupport] = 4, sigma: float = 2.0, σ: Optional[float] = None,
                  kernel=None, ntransforms: int = 1, backend=ROCBackend(0),
                  kernel_evalmode=None, fftshift: bool = False, gpu_method: str = "shared_memory",
-                 sort_points: bool = False, synchronise: bool = False, block_size=None,
+                 sort_points: bool = False, synchronise: bool = False, block_size=None, point_transform=None,
                  tile_dims: Optional[Sequence[int]] = None, interp_tile_dims: Optional[Sequence[int]] = None,
                  bin_log2: int = 0, lds_budget_bytes: int = 0, spread_threads: int = 0, interp_threads: int = 0):
         if dims is None:           # PlanNUFFT(dims; ...) form: ComplexF64 by default (src/plan.jl:597-599)
@@ -179,10 +188,17 @@ class PlanNUFFT:
             raise ValueError("kernel_evalmode must be Direct() or FastApproximation()")
         if gpu_method not in ("global_memory", "shared_memory"):
             raise ValueError("expected gpu_method ∈ (:global_memory, :shared_memory)")   # src/blocking/gpu.jl:26
-        if gpu_method != "shared_memory":
-            raise ValueError("gpu_method = :global_memory is not built; use :shared_memory")
-        if sort_points:
-            raise ValueError("sort_points = True() is not built (points are always bin-sorted into plan-owned storage)")
+        # gpu_method = :global_memory and sort_points = True() only change how the reference schedules the
+        # same arithmetic (src/spreading/gpu.jl:168-186, src/blocking/gpu.jl:126-137); here every plan runs
+        # the LDS-tile path on points that are always bin-sorted into plan-owned storage, so both are accepted.
+        if point_transform in (None, "identity"):
+            ptrans = 0
+        elif point_transform in ("nfft", "abstractnffts") or point_transform is transform_point_convention:
+            ptrans = 1                                              # src/abstractNFFTs.jl:147-155
+        else:
+            raise ValueError("point_transform must be None (identity) or the AbstractNFFTs convention: "
+                             "arbitrary closures cannot cross the C ABI")
+        self.point_transform = ptrans
         self.kernel = kernel
         self.kernel_evalmode = kernel_evalmode
         self.backend = backend
@@ -209,7 +225,7 @@ class PlanNUFFT:
         prm.evalmode = _lib.EVAL_DIRECT if isinstance(kernel_evalmode, Direct) else _lib.EVAL_FAST_APPROXIMATION
         prm.ntransforms = self._ntransforms
         prm.fftshift = int(self.fftshift)
-        prm.point_transform = 0
+        prm.point_transform = ptrans
         prm.gpu_method = 0
         if backend is None:
             prm.device = -1

@@ -46,6 +46,10 @@ KERNEL_KB = 1           # KaiserBesselKernel, src/Kernels/kaiser_bessel.jl
 KERNEL_GAUSSIAN = 2     # GaussianKernel, src/Kernels/gaussian.jl
 KERNEL_BSPLINE = 3      # BSplineKernel, src/Kernels/bspline.jl
 
+# point_transform (values of NUFFT_POINT_TRANSFORM_*)
+POINT_TRANSFORM_IDENTITY = 0
+POINT_TRANSFORM_NFFT = 1    # _transform_point_convention, src/abstractNFFTs.jl:147-155
+
 
 # --------------------------------------------------------------------------------------
 # Plan-time parameter math
@@ -311,6 +315,7 @@ class OraclePlan:
     fftshift: bool = False
     kernel: int = KERNEL_BKB
     kernel_param: Optional[float] = None
+    point_transform: int = POINT_TRANSFORM_IDENTITY
     # derived
     Nover: Tuple[int, ...] = field(init=False)
     ks: list = field(init=False)
@@ -399,6 +404,15 @@ def to_unit_cell(x: np.ndarray) -> np.ndarray:
     r = np.fmod(x, L)
     r = np.where(r == 0, np.abs(r), r)          # -0.0 -> +0.0
     return np.where(r < 0, L + r, r).astype(x.dtype)
+
+
+def nfft_point_convention(x: np.ndarray) -> np.ndarray:
+    """AbstractNFFTs locations x in [-1/2, 1/2) and the opposite sign of the exponent -> x in [0, 2pi)
+    (src/abstractNFFTs.jl:147-155), in the precision of ``x``."""
+    x = np.asarray(x)
+    L = x.dtype.type(TWO_PI)
+    t = -(L * x)
+    return np.where(t < 0, t + L, t).astype(x.dtype)
 
 
 def point_to_cell(x: np.ndarray, N: int):
@@ -500,7 +514,10 @@ def _stencil_indices(plan: OraclePlan):
     inds, vals = [], []
     M = plan.M
     for d in range(plan.ndim):
-        x = to_unit_cell(plan.points[d])
+        x = plan.points[d]
+        if plan.point_transform == POINT_TRANSFORM_NFFT:      # to_unit_cell ∘ point_transform, src/set_points.jl:46-50
+            x = nfft_point_convention(x)
+        x = to_unit_cell(x)
         i, v = evaluate_window(plan, d, x)
         i = np.minimum(i, plan.Nover[d] - 1)
         j = (i[:, None] - M + 1 + np.arange(2 * M)[None, :]) % plan.Nover[d]   # kernel_indices

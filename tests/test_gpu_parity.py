@@ -46,13 +46,16 @@ _KERNEL_OBJ = {O.KERNEL_BKB: "BackwardsKaiserBesselKernel", O.KERNEL_KB: "Kaiser
                O.KERNEL_GAUSSIAN: "GaussianKernel", O.KERNEL_BSPLINE: "BSplineKernel"}
 
 
-def _make_case(Z, dims, M, sigma, evalmode, C, Np, seed, kernel=O.KERNEL_BKB, kernel_param=None, **kw):
+def _make_case(Z, dims, M, sigma, evalmode, C, Np, seed, kernel=O.KERNEL_BKB, kernel_param=None, fftshift=False,
+               point_transform=0, **kw):
     nufft = _nufft()
     Z = np.dtype(Z)
     is_real = Z.kind == "f"
     T = np.dtype(np.float32) if Z.itemsize in (4,) or Z == np.complex64 else np.dtype(np.float64)
     rng = np.random.default_rng(seed)
     xs = [(rng.random(Np) * 3 - 1) * O.TWO_PI for _ in dims]          # points outside the unit cell too
+    if point_transform == O.POINT_TRANSFORM_NFFT:
+        xs = [rng.random(Np) - 0.5 for _ in dims]                     # AbstractNFFTs convention: [-1/2, 1/2)
     xs = [x.astype(T) for x in xs]
     if is_real:
         vs = [rng.standard_normal(Np).astype(Z) for _ in range(C)]
@@ -62,11 +65,12 @@ def _make_case(Z, dims, M, sigma, evalmode, C, Np, seed, kernel=O.KERNEL_BKB, ke
     kcls = getattr(nufft, _KERNEL_OBJ[kernel])
     kobj = kcls() if kernel_param is None else kcls(kernel_param)
     plan = nufft.PlanNUFFT(Z, dims, m=M, sigma=sigma, ntransforms=C, kernel_evalmode=mode, kernel=kobj,
+                           fftshift=fftshift, point_transform="nfft" if point_transform else None,
                            backend=nufft.ROCBackend(0), **kw)
     big_window = kernel in (O.KERNEL_BKB, O.KERNEL_KB)
     To = np.float64 if (big_window and _f32_overflows(Z, dims, M)) else T.type
     oplan = O.OraclePlan(dims, is_real=is_real, dtype=To, M=M, sigma=sigma, evalmode=evalmode, ntransforms=C,
-                         kernel=kernel, kernel_param=kernel_param)
+                         kernel=kernel, kernel_param=kernel_param, fftshift=fftshift, point_transform=point_transform)
     return nufft, plan, oplan, xs, vs
 
 
@@ -141,6 +145,46 @@ def test_explicit_kernel_parameters_match_oracle():
     _check_type1_type2(np.float64, (48, 40), 2, 2.0, O.DIRECT, 1, kernel=O.KERNEL_KB, kernel_param=beta)
     _check_type1_type2(np.float64, (48, 40), 2, 2.0, O.FAST_APPROXIMATION, 1, kernel=O.KERNEL_BKB, kernel_param=beta)
     _check_type1_type2(np.complex128, (48, 40), 4, 2.0, O.FAST_APPROXIMATION, 1, kernel=O.KERNEL_GAUSSIAN, kernel_param=1.05)
+
+
+@pytest.mark.parametrize("Z,dims", [(np.float64, (35, 64, 40)), (np.complex128, (37, 41)), (np.float64, (32, 32, 32)),
+                                    (np.complex64, (100,)), (np.float64, (31, 33)), (np.complex128, (16, 15, 12))])
+def test_fftshift_ordering_matches_oracle(Z, dims):
+    """fftshift = true: uniform data in increasing-frequency order (src/plan.jl:472,509-514,
+    src/NonuniformFFTs.jl:318-348), on the general and on the pruned-FFT path, odd and even sizes."""
+    _check_type1_type2(Z, dims, 4, 2.0, O.FAST_APPROXIMATION, 1, fftshift=True)
+
+
+@pytest.mark.parametrize("Z,dims,fftshift", [(np.complex128, (64, 81), True), (np.complex64, (128,), True),
+                                             (np.complex128, (24, 20, 30), False), (np.float64, (40, 36), True)])
+def test_nfft_point_convention_matches_oracle(Z, dims, fftshift):
+    """point_transform = _transform_point_convention (src/abstractNFFTs.jl:147-155) on the device."""
+    _check_type1_type2(Z, dims, 4, 2.0, O.DIRECT, 1, fftshift=fftshift, point_transform=O.POINT_TRANSFORM_NFFT)
+
+
+def test_nfft_plan_interface():
+    """NonuniformFFTs.NFFTPlan / plan_nfft (src/abstractNFFTs.jl:52-229) against the direct sums of the
+    NFFT definition (test/abstractNFFTs.jl:11-64 compares with NFFT.jl on the same sizes)."""
+    nufft = _nufft()
+    rng = np.random.default_rng(43)
+    dims, Np = (64, 81), 1000
+    xp = rng.random((Np, 2)) - 0.5
+    vp = rng.standard_normal(Np) + 1j * rng.standard_normal(Np)
+    xd = torch.from_numpy(xp).cuda()
+    p = nufft.plan_nfft(xd, dims, m=5, sigma=2.0, window="kaiser_bessel")
+    assert isinstance(p, nufft.NFFTPlan) and p.size_in == dims and p.size_out == (Np,)
+    assert repr(p).startswith("NonuniformFFTs.NFFTPlan{torch.float64, 2} wrapping a PlanNUFFT:")
+    us = p.adjoint_mul(torch.from_numpy(vp).cuda())
+    ks = [np.arange(-(N // 2), -(N // 2) + N, dtype=np.float64) for N in dims]
+    E = [np.exp(2j * np.pi * np.outer(ks[d], xp[:, d])) for d in range(2)]
+    exact = np.einsum("bp,ap,p->ba", E[1], E[0], vp, optimize=True)
+    assert _rel(us.cpu().numpy(), exact) < 1e-9
+    wp = p.mul(torch.from_numpy(np.ascontiguousarray(exact)).cuda())
+    exact2 = np.einsum("bp,ap,ba->p", np.conj(E[1]), np.conj(E[0]), exact, optimize=True)
+    assert _rel(wp.cpu().numpy(), exact2) < 1e-9
+    # the arguments the reference accepts for scheduling only are accepted here too
+    q = nufft.PlanNUFFT(np.complex128, (24, 24), gpu_method="global_memory", sort_points=True, block_size=(8, 8))
+    assert q.size == (24, 24)
 
 
 @pytest.mark.parametrize("Z,dims,M,sigma,evalmode,C", CASES)
