@@ -174,6 +174,25 @@ int nufft_exec_type1(nufft_plan* plan, void* const* uhat_out, const void* const*
 /* exec_type2!(vp, p, ûs_k), src/NonuniformFFTs.jl:237-291. */
 int nufft_exec_type2(nufft_plan* plan, void* const* values_out, const void* const* uhat_in, void* stream);
 
+/* exec_type1!(ûs, p, vp; callbacks) / exec_type2!(vp, p, ûs; callbacks), src/NonuniformFFTs.jl:148-195,237-291,
+ * for the two documented uses of NUFFTCallbacks (src/plan.jl:105-143, test/callbacks.jl:17-25) — arbitrary
+ * closures cannot cross a C ABI:
+ *   point_weights  T[Np]  (device, real, in the caller's point order): callbacks.nonuniform = (v, n) -> v * w[n],
+ *                  applied to the values read by type 1 / written by type 2 (src/spreading/gpu.jl:289,
+ *                  src/interpolation/gpu.jl:254);
+ *   mode_factors   T[N_out...] (device, real, same layout as one uniform array, shared by all components):
+ *                  callbacks.uniform = (w, idx) -> w * f[idx], applied to the modes written by type 1 / read by
+ *                  type 2 (src/NonuniformFFTs.jl:395-399,461-464).
+ * Either pointer may be NULL (identity).  Both are fused into existing kernels: no extra pass over the data. */
+typedef struct nufft_callbacks {
+    const void* point_weights;
+    const void* mode_factors;
+} nufft_callbacks;
+int nufft_exec_type1_cb(nufft_plan* plan, void* const* uhat_out, const void* const* values_in,
+                        const nufft_callbacks* callbacks, void* stream);
+int nufft_exec_type2_cb(nufft_plan* plan, void* const* values_out, const void* const* uhat_in,
+                        const nufft_callbacks* callbacks, void* stream);
+
 /* ---- stage-level entry points (the backend-dispatched generic functions) -- */
 
 /* fill_with_zeros_kernel!(us), src/NonuniformFFTs.jl:116-122,161-167. */

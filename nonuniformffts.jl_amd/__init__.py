@@ -10,14 +10,14 @@ The directory name contains a dot, so load it with ``nufft_pkg.py`` at the repo 
 from ._lib import LIB_PATH, lib  # noqa: F401  (fails loudly if the extension is missing)
 from .plan import (  # noqa: F401
     BackwardsKaiserBesselKernel, BSplineKernel, DimensionMismatch, Direct, FastApproximation, GaussianKernel,
-    HalfSupport, KaiserBesselKernel, NUFFTCallbacks, PlanNUFFT, ROCBackend, default_kernel,
+    HalfSupport, KaiserBesselKernel, ModeFactors, NUFFTCallbacks, PlanNUFFT, PointWeights, ROCBackend, default_kernel,
     default_kernel_evalmode, exec_type1, exec_type1_, exec_type2, exec_type2_, interpolate, oversampled_grid,
     set_points, set_points_, sort_result, spread_from_points, transform_point_convention,
 )
 from .nfft_interface import NFFTPlan, plan_nfft  # noqa: F401
 
 __all__ = [
-    "PlanNUFFT", "NUFFTCallbacks", "HalfSupport", "Direct", "FastApproximation",
+    "PlanNUFFT", "NUFFTCallbacks", "PointWeights", "ModeFactors", "HalfSupport", "Direct", "FastApproximation",
     "BackwardsKaiserBesselKernel", "KaiserBesselKernel", "GaussianKernel", "BSplineKernel", "ROCBackend", "DimensionMismatch",
     "set_points", "exec_type1", "exec_type2", "set_points_", "exec_type1_", "exec_type2_",
     "NFFTPlan", "plan_nfft",

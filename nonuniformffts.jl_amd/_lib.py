@@ -48,6 +48,10 @@ class NufftParams(C.Structure):
     ]
 
 
+class NufftCallbacks(C.Structure):
+    _fields_ = [("point_weights", C.c_void_p), ("mode_factors", C.c_void_p)]
+
+
 class NufftInfo(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("is_complex", C.c_int32), ("ndim", C.c_int32), ("half_support", C.c_int32),
@@ -79,6 +83,8 @@ SYMBOLS = {
     "nufft_set_points": (C.c_int, [_P, C.c_int64, _PP, _P]),
     "nufft_exec_type1": (C.c_int, [_P, _PP, _PP, _P]),
     "nufft_exec_type2": (C.c_int, [_P, _PP, _PP, _P]),
+    "nufft_exec_type1_cb": (C.c_int, [_P, _PP, _PP, _P, _P]),
+    "nufft_exec_type2_cb": (C.c_int, [_P, _PP, _PP, _P, _P]),
     "nufft_fill_zeros": (C.c_int, [_P, _P]),
     "nufft_spread": (C.c_int, [_P, _PP, _P]),
     "nufft_fft_forward": (C.c_int, [_P, _P]),

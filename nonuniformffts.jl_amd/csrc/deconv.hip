@@ -29,6 +29,7 @@ struct DeconvDev {
     typename Cplx<T>::type* uni[kMaxCompPerLaunch];
     T normfactor;
     int ncomp;
+    const T* mode_factors;     // optional real multiplier per output mode (uniform callback menu), or null
 };
 
 template <typename T, int D>
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256) void deconv_truncate_kernel(DeconvDev<T> a) {
         j += (int64_t)a.index_map[2][i3] * a.nspec[0] * a.nspec[1];
         o += (int64_t)i3 * a.nout[0] * a.nout[1];
     }
-    const T f = a.normfactor / phi;   // β = normfactor / prod(ϕ̂), src/NonuniformFFTs.jl:394
+    T f = a.normfactor / phi;         // β = normfactor / prod(ϕ̂), src/NonuniformFFTs.jl:394
+    if (a.mode_factors) f *= a.mode_factors[o];     // callbacks.uniform(ŵ, idx), :395-399
     for (int c = 0; c < a.ncomp; ++c) {
         const C2 u = a.spec[c][j];
         C2 w;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(256) void deconv_pad_kernel(DeconvDev<T> a) {
     int64_t o = i1;
     if constexpr (D >= 2) { phi *= a.phihat[1][i2]; o += (int64_t)i2 * a.nout[0]; }
     if constexpr (D >= 3) { phi *= a.phihat[2][i3]; o += (int64_t)i3 * a.nout[0] * a.nout[1]; }
-    const T f = T(1) / phi;           // β = 1 / prod(ϕ̂), src/NonuniformFFTs.jl:460
+    T f = T(1) / phi;                 // β = 1 / prod(ϕ̂), src/NonuniformFFTs.jl:460
+    if (a.mode_factors) f *= a.mode_factors[o];     // callbacks.uniform(ŵ, idx), :461-464
     for (int c = 0; c < a.ncomp; ++c) {
         const C2 w = a.uni[c][o];
         C2 u;
@@ -107,6 +110,7 @@ static hipError_t run_deconv(const DeconvArgs& a, void* const* uni, bool pad, hi
             d.inv_map[k] = a.inv_map[k];
         }
         d.normfactor = (T)a.normfactor;
+        d.mode_factors = static_cast<const T*>(a.mode_factors);
         d.ncomp = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         for (int c = 0; c < d.ncomp; ++c) {
             d.spec[c] = static_cast<C2*>(a.spec) + (int64_t)(c0 + c) * a.spec_stride;

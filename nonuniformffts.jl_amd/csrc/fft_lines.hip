@@ -85,6 +85,7 @@ struct FftLineArgs {
     const void* fk;           // T[nk]: factor by k'
     const void* twiddle;      // complex<T>[N]: exp(SIGN 2πi m / N)
     double scale;             // extra scalar factor (normfactor)
+    const void* mult;         // optional T[]: real multiplier indexed like the pruned side (uniform callback), or null
 };
 
 // One radix-R Stockham stage of a line held in LDS (in place, wave-synchronous).
@@ -139,7 +140,8 @@ __device__ __forceinline__ void fft_line(typename Cplx2<T>::type* line, const ty
 }
 
 // FWD: full input (N along j), pruned output (nk along k').  BWD: pruned input, full output.
-template <typename T, int LOGN, bool FWD, int TA>
+// MULT: a real multiplier array (uniform callback menu) is applied on the pruned side.
+template <typename T, int LOGN, bool FWD, int TA, bool MULT>
 __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     using C = typename Cplx2<T>::type;
     constexpr int N = 1 << LOGN;
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     const T* fa = static_cast<const T*>(a.fa);
     const T* fk = static_cast<const T*>(a.fk);
     const T scale = (T)a.scale;
+    const T* mult = static_cast<const T*>(a.mult);
 
     if (!FWD && a0 >= a.a_total) {
         // backward: columns beyond the kept ones are zeros of the oversampled spectrum
@@ -187,8 +190,10 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
         for (int e = tid; e < TA * a.nk; e += NT) {
             const int ai = e % TA, k = e / TA;
             if (a0 + ai < a.a_total) {
-                C v = in[a0 + ai + (int64_t)k * a.in_stride_j];
-                const T f = fa[(a0 + ai) % a.ka] * fk[k] * scale;
+                const int64_t off = a0 + ai + (int64_t)k * a.in_stride_j;
+                C v = in[off];
+                T f = fa[(a0 + ai) % a.ka] * fk[k] * scale;
+                if constexpr (MULT) f *= mult[off];
                 v.x *= f; v.y *= f;
                 lines[ai * LINE + lpad(a.map[k])] = v;
             }
@@ -204,9 +209,11 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
             const int ai = e % TA, k = e / TA;
             if (a0 + ai < a.a_total) {
                 C v = lines[ai * LINE + lpad(a.map[k])];
-                const T f = fa[(a0 + ai) % a.ka] * fk[k] * scale;
+                const int64_t off = a0 + ai + (int64_t)k * a.out_stride_j;
+                T f = fa[(a0 + ai) % a.ka] * fk[k] * scale;
+                if constexpr (MULT) f *= mult[off];
                 v.x *= f; v.y *= f;
-                out[a0 + ai + (int64_t)k * a.out_stride_j] = v;
+                out[off] = v;
             }
         }
     } else {
@@ -349,15 +356,15 @@ hipError_t launch_real_lines(int dtype, int logn, bool forward, const void* in, 
     return forward ? launch_real_t<double, true>(logm, a, stream) : launch_real_t<double, false>(logm, a, stream);
 }
 
-template <typename T, int LOGN, bool FWD>
-static hipError_t launch_logn(const FftLineArgs& a, hipStream_t stream) {
+template <typename T, int LOGN, bool FWD, bool MULT>
+static hipError_t launch_logn_m(const FftLineArgs& a, hipStream_t stream) {
     using C = typename Cplx2<T>::type;
     constexpr int N = 1 << LOGN;
     constexpr int LINE = N + (N >> 4) + 1;
     // TA lines per workgroup: 16 when they fit in ~150 KB of LDS, else 8 / 4
     constexpr int TA = (sizeof(C) * (16 * LINE + N) <= 150 * 1024) ? 16 : ((sizeof(C) * (8 * LINE + N) <= 150 * 1024) ? 8 : 4);
     const size_t lds = sizeof(C) * (size_t)(TA * LINE + N);
-    auto fn = fft_lines_kernel<T, LOGN, FWD, TA>;
+    auto fn = fft_lines_kernel<T, LOGN, FWD, TA, MULT>;
     static bool prepared = false;
     if (!prepared) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -368,6 +375,11 @@ static hipError_t launch_logn(const FftLineArgs& a, hipStream_t stream) {
     dim3 grid((unsigned)((acols + TA - 1) / TA), (unsigned)a.nc, 1);
     hipLaunchKernelGGL(fn, grid, dim3(TA * kWave), lds, stream, a);
     return hipGetLastError();
+}
+
+template <typename T, int LOGN, bool FWD>
+static hipError_t launch_logn(const FftLineArgs& a, hipStream_t stream) {
+    return a.mult ? launch_logn_m<T, LOGN, FWD, true>(a, stream) : launch_logn_m<T, LOGN, FWD, false>(a, stream);
 }
 
 template <typename T, bool FWD>
@@ -394,7 +406,7 @@ hipError_t launch_fft_lines(int dtype, int logn, bool forward, const FftLinePass
     a.in_stride_j = p.in_stride_j; a.in_stride_c = p.in_stride_c;
     a.out_stride_j = p.out_stride_j; a.out_stride_c = p.out_stride_c;
     a.nc = p.nc; a.nk = p.nk; a.map = p.map; a.fa = p.fa; a.ka = p.ka; a.fk = p.fk;
-    a.twiddle = p.twiddle; a.scale = p.scale;
+    a.twiddle = p.twiddle; a.scale = p.scale; a.mult = p.mult;
     if (dtype == NUFFT_F32) return forward ? launch_t<float, true>(logn, a, stream) : launch_t<float, false>(logn, a, stream);
     return forward ? launch_t<double, true>(logn, a, stream) : launch_t<double, false>(logn, a, stream);
 }

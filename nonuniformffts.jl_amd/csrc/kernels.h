@@ -43,6 +43,7 @@ struct TileKernelArgs {
     const void* const* values_in;   // spread: C device vectors Z[np]
     void* const* values_out;        // interp: C device vectors Z[np]
     double prefactor;          // interp: prod(dx_d)
+    const void* weights;       // optional T[np]: real weight per point (nonuniform callback menu), or null
     int threads;
     int lds_bytes;
     int ntiles;                // workgroups per component
@@ -69,6 +70,7 @@ struct DeconvArgs {
     void* spec;                // C oversampled spectra (complex<T>), contiguous
     int64_t spec_stride;       // complex elements between components
     double normfactor;         // prod(2π / Ñ_d) (type 1) or 1 (type 2)
+    const void* mode_factors;  // optional T[prod(nout)]: real multiplier per output mode (uniform callback), or null
 };
 hipError_t launch_deconv_truncate(const DeconvArgs& a, void* const* uhat_out, hipStream_t stream);
 hipError_t launch_deconv_pad(const DeconvArgs& a, const void* const* uhat_in, hipStream_t stream);
@@ -86,6 +88,7 @@ struct FftLinePass {
     const void* fk;                         // T[nk], factor by kept index
     const void* twiddle;                    // complex<T>[N]
     double scale;
+    const void* mult;                       // optional T[...]: real multiplier indexed like the pruned side, or null
 };
 bool fft_lines_supported(int dtype, int64_t n);
 bool real_lines_supported(int dtype, int64_t n);

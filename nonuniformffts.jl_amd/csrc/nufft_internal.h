@@ -93,6 +93,8 @@ struct nufft_plan {
     int64_t Nspec[3] = {1, 1, 1};      // dims of the oversampled spectrum (r2c halves dim 0)
     double sigma = 2.0;
     double beta[3] = {0, 0, 0};
+    const void* cb_point_weights = nullptr;   // set for the duration of nufft_exec_type{1,2}_cb
+    const void* cb_mode_factors = nullptr;
     int kernel = 0;                    // NUFFT_KERNEL_*
     int point_transform = 0;           // NUFFT_POINT_TRANSFORM_*
     double tau[3] = {0, 0, 0};         // Gaussian: 2 (ℓ Δx)²

@@ -440,9 +440,12 @@ static int build_device(nufft_plan* p) {
     }
 
     // kernels: allow the large dynamic LDS allocations
-    const bool other = needs_other_eval(p->kernel, p->evalmode);
-    NUFFT_HIP(prepare_spread(p->dtype, p->is_complex, D, p->M, (int)p->lds_spread, other));
-    NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp, other));
+    // both variants: the general one also serves per-point weights on the default kernels
+    for (int other = 0; other < 2; ++other) {
+        if (!other && needs_other_eval(p->kernel, p->evalmode)) continue;
+        NUFFT_HIP(prepare_spread(p->dtype, p->is_complex, D, p->M, (int)p->lds_spread, other != 0));
+        NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp, other != 0));
+    }
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
         hipEvent_t a, b;
@@ -515,6 +518,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
         // prefactor = prod(Δx_d), src/interpolation/gpu.jl:55-56
         for (int d = 0; d < p->D; ++d) a.prefactor *= 2.0 * M_PI / (double)p->Nover[d];
     }
+    a.weights = p->cb_point_weights;
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.fixed_tile = interp && p->interp_fixed;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
@@ -537,6 +541,7 @@ static DeconvArgs deconv_args(const nufft_plan* p) {
     a.spec = p->is_complex ? p->d_us : p->d_uhat;
     a.spec_stride = p->spec_elems;
     a.normfactor = 1.0;
+    a.mode_factors = p->cb_mode_factors;
     return a;
 }
 
@@ -621,6 +626,7 @@ static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hi
         q.out_stride_c = 0;
         q.out = user_out;
     }
+    q.mult = last ? p->cb_mode_factors : nullptr;      // uniform callback menu: same layout as the caller's array
     if (last) {
         // deconvolution + normalisation fused into the last pass: normfactor / (ϕ̂1 ϕ̂_last) (ϕ̂2 was applied by pass 2)
         q.fa = p->d_invphi[0]; q.ka = (int)K1;
@@ -666,6 +672,7 @@ static int pruned_backward_pass(nufft_plan* p, int c, int dim, const void* user_
         q.out_stride_j = S1;
         q.out_stride_c = S1 * p->Nover[1];
     }
+    q.mult = first ? p->cb_mode_factors : nullptr;
     if (first) { q.fa = p->d_invphi[0]; q.ka = (int)K1; } else { q.fa = p->d_one; q.ka = 1; }
     q.fk = p->d_invphi[dim];
     NUFFT_HIP(launch_fft_lines(p->dtype, ilog2(p->Nover[dim]), false, q, stream));
@@ -982,6 +989,33 @@ int nufft_exec_type1(nufft_plan* p, void* const* uhat_out, const void* const* va
     if ((rc = nufft_spread(p, values_in, stream))) return rc;          // (1) :169-172
     if ((rc = nufft_fft_forward(p, stream))) return rc;                // (2) :174-177
     return nufft_deconvolve_truncate(p, uhat_out, stream);             // (3) :179-185
+}
+
+// Fused callback menu: the two documented uses of NUFFTCallbacks (src/plan.jl:105-143, test/callbacks.jl:17-25)
+// that can cross a C ABI.  The pointers are only read while the call enqueues its kernels.
+namespace {
+struct CallbackScope {
+    nufft_plan* p;
+    CallbackScope(nufft_plan* plan, const nufft_callbacks* cb) : p(plan) {
+        p->cb_point_weights = cb ? cb->point_weights : nullptr;
+        p->cb_mode_factors = cb ? cb->mode_factors : nullptr;
+    }
+    ~CallbackScope() { p->cb_point_weights = nullptr; p->cb_mode_factors = nullptr; }
+};
+}  // namespace
+
+int nufft_exec_type1_cb(nufft_plan* p, void* const* uhat_out, const void* const* values_in, const nufft_callbacks* cb,
+                        void* stream) {
+    if (!p) return fail(NUFFT_ERR_INVALID_ARG, "null plan");
+    CallbackScope scope(p, cb);
+    return nufft_exec_type1(p, uhat_out, values_in, stream);
+}
+
+int nufft_exec_type2_cb(nufft_plan* p, void* const* values_out, const void* const* uhat_in, const nufft_callbacks* cb,
+                        void* stream) {
+    if (!p) return fail(NUFFT_ERR_INVALID_ARG, "null plan");
+    CallbackScope scope(p, cb);
+    return nufft_exec_type2(p, values_out, uhat_in, stream);
 }
 
 int nufft_exec_type2(nufft_plan* p, void* const* values_out, const void* const* uhat_in, void* stream) {

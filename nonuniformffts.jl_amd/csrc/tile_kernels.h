@@ -44,6 +44,7 @@ struct TileArgs {
     const T* vin[kMaxCompPerLaunch];      // spread: values (as reals; complex = interleaved)
     T* vout[kMaxCompPerLaunch];           // interp
     T prefactor;
+    const T* weights;                     // optional real weight per point (nonuniform callback menu), or null
     int evalmode;
     int kernel;                           // NUFFT_KERNEL_*; beta / bop per kernel: see WindowEval
 };
@@ -92,8 +93,10 @@ __device__ __forceinline__ BinSegs bin_segments(int lo, int hi, int N, int blog,
 // registers (the lane's (dimension, j) role per slot never changes).
 //
 // OTHERK = false (the hot instantiations): BackwardsKaiserBessel Direct (sinh form) and every
-// polynomial evaluation (FastApproximation of both Kaiser-Bessel kernels).  OTHERK = true: the
-// remaining kernel x mode combinations of the reference —
+// polynomial evaluation (FastApproximation of both Kaiser-Bessel kernels), no per-point weights.
+// OTHERK = true is the general variant: it adds the remaining kernel x mode combinations of the
+// reference and the per-point weights of the callback menu (the extra code costs the hot kernels
+// 4-12 % when it is merely present, measured) —
 //   KaiserBessel Direct   I0(beta sqrt(1 - y^2))                 src/Kernels/kaiser_bessel.jl:197-210
 //   Gaussian Direct       exp(-((M-1-j+X) dx)^2 / tau)           src/Kernels/gaussian.jl:141-153
 //   Gaussian Fast         fast Gaussian gridding a cs[m] b^(+-m) src/Kernels/gaussian.jl:125-139,155-192
@@ -142,7 +145,7 @@ struct WindowEval {
     static constexpr int L = 2 * M;
     static constexpr int NV = D * L;
     static constexpr int NSLOT = (NV + GS - 1) / GS;
-    static constexpr int NP = OTHERK ? 1 : M + 4;
+    static constexpr int NP = M + 4;
     T cs[NSLOT][NP];
     int dsel[NSLOT], jsel[NSLOT];
     bool has[NSLOT];
@@ -158,14 +161,15 @@ struct WindowEval {
             jsel[s] = kk % L;
             beta_s[s] = a.beta[dsel[s]];
             bop_s[s] = a.bop[dsel[s]];
-            if constexpr (OTHERK) {
-                cs[s][0] = T(0);
-                if (a.kernel == NUFFT_KERNEL_GAUSSIAN) {      // cs[|m|] = exp(-(m dx)^2 / tau), gaussian.jl:81-84
-                    const int m = jsel[s] - (M - 1);
-                    const T xm = T(m < 0 ? -m : m) * beta_s[s];
-                    cs[s][0] = exp(-(xm * xm) / bop_s[s]);
-                }
-            } else if (a.evalmode != NUFFT_EVAL_DIRECT) {
+            const bool poly = a.evalmode != NUFFT_EVAL_DIRECT &&
+                              (!OTHERK || a.kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL || a.kernel == NUFFT_KERNEL_KAISER_BESSEL);
+            if (OTHERK && a.kernel == NUFFT_KERNEL_GAUSSIAN) {
+#pragma unroll
+                for (int c = 0; c < NP; ++c) cs[s][c] = T(0);
+                const int m = jsel[s] - (M - 1);              // cs[|m|] = exp(-(m dx)^2 / tau), gaussian.jl:81-84
+                const T xm = T(m < 0 ? -m : m) * beta_s[s];
+                cs[s][0] = exp(-(xm * xm) / bop_s[s]);
+            } else if (poly) {
 #pragma unroll
                 for (int c = 0; c < NP; ++c) cs[s][c] = a.coefs[(dsel[s] * NP + c) * L + jsel[s]];
             } else {
@@ -181,7 +185,9 @@ struct WindowEval {
         for (int s = 0; s < NSLOT; ++s) {
             const T x = dsel[s] == 0 ? X[0] : (dsel[s] == 1 ? X[1] : X[2]);
             T val;
-            if constexpr (OTHERK) {
+            const bool poly = a.evalmode != NUFFT_EVAL_DIRECT &&
+                              (!OTHERK || a.kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL || a.kernel == NUFFT_KERNEL_KAISER_BESSEL);
+            if (OTHERK && !poly && a.kernel != NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) {
                 const int j = jsel[s];
                 if (a.kernel == NUFFT_KERNEL_KAISER_BESSEL) {
                     const T y = (T(M - 1 - j) + x) / T(M);
@@ -206,7 +212,7 @@ struct WindowEval {
                 } else {
                     val = dev_bspline_value<T, M>(T(1) - x, j);
                 }
-            } else if (a.evalmode == NUFFT_EVAL_DIRECT) {
+            } else if (!poly) {
                 val = bkb_direct<T, M>(x, jsel[s], beta_s[s], bop_s[s]);
             } else {
                 const T xx = T(2) * x - T(1);
@@ -392,7 +398,10 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         // processed, its value right after
         PointRec<T, D> rec = sorted[min(p0 + (uint32_t)grp, p1 - 1)];
         T vcur = T(0);
-        if (q < NC) vcur = vin[(int64_t)rec.idx * NC + q];
+        if (q < NC) {
+            vcur = vin[(int64_t)rec.idx * NC + q];
+            if constexpr (OTHERK) { if (a.weights) vcur *= a.weights[rec.idx]; }   // callbacks.nonuniform(v, n), src/spreading/gpu.jl:289
+        }
         for (uint32_t pc = p0; pc < p1; pc += GP::PPW) {
             const uint32_t p = pc + grp;
             const bool have = p < p1;
@@ -511,7 +520,10 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
             asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(vmine));
 #endif
             }   // okmask != 0
-            if (more && q < NC) vcur = vin[(int64_t)recn.idx * NC + q];
+            if (more && q < NC) {
+                vcur = vin[(int64_t)recn.idx * NC + q];
+                if constexpr (OTHERK) { if (a.weights) vcur *= a.weights[recn.idx]; }
+            }
             rec = recn;
         }
     }
@@ -727,7 +739,11 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
             }
 #endif
             acc = group_sum<T, GP::G, CPLX>(acc);
-            if (have && q < NC) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
+            if (have && q < NC) {
+                T res = acc * a.prefactor;
+                if constexpr (OTHERK) { if (a.weights) res *= a.weights[rec.idx]; }   // callbacks.nonuniform(v, n), src/interpolation/gpu.jl:254
+                vout[(int64_t)rec.idx * NC + q] = res;
+            }
             rec = recn;
         }
     }

@@ -68,7 +68,7 @@ template <typename T>
 static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t stream) {
     bool wrap = false;
     for (int d = 0; d < a.D; ++d) wrap = wrap || a.g.sp.nt[d] == 1;
-    const bool other = needs_other_eval(a.kernel, a.evalmode);
+    const bool other = needs_other_eval(a.kernel, a.evalmode) || a.weights != nullptr;   // general variant
     const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, interp ? (a.fixed_tile != 0 && !other) : wrap, other);
     if (!fn) return hipErrorInvalidValue;
     const int ncr = a.is_complex ? 2 : 1;
@@ -89,6 +89,7 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
             k.vout[c] = a.values_out ? static_cast<T*>(a.values_out[c0 + c]) : nullptr;
         }
         k.prefactor = (T)a.prefactor;
+        k.weights = static_cast<const T*>(a.weights);
         k.evalmode = a.evalmode;
         k.kernel = a.kernel;
         void* params[] = {&k};

@@ -79,15 +79,51 @@ class ROCBackend:
     device: int = 0
 
 
+class PointWeights:
+    """``nonuniform = (v, n) -> v * weights[n]`` (src/plan.jl:112-124): a real device vector ``T[Np]``."""
+
+    def __init__(self, weights: torch.Tensor):
+        self.weights = weights
+
+
+class ModeFactors:
+    """``uniform = (w, idx) -> w * factors[idx]`` (src/plan.jl:126-146): a real device array with the
+    dimensions of one uniform array (``size(p)``; tensor shape = reversed), shared by all components."""
+
+    def __init__(self, factors: torch.Tensor):
+        self.factors = factors
+
+
 class NUFFTCallbacks:
-    """Placeholder for src/plan.jl:146-164.  User closures cannot cross the C ABI
-    (SURVEY.md §7 "hard parts"); only the default (identity) callbacks are accepted."""
+    """``NUFFTCallbacks(; nonuniform, uniform)`` — src/plan.jl:146-164.  Arbitrary closures cannot cross the
+    C ABI (SURVEY.md §7 "hard parts"); the two documented uses are offered as a fixed menu, fused into the
+    spreading / interpolation and deconvolution kernels exactly where the reference calls the closures:
+    ``nonuniform=PointWeights(w)`` and ``uniform=ModeFactors(f)``.  Anything else raises."""
 
     def __init__(self, nonuniform=None, uniform=None):
-        if nonuniform is not None or uniform is not None:
+        if nonuniform is not None and not isinstance(nonuniform, PointWeights):
             raise NotImplementedError(
-                "user callbacks are arbitrary closures and cannot cross the C ABI; "
-                "apply them outside the transform")
+                "user callbacks are arbitrary closures and cannot cross the C ABI; use PointWeights(w) "
+                "or apply the function outside the transform")
+        if uniform is not None and not isinstance(uniform, ModeFactors):
+            raise NotImplementedError(
+                "user callbacks are arbitrary closures and cannot cross the C ABI; use ModeFactors(f) "
+                "or apply the function outside the transform")
+        self.nonuniform = nonuniform
+        self.uniform = uniform
+
+    def _struct(self, p: "PlanNUFFT", npoints: int):
+        cb = _lib.NufftCallbacks()
+        for name, obj, shape in (("point_weights", self.nonuniform and self.nonuniform.weights, (npoints,)),
+                                 ("mode_factors", self.uniform and self.uniform.factors, p.shape)):
+            if obj is None:
+                continue
+            if not isinstance(obj, torch.Tensor) or obj.dtype != p.T or obj.device != p.device or not obj.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous {p.T} tensor on {p.device}")
+            if tuple(obj.shape) != tuple(shape):
+                raise DimensionMismatch(f"{name}: expected tensor shape {tuple(shape)}, got {tuple(obj.shape)}")
+            setattr(cb, name, obj.data_ptr())
+        return cb
 
 
 def transform_point_convention(x):
@@ -467,7 +503,11 @@ def exec_type1(us, p: PlanNUFFT, vp, *, callbacks: Optional[NUFFTCallbacks] = No
     vp_t = (vp,) if isinstance(vp, torch.Tensor) else tuple(vp)
     p._check_uniform(us_t)
     p._check_nonuniform(vp_t, "input values")
-    _check(lib.nufft_exec_type1(p._handle, _ptr_table(us_t), _ptr_table(vp_t), p._stream()))
+    if callbacks is not None and (callbacks.nonuniform is not None or callbacks.uniform is not None):
+        cb = callbacks._struct(p, vp_t[0].numel())
+        _check(lib.nufft_exec_type1_cb(p._handle, _ptr_table(us_t), _ptr_table(vp_t), C.byref(cb), p._stream()))
+    else:
+        _check(lib.nufft_exec_type1(p._handle, _ptr_table(us_t), _ptr_table(vp_t), p._stream()))
     return us
 
 
@@ -479,7 +519,11 @@ def exec_type2(vp, p: PlanNUFFT, us, *, callbacks: Optional[NUFFTCallbacks] = No
     us_t = (us,) if isinstance(us, torch.Tensor) else tuple(us)
     p._check_uniform(us_t)
     p._check_nonuniform(vp_t, "output values")
-    _check(lib.nufft_exec_type2(p._handle, _ptr_table(vp_t), _ptr_table(us_t), p._stream()))
+    if callbacks is not None and (callbacks.nonuniform is not None or callbacks.uniform is not None):
+        cb = callbacks._struct(p, vp_t[0].numel())
+        _check(lib.nufft_exec_type2_cb(p._handle, _ptr_table(vp_t), _ptr_table(us_t), C.byref(cb), p._stream()))
+    else:
+        _check(lib.nufft_exec_type2(p._handle, _ptr_table(vp_t), _ptr_table(us_t), p._stream()))
     return vp
 
 

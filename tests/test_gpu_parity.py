@@ -187,6 +187,68 @@ def test_nfft_plan_interface():
     assert q.size == (24, 24)
 
 
+@pytest.mark.parametrize("Z,Ns,C", [(np.float32, (64, 32, 16), 1), (np.complex64, (64, 32, 16), 1),
+                                    (np.float64, (32, 32, 16), 2), (np.complex128, (40, 24), 1), (np.float64, (128,), 1)])
+def test_callbacks_menu(Z, Ns, C):
+    """test/callbacks.jl:6-66: random per-point weights as the non-uniform callback and 1/k² (0 at k = 0) as
+    the uniform callback; the reference result applies the same functions before / after plain transforms.
+    Same sizes as the reference for the two Float32 cases (Ns = (64, 32, 16), Np = prod(Ns) ÷ 3); the others
+    cover the pruned-FFT path (power-of-two oversampled grid), ntransforms = 2, 2-D and 1-D."""
+    nufft = _nufft()
+    Zt = np.dtype(Z)
+    is_real = Zt.kind == "f"
+    T = np.float32 if Zt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    Np = int(np.prod(Ns)) // 3
+    rng = np.random.default_rng(42)
+    weights = rng.random(Np).astype(T)
+    ks = [(np.fft.rfftfreq(N, 1 / N) if (d == 0 and is_real) else np.fft.fftfreq(N, 1 / N)) for d, N in enumerate(Ns)]
+    k2 = sum(np.reshape(k ** 2, [-1 if e == d else 1 for e in range(len(Ns))][::-1]) for d, k in enumerate(ks))
+    factors = np.where(k2 == 0, 0.0, 1.0 / np.where(k2 == 0, 1.0, k2)).astype(T)     # reversed axes = torch layout
+    xs = [(rng.random(Np) * 2 * np.pi).astype(T) for _ in Ns]
+    vs = [(rng.standard_normal(Np) if is_real else rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Zt)
+          for _ in range(C)]
+    plan = nufft.PlanNUFFT(Zt, Ns, ntransforms=C, backend=nufft.ROCBackend(0))        # default parameters, as the reference
+    dev = plan.device
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
+    nufft.set_points(plan, xd)
+    wd, fd = torch.from_numpy(weights).to(dev), torch.from_numpy(np.ascontiguousarray(factors)).to(dev)
+    assert tuple(fd.shape) == plan.shape
+    cb = nufft.NUFFTCallbacks(nonuniform=nufft.PointWeights(wd), uniform=nufft.ModeFactors(fd))
+    tup = (lambda t: t if C > 1 else t[0])
+
+    # reference: callbacks applied outside plain transforms (test/callbacks.jl:36-47)
+    vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
+    t1_in = tuple(v * wd for v in vd)
+    t1_ref = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    nufft.exec_type1(tup(t1_ref), plan, tup(t1_in))
+    t1_ref = tuple(u * fd for u in t1_ref)
+    t2_in = tuple(u * fd for u in t1_ref)
+    t2_ref = tuple(torch.empty(Np, dtype=plan.Z, device=dev) for _ in range(C))
+    nufft.exec_type2(tup(t2_ref), plan, tup(t2_in))
+    t2_ref = tuple(v * wd for v in t2_ref)
+
+    # fused callbacks
+    ws = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    nufft.exec_type1(tup(ws), plan, tup(vd), callbacks=cb)
+    wp = tuple(torch.empty(Np, dtype=plan.Z, device=dev) for _ in range(C))
+    nufft.exec_type2(tup(wp), plan, tup(ws), callbacks=cb)
+    tol = 1e-5 if T == np.float32 else 1e-12              # `≈` in the reference: rtol = sqrt(eps)
+    for c in range(C):
+        assert _rel(ws[c].cpu().numpy(), t1_ref[c].cpu().numpy()) < tol
+        assert _rel(wp[c].cpu().numpy(), t2_ref[c].cpu().numpy()) < tol
+    # only one of the two, and argument checks
+    only_w = nufft.NUFFTCallbacks(nonuniform=nufft.PointWeights(wd))
+    w2 = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    nufft.exec_type1(tup(w2), plan, tup(vd), callbacks=only_w)
+    plain = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    nufft.exec_type1(tup(plain), plan, tup(t1_in))
+    assert _rel(w2[0].cpu().numpy(), plain[0].cpu().numpy()) < tol
+    with pytest.raises(NotImplementedError):
+        nufft.NUFFTCallbacks(nonuniform=lambda v, n: v)
+    with pytest.raises(nufft.DimensionMismatch):
+        nufft.exec_type1(tup(w2), plan, tup(vd), callbacks=nufft.NUFFTCallbacks(nonuniform=nufft.PointWeights(wd[:-1].contiguous())))
+
+
 @pytest.mark.parametrize("Z,dims,M,sigma,evalmode,C", CASES)
 def test_type1_type2_match_oracle(Z, dims, M, sigma, evalmode, C):
     _check_type1_type2(Z, dims, M, sigma, evalmode, C)
