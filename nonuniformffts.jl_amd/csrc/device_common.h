@@ -132,6 +132,10 @@ struct LdsLayout {
     int tile_bytes, items_bytes, strip_bytes_per_wave, total;
 };
 
+// Work items per tile the kernels aim for: with fewer runs than this (1-D tiles have one or two, a 3-D
+// interpolation tile one per wave) the runs are split so that the 16 waves of a workgroup share the points.
+constexpr int kItemTarget = 64;
+
 constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int tile_elem_bytes, int real_bytes, int D, int M,
                                                    int ncomp, int nwaves, int max_items) {
     LdsLayout l{};

@@ -260,7 +260,8 @@ static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, int real_bytes
         const int64_t rows = padded ? n[d] / b + 1 : n[d] / b + 4;
         items *= std::min<int64_t>(nb, rows);
     }
-    t.max_items = (int)items;
+    // room for splitting long runs into several work items (kItemTarget per tile, see split_work_items)
+    t.max_items = (int)std::max<int64_t>(items, 2 * kItemTarget);
 }
 
 bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,

@@ -269,6 +269,31 @@ struct RowWalker {
     }
 };
 
+// Splits the `nruns` runs of the item table (uint2 = [first, last) of the sorted array) in place into
+// S pieces each, with piece lengths a multiple of `ppw` points (full chunks), so that a tile has about
+// kItemTarget work items for its waves to share.  Returns the new item count.  Must be called by the
+// whole workgroup after the table has been written (contains the barriers it needs).
+__device__ __forceinline__ int split_work_items(uint2* items, int nruns, int max_items, int ppw, int tid) {
+    if (nruns <= 0 || nruns >= kItemTarget) { __syncthreads(); return nruns; }
+    int S = (kItemTarget + nruns - 1) / nruns;
+    if (nruns * S > max_items) S = max_items / nruns;
+    if (S <= 1) { __syncthreads(); return nruns; }
+    __syncthreads();
+    const int total = nruns * S;           // <= 2 * kItemTarget <= workgroup size
+    uint2 run = make_uint2(0u, 0u);
+    if (tid < total) run = items[tid / S];
+    __syncthreads();
+    if (tid < total) {
+        const uint32_t len = run.y - run.x;
+        uint32_t piece = (len + (uint32_t)S - 1) / (uint32_t)S;
+        piece = (piece + (uint32_t)ppw - 1) / (uint32_t)ppw * (uint32_t)ppw;
+        const uint32_t q0 = min(run.y, run.x + (uint32_t)(tid % S) * piece);
+        items[tid] = make_uint2(q0, min(run.y, q0 + piece));
+    }
+    __syncthreads();
+    return total;
+}
+
 __device__ __forceinline__ int wrap_index(int gidx, int N) {
     if (gidx < 0) gidx += N;
     if (gidx >= N) gidx -= N;
@@ -372,8 +397,8 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         else { seg[d].n = 1; seg[d].lo[0] = 0; seg[d].len[0] = 1; seg[d].lo[1] = 0; seg[d].len[1] = 0; }
     }
     const int R2 = seg[1].total(), R3 = seg[2].total();
-    const int nitems = min(R2 * R3 * seg[0].n, ts.max_items);
-    for (int item = tid; item < nitems; item += nthreads) {
+    const int nruns = min(R2 * R3 * seg[0].n, ts.max_items);
+    for (int item = tid; item < nruns; item += nthreads) {
         const int sg = item % seg[0].n;
         const int r2 = (item / seg[0].n) % R2;
         const int r3 = item / (seg[0].n * R2);
@@ -381,7 +406,7 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         items[item] = make_uint2(a.offsets[bin0], a.offsets[bin0 + (sg ? seg[0].len[1] : seg[0].len[0])]);
     }
     if (tid == 0) *next_item = 0;
-    __syncthreads();
+    const int nitems = split_work_items(items, nruns, ts.max_items, GP::PPW, tid);
 
     const PointRec<T, D>* sorted = static_cast<const PointRec<T, D>*>(a.sorted);
     const T* vin = a.vin[comp_id];
@@ -587,7 +612,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         blo[d] = d < D ? org[d] >> g.blog[d] : 0;
         bcnt[d] = d < D ? ((org[d] + neff[d] - 1) >> g.blog[d]) - blo[d] + 1 : 1;
     }
-    const int nitems = min(bcnt[1] * bcnt[2], ts.max_items);
+    const int nruns = min(bcnt[1] * bcnt[2], ts.max_items);
 
     const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves, ts.max_items);
     T* tile = reinterpret_cast<T*>(smem);
@@ -602,7 +627,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         if (tid == 0) *next_item = 0;
         __syncthreads();
         int any = 0;
-        for (int item = tid; item < nitems; item += nthreads) {
+        for (int item = tid; item < nruns; item += nthreads) {
             const int bin0 = ((blo[2] + item / bcnt[1]) * g.nb[1] + blo[1] + item % bcnt[1]) * g.nb[0] + blo[0];
             const uint2 pr = make_uint2(a.offsets[bin0], a.offsets[bin0 + bcnt[0]]);
             items[item] = pr;
@@ -615,6 +640,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         if (!f) return;
         if (tid == 0) *next_item = 0;
     }
+    const int nitems = split_work_items(items, nruns, ts.max_items, GP::PPW, tid);
 
     // load the padded tile with periodic wrap (gridvalues_to_local_memory!, src/interpolation/gpu.jl:331-355)
     const T* grid = a.grid[comp_id];
