@@ -105,6 +105,50 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
     return base + k;
 }
 
+// Contiguous runs of bins that cover the cell interval [lo, hi) of a periodic axis of N cells.
+struct BinSegs {
+    int n;          // number of runs (1 or 2)
+    int lo[2];      // first bin of each run
+    int len[2];     // bins in each run
+    __device__ __forceinline__ int total() const { return len[0] + len[1]; }
+    __device__ __forceinline__ int bin(int r) const { return r < len[0] ? lo[0] + r : lo[1] + (r - len[0]); }
+};
+
+__device__ __forceinline__ BinSegs bin_segments(int lo, int hi, int N, int blog, int nb) {
+    BinSegs s;
+    s.n = 1;
+    s.lo[0] = 0; s.len[0] = nb; s.lo[1] = 0; s.len[1] = 0;
+    if (hi - lo >= N) return s;                       // whole axis
+    if (lo >= 0 && hi <= N) {                         // no wrap
+        s.lo[0] = lo >> blog;
+        s.len[0] = ((hi - 1) >> blog) - s.lo[0] + 1;
+        return s;
+    }
+    // wraps once: [lo', N) and [0, hi')
+    const int lo2 = lo < 0 ? lo + N : lo;
+    const int hi2 = lo < 0 ? hi : hi - N;
+    const int a_first = lo2 >> blog;                  // run A: a_first .. nb-1
+    const int b_last = (hi2 - 1) >> blog;             // run B: 0 .. b_last
+    if (b_last + 1 >= a_first) return s;              // runs touch or overlap: whole axis
+    s.n = 2;
+    s.lo[0] = a_first; s.len[0] = nb - a_first;
+    s.lo[1] = 0;       s.len[1] = b_last + 1;
+    return s;
+}
+
+// Same idea at a finer grain: chunks of `ch` consecutive slots stay together (neighbouring tiles share halo
+// lines in one XCD's L2) but consecutive chunks go to different XCDs, so that a dense region of a
+// non-uniform point set is shared by all XCDs instead of landing in one XCD's contiguous range.
+// Bijective on [0, nblocks); ch = 0 selects xcd_remap.
+__device__ __forceinline__ int xcd_remap_chunked(int b, int nblocks, int ch) {
+    if (ch <= 0) return xcd_remap(b, nblocks);
+    const int group = 8 * ch;
+    const int full = nblocks / group * group;
+    if (b >= full) return b;
+    const int xcd = b & 7, k = b >> 3;
+    return ((k / ch) * 8 + xcd) * ch + k % ch;
+}
+
 // Order LDS traffic of one wave without a workgroup barrier: LDS instructions of a wave complete
 // in issue order; this only stops the compiler from moving accesses across the point.
 __device__ __forceinline__ void wave_lds_fence() {

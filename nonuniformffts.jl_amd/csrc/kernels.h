@@ -28,6 +28,28 @@ size_t point_record_bytes(int dtype, int D);
 hipError_t launch_binsort(const SortArgs& s, hipStream_t stream);
 hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np, int32_t* perm_dev, hipStream_t stream);
 
+// ---- load balance (balance.hip) ----------------------------------------------------------------------
+struct BalanceArgs {
+    Geom g;
+    int D, M;
+    bool enabled;              // false: one slice per tile
+    uint32_t extra_sp, extra_ip;   // budgets of extra slices (= extra workgroups of the launch grids)
+    uint32_t smax;             // most slices of one tile (< 65536)
+    const uint32_t* offsets;   // bin offsets of the sort
+    // arrays over the tiles of both tilings, spreading tiles first
+    uint32_t* work;            // [nsp + nip]
+    uint32_t* nslices;         // [nsp + nip + 1]
+    uint32_t* desc_off;        // [nsp + nip + 1]
+    uint2* desc;               // [nsp + extra_sp + nip + extra_ip]; interpolation slots start at nsp + extra_sp
+    uint32_t* slots_in_use;    // [2]
+    void* scan_tmp;
+    size_t scan_tmp_bytes;
+};
+size_t balance_scan_tmp_bytes(int ntiles_both);
+hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream);
+hipError_t launch_zero_split_tiles(int dtype, const Geom& g, int D, int is_complex, int C, const uint32_t* nslices,
+                                   void* grid, int64_t grid_stride_reals, hipStream_t stream);
+
 // ---- spreading / interpolation (spread_*.hip, interp_*.hip) -------------------------------------
 struct TileKernelArgs {
     int dtype, is_complex, D, M, evalmode, C;
@@ -46,7 +68,10 @@ struct TileKernelArgs {
     const void* weights;       // optional T[np]: real weight per point (nonuniform callback menu), or null
     int threads;
     int lds_bytes;
-    int ntiles;                // workgroups per component
+    int ntiles;                // workgroups per component (tiles + budget of extra slices)
+    const void* desc;          // uint2[ntiles]: slot -> (tile, slice << 16 | slices), see balance.hip
+    const uint32_t* desc_total;    // number of slots in use
+    int xcd_chunk;
     int fixed_tile;            // interp: g.ip equals the compile-time tile (kernel variant with constant strides)
 };
 // Compile-time interpolation tile of an instantiation: n[0..2] cells (n[0] == 0: none), n[3] = LDS row

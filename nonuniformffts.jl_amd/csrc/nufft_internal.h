@@ -128,6 +128,18 @@ struct nufft_plan {
     void* d_sorted = nullptr;          // PointRec<T, D>[Np]
     void* d_scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
+    // load balance (balance.hip): arrays over the tiles of both tilings, spreading tiles first
+    struct Balance {
+        uint32_t extra[2] = {0, 0};        // budget of extra slices = extra workgroups in the launch grids
+        uint32_t* d_work = nullptr;        // [nsp + nip]
+        uint32_t* d_nslices = nullptr;     // [nsp + nip + 1]
+        uint32_t* d_desc_off = nullptr;    // [nsp + nip + 1]
+        void* d_desc = nullptr;            // uint2[nsp + extra_sp + nip + extra_ip]
+        uint32_t* d_slots = nullptr;       // [2] slots in use
+        void* d_tmp = nullptr;
+        size_t tmp_bytes = 0;
+    } bal;
+    bool balance_enabled = true;
     int64_t workspace_bytes = 0;
 
     // pruned FFT path (fft_lines.hip): dimension 1 by rocFFT (1-D batched r2c / c2r), higher dimensions by

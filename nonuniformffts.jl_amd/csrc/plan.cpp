@@ -361,6 +361,21 @@ static int build_device(nufft_plan* p) {
     if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_offsets), nt1 * sizeof(uint32_t)))) return rc;
     p->scan_tmp_bytes = binsort_scan_tmp_bytes((int)p->tile.nbins);
     if ((rc = dev_alloc(p, &p->d_scan_tmp, p->scan_tmp_bytes))) return rc;
+    // load balance: slot tables for tiles + a budget of extra slices (a quarter of the tiles, at least 1024)
+    p->balance_enabled = env_int("NUFFT_BALANCE", 1) != 0;
+    {
+        nufft_plan::Balance& b = p->bal;
+        const int64_t nsp = p->tile.sp.ntiles, nip = p->tile.ip.ntiles;
+        b.extra[0] = p->balance_enabled ? (uint32_t)std::max<int64_t>(1024, nsp / 4) : 0u;
+        b.extra[1] = p->balance_enabled ? (uint32_t)std::max<int64_t>(1024, nip / 4) : 0u;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_work), (size_t)(nsp + nip) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_nslices), (size_t)(nsp + nip + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_desc_off), (size_t)(nsp + nip + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, &b.d_desc, (size_t)(nsp + nip + b.extra[0] + b.extra[1]) * 8))) return rc;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_slots), 2 * sizeof(uint32_t)))) return rc;
+        b.tmp_bytes = balance_scan_tmp_bytes((int)(nsp + nip));
+        if ((rc = dev_alloc(p, &b.d_tmp, b.tmp_bytes))) return rc;
+    }
 
     // rocFFT plans (plan_rfft / plan_brfft / plan_fft! / plan_bfft!, src/plan.jl:45-46,57-58)
     size_t lengths[3] = {1, 1, 1};
@@ -467,6 +482,8 @@ static void release(nufft_plan* p) {
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
         fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
+        fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
+        fr(p->bal.d_slots); fr(p->bal.d_tmp);
         for (int d = 0; d < 3; ++d) { fr(p->d_tw_fw[d]); fr(p->d_tw_bw[d]); fr(p->d_invphi[d]); }
         if (p->fft1_fw) (void)rocfft_plan_destroy(p->fft1_fw);
         if (p->fft1_bw) (void)rocfft_plan_destroy(p->fft1_bw);
@@ -522,7 +539,12 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.fixed_tile = interp && p->interp_fixed;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
-    a.ntiles = (int)(interp ? p->tile.ip.ntiles : p->tile.sp.ntiles);
+    const nufft_plan::Balance& b = p->bal;
+    const int nt = (int)(interp ? p->tile.ip.ntiles : p->tile.sp.ntiles);
+    a.ntiles = nt + (int)b.extra[interp ? 1 : 0];     // launch grid: tiles + budget of extra slices
+    a.desc = static_cast<const char*>(b.d_desc) + (interp ? ((size_t)p->tile.sp.ntiles + b.extra[0]) * 8 : 0);
+    a.desc_total = b.d_slots + (interp ? 1 : 0);
+    a.xcd_chunk = env_int("NUFFT_XCD_CHUNK", 8);
     return a;
 }
 
@@ -849,6 +871,27 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     s.scan_tmp = p->d_scan_tmp;
     s.scan_tmp_bytes = p->scan_tmp_bytes;
     NUFFT_HIP(launch_binsort(s, stream));
+    // slices per tile from the work each tile now holds (balance.hip)
+    {
+        const nufft_plan::Balance& b = p->bal;
+        BalanceArgs q{};
+        q.g = s.g;
+        q.D = p->D;
+        q.M = p->M;
+        q.enabled = p->balance_enabled && np > 0;
+        q.extra_sp = b.extra[0];
+        q.extra_ip = b.extra[1];
+        q.smax = 4096;
+        q.offsets = p->d_offsets;
+        q.work = b.d_work;
+        q.nslices = b.d_nslices;
+        q.desc_off = b.d_desc_off;
+        q.desc = static_cast<uint2*>(b.d_desc);
+        q.slots_in_use = b.d_slots;
+        q.scan_tmp = b.d_tmp;
+        q.scan_tmp_bytes = b.tmp_bytes;
+        NUFFT_HIP(launch_balance(q, stream));
+    }
     p->Np = np;
     return NUFFT_OK;
 }
@@ -874,6 +917,9 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
     StageTimer tm(p, NUFFT_STAGE_T1_SPREAD, stream);
     TileKernelArgs a = tile_args(p, false);
     a.values_in = values_in;
+    if (p->balance_enabled)    // tiles shared by several workgroups accumulate with atomics: zero them first
+        NUFFT_HIP(launch_zero_split_tiles(p->dtype, a.g, p->D, p->is_complex, p->C, p->bal.d_nslices, p->d_us,
+                                          p->grid_elems * (p->is_complex ? 2 : 1), stream));
     NUFFT_HIP(launch_spread(a, stream));
     return NUFFT_OK;
 }

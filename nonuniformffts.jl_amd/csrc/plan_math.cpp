@@ -261,7 +261,7 @@ static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, int real_bytes
         items *= std::min<int64_t>(nb, rows);
     }
     // room for splitting long runs into several work items (kItemTarget per tile, see split_work_items)
-    t.max_items = (int)std::max<int64_t>(items, 2 * kItemTarget);
+    t.max_items = (int)std::min<int64_t>(items + kItemTarget, 4096);
 }
 
 bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,

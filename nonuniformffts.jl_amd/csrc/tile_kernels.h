@@ -45,6 +45,9 @@ struct TileArgs {
     T* vout[kMaxCompPerLaunch];           // interp
     T prefactor;
     const T* weights;                     // optional real weight per point (nonuniform callback menu), or null
+    const uint2* desc;                    // slot -> (tile, slice << 16 | slices of the tile), balance.hip
+    const uint32_t* desc_total;           // slots in use (the launch grid may be larger)
+    int xcd_chunk;                        // slots per XCD chunk (0: one contiguous range per XCD)
     int evalmode;
     int kernel;                           // NUFFT_KERNEL_*; beta / bop per kernel: see WindowEval
 };
@@ -56,37 +59,6 @@ struct Grp {
     static constexpr int G = lanes_per_point(NC, M);    // lanes per point
     static constexpr int PPW = kWave / G;               // points per wave at once
 };
-
-// Contiguous runs of bins that cover the cell interval [lo, hi) of a periodic axis of N cells.
-struct BinSegs {
-    int n;          // number of runs (1 or 2)
-    int lo[2];      // first bin of each run
-    int len[2];     // bins in each run
-    __device__ __forceinline__ int total() const { return len[0] + len[1]; }
-    __device__ __forceinline__ int bin(int r) const { return r < len[0] ? lo[0] + r : lo[1] + (r - len[0]); }
-};
-
-__device__ __forceinline__ BinSegs bin_segments(int lo, int hi, int N, int blog, int nb) {
-    BinSegs s;
-    s.n = 1;
-    s.lo[0] = 0; s.len[0] = nb; s.lo[1] = 0; s.len[1] = 0;
-    if (hi - lo >= N) return s;                       // whole axis
-    if (lo >= 0 && hi <= N) {                         // no wrap
-        s.lo[0] = lo >> blog;
-        s.len[0] = ((hi - 1) >> blog) - s.lo[0] + 1;
-        return s;
-    }
-    // wraps once: [lo', N) and [0, hi')
-    const int lo2 = lo < 0 ? lo + N : lo;
-    const int hi2 = lo < 0 ? hi : hi - N;
-    const int a_first = lo2 >> blog;                  // run A: a_first .. nb-1
-    const int b_last = (hi2 - 1) >> blog;             // run B: 0 .. b_last
-    if (b_last + 1 >= a_first) return s;              // runs touch or overlap: whole axis
-    s.n = 2;
-    s.lo[0] = a_first; s.len[0] = nb - a_first;
-    s.lo[1] = 0;       s.len[1] = b_last + 1;
-    return s;
-}
 
 // Window evaluation of one wave: the G lanes of a group evaluate the D*2M values of their point and
 // exchange them through the wave's LDS strip.  Coefficients of the piecewise polynomial stay in
@@ -270,27 +242,39 @@ struct RowWalker {
 };
 
 // Splits the `nruns` runs of the item table (uint2 = [first, last) of the sorted array) in place into
-// S pieces each, with piece lengths a multiple of `ppw` points (full chunks), so that a tile has about
-// kItemTarget work items for its waves to share.  Returns the new item count.  Must be called by the
-// whole workgroup after the table has been written (contains the barriers it needs).
-__device__ __forceinline__ int split_work_items(uint2* items, int nruns, int max_items, int ppw, int tid) {
-    if (nruns <= 0 || nruns >= kItemTarget) { __syncthreads(); return nruns; }
-    int S = (kItemTarget + nruns - 1) / nruns;
-    if (nruns * S > max_items) S = max_items / nruns;
-    if (S <= 1) { __syncthreads(); return nruns; }
+// work items: every run is cut into c * nslices pieces (c such that a slice has about kItemTarget
+// items; piece lengths a multiple of `ppw` points: full chunks), of which this workgroup — slice `slice`
+// of the `nslices` that share the tile — keeps pieces slice, slice + nslices, ...  Returns the new item
+// count (nruns * c <= max_items).  Must be called by the whole workgroup after the table has been
+// written (it contains the barriers it needs).
+__device__ __forceinline__ int split_work_items(uint2* items, int nruns, int max_items, int ppw, int tid, int nthreads,
+                                                int slice, int nslices) {
     __syncthreads();
-    const int total = nruns * S;           // <= 2 * kItemTarget <= workgroup size
-    uint2 run = make_uint2(0u, 0u);
-    if (tid < total) run = items[tid / S];
-    __syncthreads();
-    if (tid < total) {
-        const uint32_t len = run.y - run.x;
-        uint32_t piece = (len + (uint32_t)S - 1) / (uint32_t)S;
-        piece = (piece + (uint32_t)ppw - 1) / (uint32_t)ppw * (uint32_t)ppw;
-        const uint32_t q0 = min(run.y, run.x + (uint32_t)(tid % S) * piece);
-        items[tid] = make_uint2(q0, min(run.y, q0 + piece));
+    if (nruns <= 0) return 0;
+    int c = nruns >= kItemTarget ? 1 : (kItemTarget + nruns - 1) / nruns;
+    if (nruns * c > max_items) c = max_items / nruns;
+    if (c < 1) c = 1;
+    if (c == 1 && nslices == 1) return nruns;
+    const int total = nruns * c;
+    // In-place expansion from the top: a round of `nthreads` items reads its runs (slots it / c <= it),
+    // then writes slots that no later round reads.
+    for (int hi = total; hi > 0; hi -= nthreads) {
+        const int it = hi - 1 - tid;
+        uint2 run = make_uint2(0u, 0u);
+        if (it >= 0) run = items[it / c];
+        __syncthreads();
+        if (it >= 0) {
+            const uint32_t len = run.y - run.x;
+            const uint32_t pieces = (uint32_t)c * (uint32_t)nslices;
+            uint32_t piece = (len + pieces - 1) / pieces;
+            piece = (piece + (uint32_t)ppw - 1) / (uint32_t)ppw * (uint32_t)ppw;
+            const uint64_t first = (uint64_t)run.x + (uint64_t)((it % c) * nslices + slice) * piece;
+            const uint32_t q0 = first < run.y ? (uint32_t)first : run.y;
+            const uint32_t q1 = (uint64_t)q0 + piece < run.y ? q0 + piece : run.y;
+            items[it] = make_uint2(q0, q1);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     return total;
 }
 
@@ -348,7 +332,11 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     const Geom& g = a.g;
     const TileShape& ts = g.sp;
 
-    const int tile_id = xcd_remap(blockIdx.x, ts.ntiles);
+    // slot -> (tile, slice): heavy tiles are shared by several workgroups (balance.hip)
+    const uint32_t nslots = *a.desc_total;
+    if (blockIdx.x >= nslots) return;
+    const uint2 de = a.desc[xcd_remap_chunked(blockIdx.x, (int)nslots, a.xcd_chunk)];
+    const int tile_id = (int)de.x, slice = (int)(de.y >> 16), nslices = (int)(de.y & 0xffffu);
     const int comp_id = blockIdx.y;
     int t[3];
     tile_coords(tile_id, ts, t);
@@ -406,7 +394,7 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         items[item] = make_uint2(a.offsets[bin0], a.offsets[bin0 + (sg ? seg[0].len[1] : seg[0].len[0])]);
     }
     if (tid == 0) *next_item = 0;
-    const int nitems = split_work_items(items, nruns, ts.max_items, GP::PPW, tid);
+    const int nitems = split_work_items(items, nruns, ts.max_items, GP::PPW, tid, nthreads, slice, nslices);
 
     const PointRec<T, D>* sorted = static_cast<const PointRec<T, D>*>(a.sorted);
     const T* vin = a.vin[comp_id];
@@ -564,7 +552,15 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         if constexpr (D >= 3) rowbase += (int64_t)(org[2] + rw.l3) * g.Nover[1];
         rowbase = (rowbase * g.Nover[0] + org[0]) * NC;
         const A* src = tile + rw.l2 * ts.row_stride + rw.l3 * ts.plane_stride;
-        for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) grid[rowbase + e] = (T)src[e];
+        if (nslices == 1) {
+            for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) grid[rowbase + e] = (T)src[e];
+        } else {
+            // one of several slices of this tile: add the partial tile (interior zeroed by zero_split_tiles_kernel)
+            for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) {
+                const T v = (T)src[e];
+                if (v != T(0)) (void)__hip_atomic_fetch_add(&grid[rowbase + e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -590,7 +586,10 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     const Geom& g = a.g;
     const TileShape& ts = g.ip;
 
-    const int tile_id = xcd_remap(blockIdx.x, ts.ntiles);
+    const uint32_t nslots = *a.desc_total;
+    if (blockIdx.x >= nslots) return;
+    const uint2 de = a.desc[xcd_remap_chunked(blockIdx.x, (int)nslots, a.xcd_chunk)];
+    const int tile_id = (int)de.x, slice = (int)(de.y >> 16), nslices = (int)(de.y & 0xffffu);
     const int comp_id = blockIdx.y;
     int t[3];
     tile_coords(tile_id, ts, t);
@@ -640,7 +639,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         if (!f) return;
         if (tid == 0) *next_item = 0;
     }
-    const int nitems = split_work_items(items, nruns, ts.max_items, GP::PPW, tid);
+    const int nitems = split_work_items(items, nruns, ts.max_items, GP::PPW, tid, nthreads, slice, nslices);
 
     // load the padded tile with periodic wrap (gridvalues_to_local_memory!, src/interpolation/gpu.jl:331-355)
     const T* grid = a.grid[comp_id];

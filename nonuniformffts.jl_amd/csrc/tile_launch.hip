@@ -90,6 +90,9 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         }
         k.prefactor = (T)a.prefactor;
         k.weights = static_cast<const T*>(a.weights);
+        k.desc = static_cast<const uint2*>(a.desc);
+        k.desc_total = a.desc_total;
+        k.xcd_chunk = a.xcd_chunk;
         k.evalmode = a.evalmode;
         k.kernel = a.kernel;
         void* params[] = {&k};

@@ -64,7 +64,10 @@ print(f"plan: Nover={plan.oversampled_dims} bins={[info.bin_dims[d] for d in ran
 g = torch.Generator(device="cuda").manual_seed(42)
 if a.dist == "uniform":
     xs = tuple(torch.rand(Np, dtype=T, device="cuda", generator=g) * (2 * np.pi) for _ in dims)
-else:
+elif a.dist.startswith("cluster"):      # cluster:<sigma in radians>, centred at pi
+    sg = float(a.dist.split(":")[1])
+    xs = tuple(torch.randn(Np, dtype=T, device="cuda", generator=g) * sg + np.pi for _ in dims)
+else:                                   # "randn": the reference's benchmark protocol (folded N(0, 1) coordinates)
     xs = tuple(torch.randn(Np, dtype=T, device="cuda", generator=g) for _ in dims)
 vs = tuple(torch.randn(Np, dtype=Z, device="cuda", generator=g) for _ in range(a.c))
 us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device="cuda") for _ in range(a.c))

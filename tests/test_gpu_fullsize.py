@@ -109,6 +109,51 @@ def test_repeatability_and_reuse(case):
     nufft.set_points(plan, xs)                    # restore for other tests
 
 
+@pytest.mark.parametrize("dist", ["randn", "cluster"])
+def test_nonuniform_distributions_spot_check_and_balance(dist):
+    """Non-uniform point sets (the reference's benchmark draws folded N(0, 1) coordinates,
+    benchmark/CPU+AMDGPU/run_benchmarks.jl:57-66; "cluster": N(pi, 0.1^2), almost every point in a handful of
+    tiles): heavy tiles are shared by several workgroups (balance.hip).  Exact spot checks of type-1 modes, and
+    type 1 / type 2 against a plan that runs without load balancing (NUFFT_BALANCE=0)."""
+    import os
+    from nufft_pkg import nufft
+    Np = 4_000_000
+    g = torch.Generator(device="cuda").manual_seed(77)
+    if dist == "randn":
+        xs = tuple(torch.randn(Np, dtype=torch.float64, device="cuda", generator=g) for _ in range(3))
+    else:
+        xs = tuple(torch.randn(Np, dtype=torch.float64, device="cuda", generator=g) * 0.1 + np.pi for _ in range(3))
+    v = torch.randn(Np, dtype=torch.float64, device="cuda", generator=g)
+    plan = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, backend=nufft.ROCBackend(0))
+    nufft.set_points(plan, xs)
+    u = torch.empty(plan.shape, dtype=torch.complex128, device="cuda")
+    nufft.exec_type1(u, plan, v)
+    k1, k2, k3 = _wavenumbers(plan)
+    rng = np.random.default_rng(5)
+    num = den = 0.0
+    for _ in range(16):
+        i1, i2, i3 = int(rng.integers(0, N // 2 + 1)), int(rng.integers(0, N)), int(rng.integers(0, N))
+        phase = k1[i1] * xs[0] + k2[i2] * xs[1] + k3[i3] * xs[2]
+        exact = torch.complex((v * torch.cos(phase)).sum(), -(v * torch.sin(phase)).sum())
+        num += float((u[i3, i2, i1] - exact).abs() ** 2)
+        den += float(exact.abs() ** 2)
+    assert np.sqrt(num / den) < 2 * CEIL
+    out = torch.empty(Np, dtype=torch.float64, device="cuda")
+    nufft.exec_type2(out, plan, u)
+    os.environ["NUFFT_BALANCE"] = "0"
+    try:
+        plain = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, backend=nufft.ROCBackend(0))
+    finally:
+        del os.environ["NUFFT_BALANCE"]
+    nufft.set_points(plain, xs)
+    u0 = torch.empty_like(u)
+    nufft.exec_type1(u0, plain, v)
+    assert float((u - u0).norm() / u0.norm()) < 1e-12          # same sums, different order of the atomics
+    out0 = torch.empty_like(out)
+    nufft.exec_type2(out0, plain, u)
+    assert float((out - out0).norm() / out0.norm()) < 1e-13
+
+
 def test_config_c3_complexf32_m8_1024_cubed_spot_check():
     """BASELINE config C3 shape: 3-D, Ns = 512^3, ComplexF32, m = 8 (oversampled 1024^3, 8.6 GB grid; LDS pressure).
     Np is reduced to 2e7 to keep the test short; exact spot checks of type-1 modes and type-2 points in Float64.
