@@ -305,7 +305,9 @@ def cpu_baseline(a):
         t = run(Np_s)
         return {"value": Np_s / t, "unit": "NU-points/s", "cores": cores, "kind": "port",
                 "sample": f"one set_points+type-1 transform, same grid ({a.n}^3, sigma={a.sigma}, m={a.m}), "
-                          f"Np={Np_s} of {int(a.np)} points, {t:.1f} s wall; C/OpenMP blocked spreading + scipy pocketfft",
+                          f"Np={Np_s} of {int(a.np)} points, {t:.1f} s wall; C/OpenMP blocked spreading (plain adds under a lock, "
+                          f"the reference's default) + scipy pocketfft; threads = CPUs available to the process "
+                          f"(affinity capped by the cgroup quota: {CO.available_cpus()} of {os.cpu_count()} logical CPUs)",
                 "seconds": t}
     except Exception as exc:  # the baseline is informative only
         return {"value": None, "unit": "NU-points/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}

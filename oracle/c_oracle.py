@@ -34,7 +34,38 @@ def lib():
     return _lib
 
 
+def available_cpus() -> int:
+    """CPUs this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a
+    container that sees 256 logical CPUs may be limited to 16 CPUs' worth of time; more threads than that
+    only add contention)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+_threads_set = False
+
+
 def num_threads() -> int:
+    """Threads the C oracle runs with: OMP_NUM_THREADS if the caller set it, else available_cpus()."""
+    global _threads_set
+    if not _threads_set:
+        if "OMP_NUM_THREADS" not in os.environ:
+            lib().oracle_set_num_threads(available_cpus())
+        _threads_set = True
     return int(lib().oracle_num_threads())
 
 
@@ -47,6 +78,7 @@ def _ptrs(arrs):
 
 def _common(plan: O.OraclePlan):
     assert np.dtype(plan.dtype) == np.float64, "the C oracle is Float64 only"
+    num_threads()                                   # applies the CPU quota once
     D = plan.ndim
     N = (C.c_int64 * 3)(*(list(plan.Nover) + [1] * (3 - D)))
     coefs = np.ascontiguousarray(np.stack([plan.coefs[d] for d in range(D)]))   # [D][npoly][2M]
@@ -86,7 +118,7 @@ def interpolate(plan: O.OraclePlan, us):
 
 
 def _fft_workers():
-    return max(1, os.cpu_count() or 1)
+    return num_threads()
 
 
 def exec_type1(plan: O.OraclePlan, vp):

@@ -158,6 +158,8 @@ int oracle_spread_blocked(int D, const int64_t* N, int M, int evalmode, int ncom
     int64_t P[3];
     for (int d = 0; d < 3; ++d) P[d] = d < D ? b.bd[d] + L : 1;   /* padded block, cpu.jl:54 */
     const size_t pelems = (size_t)(P[0] * P[1] * P[2]) * ncomp;
+    const char* ua = getenv("ORACLE_USE_ATOMICS");
+    const int use_atomics = ua && ua[0] == '1';
 #pragma omp parallel
     {
         double* buf = (double*)malloc(sizeof(double) * pelems);
@@ -199,22 +201,49 @@ int oracle_spread_blocked(int D, const int64_t* N, int M, int evalmode, int ncom
                         }
                     }
                 }
-                /* add_from_block! with periodic wrap, atomics variant (cpu_blocked.jl:170-266) */
+                /* add_from_block! with periodic wrap (cpu_blocked.jl:170-266).  Default of the reference
+                 * (cpu_use_atomics = false, :156-163): plain adds under one lock; ORACLE_USE_ATOMICS=1 selects
+                 * the atomics variant instead. */
                 int64_t o[3];
                 for (int d = 0; d < 3; ++d) o[d] = t[d] * b.bd[d] - M;   /* local index l (0-based) -> global o + l */
-                for (int64_t l3 = 0; l3 < P[2]; ++l3) {
-                    const int64_t g3 = D >= 3 ? wrap(o[2] + l3, g.N[2]) : 0;
-                    for (int64_t l2 = 0; l2 < P[1]; ++l2) {
-                        const int64_t g2 = D >= 2 ? wrap(o[1] + l2, g.N[1]) : 0;
-                        const double* src = buf + ((size_t)(l3 * P[1] + l2) * P[0]) * ncomp;
-                        double* dstrow = u[c] + ((size_t)(g3 * g.N[1] + g2) * g.N[0]) * ncomp;
-                        for (int64_t l1 = 0; l1 < P[0]; ++l1) {
-                            const int64_t g1 = wrap(o[0] + l1, g.N[0]);
-                            for (int k = 0; k < ncomp; ++k) {
-                                const double val = src[l1 * ncomp + k];
-                                if (val != 0.0) {
+                if (use_atomics) {
+                    for (int64_t l3 = 0; l3 < P[2]; ++l3) {
+                        const int64_t g3 = D >= 3 ? wrap(o[2] + l3, g.N[2]) : 0;
+                        for (int64_t l2 = 0; l2 < P[1]; ++l2) {
+                            const int64_t g2 = D >= 2 ? wrap(o[1] + l2, g.N[1]) : 0;
+                            const double* src = buf + ((size_t)(l3 * P[1] + l2) * P[0]) * ncomp;
+                            double* dstrow = u[c] + ((size_t)(g3 * g.N[1] + g2) * g.N[0]) * ncomp;
+                            for (int64_t l1 = 0; l1 < P[0]; ++l1) {
+                                const int64_t g1 = wrap(o[0] + l1, g.N[0]);
+                                for (int k = 0; k < ncomp; ++k) {
+                                    const double val = src[l1 * ncomp + k];
+                                    if (val != 0.0) {
 #pragma omp atomic
-                                    dstrow[g1 * ncomp + k] += val;
+                                        dstrow[g1 * ncomp + k] += val;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else {
+#pragma omp critical(oracle_merge)
+                    {
+                        for (int64_t l3 = 0; l3 < P[2]; ++l3) {
+                            const int64_t g3 = D >= 3 ? wrap(o[2] + l3, g.N[2]) : 0;
+                            for (int64_t l2 = 0; l2 < P[1]; ++l2) {
+                                const int64_t g2 = D >= 2 ? wrap(o[1] + l2, g.N[1]) : 0;
+                                const double* src = buf + ((size_t)(l3 * P[1] + l2) * P[0]) * ncomp;
+                                double* dstrow = u[c] + ((size_t)(g3 * g.N[1] + g2) * g.N[0]) * ncomp;
+                                /* contiguous pieces of the row between wrap points */
+                                int64_t l1 = 0;
+                                while (l1 < P[0]) {
+                                    const int64_t g1 = wrap(o[0] + l1, g.N[0]);
+                                    int64_t len = g.N[0] - g1;
+                                    if (len > P[0] - l1) len = P[0] - l1;
+                                    double* dst = dstrow + g1 * ncomp;
+                                    const double* sp = src + l1 * ncomp;
+                                    for (int64_t e = 0; e < len * ncomp; ++e) dst[e] += sp[e];
+                                    l1 += len;
                                 }
                             }
                         }
@@ -308,6 +337,10 @@ int oracle_interp_blocked(int D, const int64_t* N, int M, int evalmode, int ncom
     }
     free_blocking(&b);
     return 0;
+}
+
+void oracle_set_num_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
 }
 
 int oracle_num_threads(void) {
