@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--evalmode", default="fast", choices=["direct", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="take the multi-process code path (RCCL init, side-stream gather) even with one rank: "
+                         "a single-GPU self-test of the N > 1 path")
     return ap.parse_args()
 
 
@@ -88,7 +91,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or (a.force_distributed and "RANK" in os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
