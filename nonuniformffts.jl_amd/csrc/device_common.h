@@ -294,6 +294,33 @@ __device__ __forceinline__ double dpp_move(double x) {
     return __builtin_bit_cast(double, r);
 }
 
+// Broadcast of lane J (0..15) of every 16-lane row to the whole row: DPP row_newbcast, one VALU instruction
+// also for 64-bit data (v_mov_b64_dpp; the double-precision ALU accepts only this DPP control).
+template <int J>
+__device__ __forceinline__ float row_bcast_c(float x) {
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, false));
+}
+template <int J>
+__device__ __forceinline__ double row_bcast_c(double x) {
+    const long v = __builtin_bit_cast(long, x);
+    return __builtin_bit_cast(double, (long)__builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, false));
+}
+// j must be a compile-time constant after unrolling (the switch folds away)
+template <typename T>
+__device__ __forceinline__ T row_bcast(T x, int j) {
+    switch (j & 15) {
+        case 0: return row_bcast_c<0>(x);   case 1: return row_bcast_c<1>(x);
+        case 2: return row_bcast_c<2>(x);   case 3: return row_bcast_c<3>(x);
+        case 4: return row_bcast_c<4>(x);   case 5: return row_bcast_c<5>(x);
+        case 6: return row_bcast_c<6>(x);   case 7: return row_bcast_c<7>(x);
+        case 8: return row_bcast_c<8>(x);   case 9: return row_bcast_c<9>(x);
+        case 10: return row_bcast_c<10>(x); case 11: return row_bcast_c<11>(x);
+        case 12: return row_bcast_c<12>(x); case 13: return row_bcast_c<13>(x);
+        case 14: return row_bcast_c<14>(x); default: return row_bcast_c<15>(x);
+    }
+}
+
 __device__ __forceinline__ float swap16_add(float x) {
     const int v = __builtin_bit_cast(int, x);
     auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);

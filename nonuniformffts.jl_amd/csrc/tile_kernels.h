@@ -461,9 +461,13 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                 T w3[L];
                 if constexpr (D >= 3) {
 #if NUFFT_W3_READLANE
-                    const T w3l = sp[2 * L + (lane % L)];       // one LDS read, then scalar broadcasts
+                    // one LDS read per 16 window values (lane l of a row holds value l), then DPP row
+                    // broadcasts: one VALU instruction per value instead of two v_readlane_b32
+                    const T w3a = sp[2 * L + min(lane & 15, L - 1)];
+                    T w3b = T(0);
+                    if constexpr (L > 16) w3b = sp[2 * L + min(16 + (lane & 15), L - 1)];
 #pragma unroll
-                    for (int j = 0; j < L; ++j) w3[j] = readlane_t(w3l, j);
+                    for (int j = 0; j < L; ++j) w3[j] = j < 16 ? row_bcast(w3a, j) : row_bcast(w3b, j - 16);
 #else
 #pragma unroll
                     for (int j = 0; j < L; ++j) w3[j] = sp[2 * L + j];
