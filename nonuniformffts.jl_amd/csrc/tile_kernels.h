@@ -29,6 +29,9 @@
 #ifndef NUFFT_W3_READLANE
 #define NUFFT_W3_READLANE 1
 #endif
+#ifndef NUFFT_INTERP_REGW
+#define NUFFT_INTERP_REGW 1         // interpolation: window values exchanged by DPP broadcasts instead of an LDS strip
+#endif
 
 namespace nufft {
 
@@ -153,6 +156,15 @@ struct WindowEval {
 
     // X[d]: cell fraction of this lane's point; strip: this group's NV slots in LDS.
     __device__ __forceinline__ void eval_to_strip(const TileArgs<T>& a, const T (&X)[3], T* strip, int q) const {
+        T v[NSLOT];
+        eval_regs(a, X, v);
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+            if (has[s]) strip[q + s * GS] = v[s];
+    }
+
+    // the same values left in registers: v[s] is window value k = q + s * GS of the lane's point
+    __device__ __forceinline__ void eval_regs(const TileArgs<T>& a, const T (&X)[3], T (&v)[NSLOT]) const {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const T x = dsel[s] == 0 ? X[0] : (dsel[s] == 1 ? X[1] : X[2]);
@@ -192,7 +204,7 @@ struct WindowEval {
 #pragma unroll
                 for (int c = NP - 2; c >= 0; --c) val = fma(xx, val, cs[s][c]);
             }
-            if (has[s]) strip[q + s * GS] = val;
+            v[s] = val;
         }
     }
 };
@@ -731,12 +743,30 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
                 X[d] = rec.r[d] - T(c);
                 s[d] = c - org[d];                 // first stencil node in padded-tile coordinates
             }
-            wave_lds_fence();
+            // Real data with 8 or 16 lanes per point: the window values stay in the registers of the lanes that
+            // evaluated them (value k = d * 2M + j in slot k / G of lane k % G of the group) and reach the
+            // other lanes of the group by DPP row broadcasts — no LDS strip, no LDS waits around it.
+            constexpr bool REGW = NUFFT_INTERP_REGW && !CPLX && D >= 2 && (GP::G == 8 || GP::G == 16);
+            T wv[WindowEval<T, NC, D, M, GP::G, OTHERK>::NSLOT];
+            T w1;
+            if constexpr (REGW) {
+                we.eval_regs(a, X, wv);
+                w1 = wv[0];                                   // NC = 1: lane q < 2M owns w1[q]
+            } else {
+                wave_lds_fence();
 #if !defined(NUFFT_ABL_NO_EVAL)
-            we.eval_to_strip(a, X, strip, q);
+                we.eval_to_strip(a, X, strip, q);
 #endif
-            wave_lds_fence();
-            const T w1 = strip[j1];
+                wave_lds_fence();
+                w1 = strip[j1];
+            }
+            auto wfetch = [&](int d, int j) -> T {           // w_d[j] of this lane's point (d, j constants after unrolling)
+                const int kk = d * L + j;
+                const T x = wv[kk / GP::G];
+                if constexpr (GP::G == 16) return row_bcast(x, kk % GP::G);
+                const T lo = row_bcast(x, kk % GP::G), hi = row_bcast(x, kk % GP::G + 8);
+                return (lane & 8) ? hi : lo;
+            };
 #if defined(NUFFT_ABL_INTERP_SAMEADDR)
             for (int d = 0; d < D; ++d) s[d] = __builtin_amdgcn_readfirstlane(s[d]);
 #endif
@@ -745,7 +775,27 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
 #if defined(NUFFT_ABL_INTERP_NOREAD)
             if (have && lane_active) acc = base[0] * w1;
 #else
-            if (have && lane_active) {
+            if constexpr (REGW) {
+                // every lane runs the loop (the broadcasts need the whole wave); inactive lanes read valid
+                // addresses of the tile (their record repeats the last point) and are masked at the end
+                if constexpr (D == 2) {
+#pragma unroll
+                    for (int j2 = 0; j2 < L; ++j2) acc = fma(base[j2 * RSp], wfetch(1, j2), acc);
+                } else {
+                    T w2[L];
+#pragma unroll
+                    for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
+#pragma unroll
+                    for (int j3 = 0; j3 < L; ++j3) {
+                        const T* plane = base + j3 * PSp;
+                        T t2 = T(0);
+#pragma unroll
+                        for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * RSp], w2[j2], t2);
+                        acc = fma(t2, wfetch(2, j3), acc);
+                    }
+                }
+                acc = (have && lane_active) ? acc * w1 : T(0);
+            } else if (have && lane_active) {
                 if constexpr (D == 1) {
                     acc = base[0];
                 } else if constexpr (D == 2) {
