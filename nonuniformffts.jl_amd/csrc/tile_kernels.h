@@ -23,11 +23,16 @@
 
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "device_common.h"
 #include "nufft_mi355x.h"
 
 #ifndef NUFFT_W3_READLANE
 #define NUFFT_W3_READLANE 1
+#endif
+#ifndef NUFFT_INTERP_ASM_READS
+#define NUFFT_INTERP_ASM_READS 1    // compile-time-tile interpolation: hand-scheduled LDS reads with immediate offsets
 #endif
 #ifndef NUFFT_INTERP_REGW
 #define NUFFT_INTERP_REGW 1         // interpolation: window values exchanged by DPP broadcasts instead of an LDS strip
@@ -580,6 +585,45 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     }
 }
 
+// Hand-scheduled LDS reads for the interpolation gather of the compile-time-tile variant: one base address,
+// immediate offsets (no address arithmetic) and explicit s_waitcnt, written as inline assembly so that the
+// compiler can neither pair them into ds_read2_b64 (whose two addresses share banks at an unaligned row
+// stride) nor serialise them.  The caller keeps at most two planes (2 * 2M reads) in flight.
+template <typename T, int OFF>
+__device__ __forceinline__ void lds_read_imm(T& dst, uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "LDS immediate offset out of range");
+    if constexpr (sizeof(T) == 8) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+    else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <typename T, int R, int FIRST_OFF, int ROW_BYTES, int... J>
+__device__ __forceinline__ void lds_read_rows(T (&b)[R], uint32_t addr, std::integer_sequence<int, J...>) {
+    (lds_read_imm<T, FIRST_OFF + J * ROW_BYTES>(b[J], addr), ...);
+}
+// wait until at most PENDING LDS operations are outstanding; the registers are operands so that their
+// consumers are ordered after the wait
+template <int PENDING, typename T, int R>
+__device__ __forceinline__ void lds_wait_rows(T (&b)[R]) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING));
+#pragma unroll
+    for (int j = 0; j < R; ++j) asm volatile("" : "+v"(b[j]));
+}
+
+// Row groups G, G + 1, ... of R rows each (group g = rows (g % (L / R)) * R ... of plane g / (L / R)):
+// `cur` was requested by the caller; request group G + 1 into `nxt`, wait for `cur`, consume it, swap.
+template <typename T, int L, int R, int PB, int RB, int G, typename F>
+__device__ __forceinline__ void interp_row_groups(T (&cur)[R], T (&nxt)[R], uint32_t baddr, F&& consume) {
+    constexpr int GPP = L / R, NG = L * GPP;
+    if constexpr (G + 1 < NG) {
+        lds_read_rows<T, R, ((G + 1) / GPP) * PB + ((G + 1) % GPP) * R * RB, RB>(nxt, baddr, std::make_integer_sequence<int, R>{});
+        lds_wait_rows<R>(cur);              // the R reads of group G + 1 may still be in flight
+        consume(cur, G);
+        interp_row_groups<T, L, R, PB, RB, G + 1>(nxt, cur, baddr, consume);
+    } else {
+        lds_wait_rows<0>(cur);
+        consume(cur, G);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Interpolation
 // ---------------------------------------------------------------------------------------------
@@ -781,6 +825,30 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
                 if constexpr (D == 2) {
 #pragma unroll
                     for (int j2 = 0; j2 < L; ++j2) acc = fma(base[j2 * RSp], wfetch(1, j2), acc);
+                } else if constexpr (FIXED && NUFFT_INTERP_ASM_READS && L <= 15 &&
+                                     (L - 1) * FD.row_stride * (FD.n[1] + L) * (int)sizeof(T) < 65536) {
+                    T w2[L];
+#pragma unroll
+                    for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
+                    constexpr int RB = FD.row_stride * (int)sizeof(T);
+                    constexpr int PB = FD.row_stride * (FD.n[1] + L - 1) * (int)sizeof(T);
+                    const uint32_t baddr = (uint32_t)(uintptr_t)base;       // LDS byte address of this lane's corner
+                    // software pipeline over groups of R rows, two groups in flight
+                    constexpr int R = 2;                     // 2M is even; larger groups spill registers (measured)
+                    constexpr int GPP = L / R;
+                    T pa[R], pb[R];
+                    lds_read_rows<T, R, 0, RB>(pa, baddr, std::make_integer_sequence<int, R>{});
+                    T t2 = T(0);
+                    auto group_fma = [&](T (&rows)[R], int gidx) {
+                        const int j3 = gidx / GPP, r0 = (gidx % GPP) * R;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) t2 = fma(rows[r], w2[r0 + r], t2);
+                        if (gidx % GPP == GPP - 1) {
+                            acc = fma(t2, wfetch(2, j3), acc);
+                            t2 = T(0);
+                        }
+                    };
+                    interp_row_groups<T, L, R, PB, RB, 0>(pa, pb, baddr, group_fma);
                 } else {
                     T w2[L];
 #pragma unroll
