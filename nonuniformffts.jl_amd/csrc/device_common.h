@@ -230,6 +230,31 @@ constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, in
     return best;
 }
 
+// Compile-time spreading tile (interior only, Float64 accumulation) under the same conditions and with the
+// same cost model as the run-time search (point visits per point); row stride padded for the LDS banks.
+constexpr __host__ __device__ FixedTileDims fixed_spread_tile(int real_bytes, int ncomp, int D, int M) {
+    const int L = 2 * M, halo = L - 1, b = 4, nwaves = 16;
+    const int ppw = kWave / lanes_per_point(ncomp, M);
+    const int strips = nwaves * round_up(ppw * D * L * real_bytes, 16) + 6144;
+    const long avail = (163840 - 256 - strips) / 8;
+    const int cap = D == 1 ? 8192 : 96;
+    FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0};
+    double best_cost = 1e300;
+    for (int n3 = (D >= 3 ? b : 1); n3 <= (D >= 3 ? cap : 1); n3 += b)
+        for (int n2 = (D >= 2 ? b : 1); n2 <= (D >= 2 ? cap : 1); n2 += b)
+            for (int n1 = b; n1 <= cap; n1 += b) {
+                const int rs = D >= 2 ? padded_row_stride(ncomp * n1, ncomp * L, 8) : ncomp * n1;
+                const long elems = (long)rs * (D >= 2 ? n2 : 1) * (D >= 3 ? n3 : 1);
+                if (elems > avail) break;
+                double cost = (double)(n1 + halo) / n1;
+                if (D >= 2) cost *= (double)(n2 + halo) / n2;
+                if (D >= 3) cost *= (double)(n3 + halo) / n3;
+                cost -= 1e-6 * n1;
+                if (cost < best_cost) { best_cost = cost; best.n[0] = n1; best.n[1] = n2; best.n[2] = n3; best.row_stride = rs; }
+            }
+    return best;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Window evaluation (backwards Kaiser-Bessel)
 // ---------------------------------------------------------------------------------------------

@@ -107,6 +107,7 @@ struct nufft_plan {
     std::vector<int64_t> index_map[3];
     nufft::TileGeom tile;
     bool interp_fixed = false;         // tile.ip is the compile-time tile of the kernel instantiation
+    bool spread_fixed = false;         // tile.sp likewise
     int64_t lds_spread = 0, lds_interp = 0;
 
     // device data

@@ -281,6 +281,16 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         if (ok) for (int d = 0; d < 3; ++d) forced_ip[d] = fixed_ip[d];
         else fixed_ip[0] = 0;
     }
+    // the same for the spreading tile (fixed_spread_tile): every edge must leave room for the clipped halo
+    int fixed_sp[4] = {0, 0, 0, 0};
+    if (forced_sp[0] <= 0 && bin_log2 <= 2 && p->spread_threads == 1024 && budget == kLdsLimit - 256 &&
+        env_int("NUFFT_SPREAD_FIXED", 1)) {
+        spread_fixed_dims(p->dtype, p->is_complex, p->D, p->M, fixed_sp);
+        bool ok = fixed_sp[0] > 0;
+        for (int d = 0; d < p->D && ok; ++d) ok = fixed_sp[d] + 2 * p->M - 1 <= p->Nover[d] && fixed_sp[d] < p->Nover[d];
+        if (ok) for (int d = 0; d < 3; ++d) forced_sp[d] = fixed_sp[d];
+        else fixed_sp[0] = 0;
+    }
     // Tile edges are multiples of the bin edge; when even one bin plus halo overflows the LDS (large M,
     // complex Float64) retry with smaller bins down to single cells.
     bool found = false;
@@ -295,6 +305,8 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     p->interp_fixed = fixed_ip[0] > 0;
     for (int d = 0; d < p->D; ++d) p->interp_fixed = p->interp_fixed && p->tile.ip.n[d] == fixed_ip[d];
     p->interp_fixed = p->interp_fixed && p->tile.ip.row_stride == fixed_ip[3];
+    p->spread_fixed = fixed_sp[0] > 0 && p->tile.sp.row_stride == fixed_sp[3];
+    for (int d = 0; d < p->D; ++d) p->spread_fixed = p->spread_fixed && p->tile.sp.n[d] == fixed_sp[d] && p->tile.sp.nt[d] > 1;
     p->lds_spread = lds_layout((int)p->tile.sp.elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64, p->tile.sp.max_items).total;
     p->lds_interp = lds_layout((int)p->tile.ip.elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64, p->tile.ip.max_items).total;
     if (p->lds_spread > kLdsLimit || p->lds_interp > kLdsLimit)
@@ -537,7 +549,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     }
     a.weights = p->cb_point_weights;
     a.threads = interp ? p->interp_threads : p->spread_threads;
-    a.fixed_tile = interp && p->interp_fixed;
+    a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
     const nufft_plan::Balance& b = p->bal;
     const int nt = (int)(interp ? p->tile.ip.ntiles : p->tile.sp.ntiles);

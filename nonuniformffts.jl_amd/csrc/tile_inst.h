@@ -22,6 +22,25 @@ static TileKernelPtr inst() {
     else return nullptr;
 }
 
+#if defined(NUFFT_SPREAD_FIXED_GETTER)
+// spreading with the compile-time tile (default window evaluation, no wrap), where such a tile exists
+template <int D, int M>
+static TileKernelPtr inst_fixed() {
+    constexpr bool ok = fixed_spread_tile((int)sizeof(NUFFT_T), NUFFT_CPLX ? 2 : 1, D, M).n[0] > 0;
+    if constexpr (ok) return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, M, false, false, true>;
+    else return nullptr;
+}
+template <int D>
+static TileKernelPtr pick_m_fixed(int M) {
+    switch (M) {
+        case 2: return inst_fixed<D, 2>();  case 3: return inst_fixed<D, 3>();  case 4: return inst_fixed<D, 4>();
+        case 5: return inst_fixed<D, 5>();  case 6: return inst_fixed<D, 6>();  case 7: return inst_fixed<D, 7>();
+        case 8: return inst_fixed<D, 8>();  case 9: return inst_fixed<D, 9>();  case 10: return inst_fixed<D, 10>();
+        default: return nullptr;
+    }
+}
+#endif
+
 template <int D, bool FLAG, bool OTHER>
 static TileKernelPtr pick_m(int M) {
     switch (M) {
@@ -52,6 +71,21 @@ const void* NUFFT_GETTER(int D, int M, bool flag, bool other) {
     if (flag) return other ? pick_d<true, true>(D, M) : pick_d<true, false>(D, M);
     return other ? pick_d<false, true>(D, M) : pick_d<false, false>(D, M);
 }
+
+#if defined(NUFFT_SPREAD_FIXED_GETTER)
+// kernel with the compile-time spreading tile (or null) and that tile: n[0..2] cells, n[3] = LDS row stride
+const void* NUFFT_SPREAD_FIXED_GETTER(int D, int M, int* n) {
+    const FixedTileDims fd = fixed_spread_tile((int)sizeof(NUFFT_T), NUFFT_CPLX ? 2 : 1, D, M);
+    for (int d = 0; d < 3; ++d) n[d] = fd.n[d];
+    n[3] = fd.row_stride;
+    switch (D) {
+        case 1: return reinterpret_cast<const void*>(pick_m_fixed<1>(M));
+        case 2: return reinterpret_cast<const void*>(pick_m_fixed<2>(M));
+        case 3: return reinterpret_cast<const void*>(pick_m_fixed<3>(M));
+        default: return nullptr;
+    }
+}
+#endif
 
 #if defined(NUFFT_FIXED_DIMS_GETTER)
 void NUFFT_FIXED_DIMS_GETTER(int D, int M, int* n) {

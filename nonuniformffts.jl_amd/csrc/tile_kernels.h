@@ -258,6 +258,18 @@ struct RowWalker {
     }
 };
 
+// L Float64 LDS atomics with immediate offsets J * PLANE_BYTES from one address (values w * w3[J]).
+template <int OFF>
+__device__ __forceinline__ void lds_add_imm(uint32_t addr, double v) {
+    static_assert(OFF >= 0 && OFF < 65536, "LDS immediate offset out of range");
+    asm volatile("ds_add_f64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int L, int PLANE_BYTES, typename T, int... J>
+__device__ __forceinline__ void lds_add_planes(double* p, T w, const T (&w3)[L], std::integer_sequence<int, J...>) {
+    const uint32_t addr = (uint32_t)(uintptr_t)p;
+    (lds_add_imm<J * PLANE_BYTES>(addr, (double)(w * w3[J])), ...);
+}
+
 // Splits the `nruns` runs of the item table (uint2 = [first, last) of the sorted array) in place into
 // work items: every run is cut into c * nslices pieces (c such that a slice has about kItemTarget
 // items; piece lengths a multiple of `ppw` points: full chunks), of which this workgroup — slice `slice`
@@ -331,12 +343,16 @@ __device__ __forceinline__ double readlane_t(double x, int l) {
 // by a scalar branch.  WRAP = some axis is spanned by a single tile (small grids): stencil indices
 // then wrap around that axis instead of being clipped; the hot instantiation (WRAP = false) carries
 // none of that code.
-template <typename T, bool CPLX, int D, int M, bool WRAP, bool OTHERK = false>
+// FIXEDT (only with !WRAP): the tile is the compile-time one of fixed_spread_tile(); the LDS atomics of a point
+// whose planes all lie inside the tile are then issued with immediate offsets from one address.
+template <typename T, bool CPLX, int D, int M, bool WRAP, bool OTHERK = false, bool FIXEDT = false>
 __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
     using GP = Grp<NC, M>;
     using A = double;
+    constexpr FixedTileDims FS = fixed_spread_tile((int)sizeof(T), NC, D, M);
+    static_assert(!FIXEDT || (FS.n[0] > 0 && !WRAP), "no compile-time tile for this instantiation");
     constexpr int FACE = GP::W1 * (D >= 2 ? L : 1);
     constexpr int NPASS = (FACE + kWave - 1) / kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -361,10 +377,13 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     bool wrapd[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        org[d] = t[d] * ts.n[d];
-        neff[d] = min(ts.n[d], g.Nover[d] - org[d]);
+        const int nd = FIXEDT ? FS.n[d] : ts.n[d];
+        org[d] = t[d] * nd;
+        neff[d] = min(nd, g.Nover[d] - org[d]);
         wrapd[d] = WRAP && ts.nt[d] == 1;   // a single tile spans the axis: wrap instead of clip
     }
+    const int RS = FIXEDT ? FS.row_stride : ts.row_stride;
+    const int PS = FIXEDT ? FS.row_stride * FS.n[1] : ts.plane_stride;
 
     const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves, ts.max_items);
     A* tile = reinterpret_cast<A*>(smem);
@@ -514,7 +533,7 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                         if (WRAP && wrapd[1]) { if (l2 < 0) l2 += g.Nover[1]; if (l2 >= g.Nover[1]) l2 -= g.Nover[1]; }
                         lane_ok = lane_ok && (unsigned)l2 < (unsigned)neff[1];
                         w *= sp[L + j2f[ps]];
-                        addr += l2 * ts.row_stride;
+                        addr += l2 * RS;
                     }
                     if constexpr (D <= 2) {
                         if (lane_ok) lds_atomic_add(addr, (A)w);
@@ -526,22 +545,26 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                                     int l3 = S3 + j3;
                                     if (l3 < 0) l3 += g.Nover[2];
                                     if (l3 >= g.Nover[2]) l3 -= g.Nover[2];
-                                    lds_atomic_add(addr + l3 * ts.plane_stride, (A)(w * w3[j3]));
+                                    lds_atomic_add(addr + l3 * PS, (A)(w * w3[j3]));
                                 }
                             } else {
-                                A* pl = addr + (S3 + first3) * ts.plane_stride;
+                                A* pl = addr + (S3 + first3) * PS;
                                 if (planes == (1u << L) - 1u) {      // all planes inside: no per-plane control
+                                    if constexpr (FIXEDT && (L - 1) * FS.row_stride * FS.n[1] * 8 < 65536) {
+                                        lds_add_planes<L, FS.row_stride * FS.n[1] * 8>(pl, w, w3, std::make_integer_sequence<int, L>{});
+                                    } else {
 #pragma unroll
-                                    for (int j3 = 0; j3 < L; ++j3) {
-                                        lds_atomic_add(pl, (A)(w * w3[j3]));
-                                        pl += ts.plane_stride;
+                                        for (int j3 = 0; j3 < L; ++j3) {
+                                            lds_atomic_add(pl, (A)(w * w3[j3]));
+                                            pl += PS;
+                                        }
                                     }
                                 } else {
 #pragma unroll
                                     for (int j3 = 0; j3 < L; ++j3) {
                                         if (planes & (1u << j3)) {
                                             lds_atomic_add(pl, (A)(w * w3[j3]));
-                                            pl += ts.plane_stride;
+                                            pl += PS;
                                         }
                                     }
                                 }
@@ -561,6 +584,8 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
             rec = recn;
         }
     }
+    // the immediate-offset atomics are inline assembly: the compiler does not know that they are in flight
+    if constexpr (FIXEDT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
     // store the finished interior: every grid cell is written exactly once (no zero fill needed)
@@ -572,7 +597,7 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         if constexpr (D >= 2) rowbase = org[1] + rw.l2;
         if constexpr (D >= 3) rowbase += (int64_t)(org[2] + rw.l3) * g.Nover[1];
         rowbase = (rowbase * g.Nover[0] + org[0]) * NC;
-        const A* src = tile + rw.l2 * ts.row_stride + rw.l3 * ts.plane_stride;
+        const A* src = tile + rw.l2 * RS + rw.l3 * PS;
         if (nslices == 1) {
             for (int e = rw.lane_in_row; e < w_row; e += rw.lanes_per_row) grid[rowbase + e] = (T)src[e];
         } else {

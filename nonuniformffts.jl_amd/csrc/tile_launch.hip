@@ -15,6 +15,10 @@ const void* interp_kernel_f32c(int D, int M, bool flag, bool other);
 const void* interp_kernel_f64r(int D, int M, bool flag, bool other);
 const void* interp_kernel_f64c(int D, int M, bool flag, bool other);
 
+const void* spread_fixed_f32r(int D, int M, int* n);
+const void* spread_fixed_f32c(int D, int M, int* n);
+const void* spread_fixed_f64r(int D, int M, int* n);
+const void* spread_fixed_f64c(int D, int M, int* n);
 void interp_fixed_dims_f32r(int D, int M, int* n);
 void interp_fixed_dims_f32c(int D, int M, int* n);
 void interp_fixed_dims_f64r(int D, int M, int* n);
@@ -26,6 +30,15 @@ void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n) {
     if (dtype == NUFFT_F32) is_complex ? interp_fixed_dims_f32c(D, M, n) : interp_fixed_dims_f32r(D, M, n);
     else is_complex ? interp_fixed_dims_f64c(D, M, n) : interp_fixed_dims_f64r(D, M, n);
 }
+
+// Kernel with the compile-time spreading tile (null: none) and the tile itself (n[0..2], n[3] = row stride).
+const void* spread_fixed_kernel(int dtype, int is_complex, int D, int M, int* n) {
+    n[0] = n[1] = n[2] = n[3] = 0;
+    if (M < 2 || M > 10 || D < 1 || D > 3) return nullptr;
+    if (dtype == NUFFT_F32) return is_complex ? spread_fixed_f32c(D, M, n) : spread_fixed_f32r(D, M, n);
+    return is_complex ? spread_fixed_f64c(D, M, n) : spread_fixed_f64r(D, M, n);
+}
+void spread_fixed_dims(int dtype, int is_complex, int D, int M, int* n) { (void)spread_fixed_kernel(dtype, is_complex, D, M, n); }
 
 // `flag`: spreading = single-tile axis (wrap variant); interpolation = compile-time tile.
 // `other`: window evaluation of the non-default kernels (see needs_other_eval).
@@ -54,6 +67,14 @@ static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, 
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
+    if (!interp && !other) {
+        int n[4];
+        const void* fn = spread_fixed_kernel(dtype, is_complex, D, M, n);
+        if (fn) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+    }
     return hipSuccess;
 }
 
@@ -70,6 +91,11 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
     for (int d = 0; d < a.D; ++d) wrap = wrap || a.g.sp.nt[d] == 1;
     const bool other = needs_other_eval(a.kernel, a.evalmode) || a.weights != nullptr;   // general variant
     const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, interp ? (a.fixed_tile != 0 && !other) : wrap, other);
+    if (!interp && a.fixed_tile != 0 && !other && !wrap) {
+        int n[4];
+        const void* ff = spread_fixed_kernel(a.dtype, a.is_complex, a.D, a.M, n);
+        if (ff) fn = ff;
+    }
     if (!fn) return hipErrorInvalidValue;
     const int ncr = a.is_complex ? 2 : 1;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
