@@ -5,6 +5,7 @@
 
 #include "nufft_mi355x.h"
 #include <cstdint>
+#include <utility>
 
 namespace nufft {
 
@@ -331,18 +332,40 @@ __device__ __forceinline__ double row_bcast_c(double x) {
     const long v = __builtin_bit_cast(long, x);
     return __builtin_bit_cast(double, (long)__builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, false));
 }
+// The same as inline assembly with a separate destination: the builtin ties the destination to its `old`
+// operand, which costs a register copy per broadcast.  A DPP instruction must not read a VGPR written by
+// a VALU instruction in the two preceding wait states; the compiler's hazard recogniser does not look into
+// inline assembly, hence the s_nop (two wait states of the issuing wave only).
+template <int J>
+__device__ __forceinline__ float row_bcast_asm(float x) {
+    float r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(J));
+    return r;
+}
+template <int J>
+__device__ __forceinline__ double row_bcast_asm(double x) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(J));
+    return r;
+}
+// all values 0 .. N-1 (N <= 16) of a row into w[], N instructions
+template <typename T, int N, int... J>
+__device__ __forceinline__ void row_bcast_all(T x, T (&w)[N], int base, std::integer_sequence<int, J...>) {
+    ((w[base + J] = row_bcast_asm<J>(x)), ...);
+}
+
 // j must be a compile-time constant after unrolling (the switch folds away)
 template <typename T>
 __device__ __forceinline__ T row_bcast(T x, int j) {
     switch (j & 15) {
-        case 0: return row_bcast_c<0>(x);   case 1: return row_bcast_c<1>(x);
-        case 2: return row_bcast_c<2>(x);   case 3: return row_bcast_c<3>(x);
-        case 4: return row_bcast_c<4>(x);   case 5: return row_bcast_c<5>(x);
-        case 6: return row_bcast_c<6>(x);   case 7: return row_bcast_c<7>(x);
-        case 8: return row_bcast_c<8>(x);   case 9: return row_bcast_c<9>(x);
-        case 10: return row_bcast_c<10>(x); case 11: return row_bcast_c<11>(x);
-        case 12: return row_bcast_c<12>(x); case 13: return row_bcast_c<13>(x);
-        case 14: return row_bcast_c<14>(x); default: return row_bcast_c<15>(x);
+        case 0: return row_bcast_asm<0>(x);   case 1: return row_bcast_asm<1>(x);
+        case 2: return row_bcast_asm<2>(x);   case 3: return row_bcast_asm<3>(x);
+        case 4: return row_bcast_asm<4>(x);   case 5: return row_bcast_asm<5>(x);
+        case 6: return row_bcast_asm<6>(x);   case 7: return row_bcast_asm<7>(x);
+        case 8: return row_bcast_asm<8>(x);   case 9: return row_bcast_asm<9>(x);
+        case 10: return row_bcast_asm<10>(x); case 11: return row_bcast_asm<11>(x);
+        case 12: return row_bcast_asm<12>(x); case 13: return row_bcast_asm<13>(x);
+        case 14: return row_bcast_asm<14>(x); default: return row_bcast_asm<15>(x);
     }
 }
 

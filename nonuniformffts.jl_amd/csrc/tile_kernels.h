@@ -502,8 +502,12 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                     const T w3a = sp[2 * L + min(lane & 15, L - 1)];
                     T w3b = T(0);
                     if constexpr (L > 16) w3b = sp[2 * L + min(16 + (lane & 15), L - 1)];
+                    if constexpr (L <= 16) {
+                        row_bcast_all(w3a, w3, 0, std::make_integer_sequence<int, L>{});
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < L; ++j) w3[j] = j < 16 ? row_bcast(w3a, j) : row_bcast(w3b, j - 16);
+                        for (int j = 0; j < L; ++j) w3[j] = j < 16 ? row_bcast(w3a, j) : row_bcast(w3b, j - 16);
+                    }
 #else
 #pragma unroll
                     for (int j = 0; j < L; ++j) w3[j] = sp[2 * L + j];
