@@ -362,7 +362,10 @@ static hipError_t launch_logn_m(const FftLineArgs& a, hipStream_t stream) {
     constexpr int N = 1 << LOGN;
     constexpr int LINE = N + (N >> 4) + 1;
     // TA lines per workgroup: 16 when they fit in ~150 KB of LDS, else 8 / 4
-    constexpr int TA = (sizeof(C) * (16 * LINE + N) <= 150 * 1024) ? 16 : ((sizeof(C) * (8 * LINE + N) <= 150 * 1024) ? 8 : 4);
+#ifndef NUFFT_FFT_LDS_LIMIT
+#define NUFFT_FFT_LDS_LIMIT (80 * 1024)      // two workgroups per CU (70 KB at N = 512 Float64) beat one with 16 lines: measured
+#endif
+    constexpr int TA = (sizeof(C) * (16 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 16 : ((sizeof(C) * (8 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 8 : 4);
     const size_t lds = sizeof(C) * (size_t)(TA * LINE + N);
     auto fn = fft_lines_kernel<T, LOGN, FWD, TA, MULT>;
     static bool prepared = false;
