@@ -1,0 +1,72 @@
+"""Plan lifetime, stream and reuse behaviour of the HIP path (no reference counterpart: the reference relies on
+Julia's GC and KernelAbstractions streams; these are the conventions INTEGRATION.md promises the Julia shim)."""
+import gc
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _case(nufft, Z=torch.float64, dims=(48, 40, 36), Np=30000, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    xs = tuple(torch.rand(Np, dtype=torch.float64, device="cuda", generator=g) * (2 * np.pi) for _ in dims)
+    v = torch.randn(Np, dtype=torch.float64, device="cuda", generator=g)
+    return xs, v
+
+
+def test_plan_destroy_returns_device_memory():
+    from nufft_pkg import nufft
+    torch.cuda.synchronize()
+    xs, v = _case(nufft)
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        p = nufft.PlanNUFFT(torch.float64, (128, 128, 128), backend=nufft.ROCBackend(0))
+        nufft.set_points(p, tuple(x[:1000].contiguous() for x in xs))
+        assert p.info().workspace_bytes > 128 ** 3 * 8
+        del p
+        gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20          # 12 plans of ~0.3 GB each would show if the handle leaked
+
+
+def test_side_stream_and_interleaved_plans():
+    """All work is enqueued on the stream current at call time; two plans with different parameters can be
+    used alternately; a plan can take a larger and then a smaller point set."""
+    from nufft_pkg import nufft
+    dims = (48, 40, 36)
+    xs, v = _case(nufft, dims=dims)
+    pa = nufft.PlanNUFFT(torch.float64, dims, m=4, backend=nufft.ROCBackend(0))
+    pb = nufft.PlanNUFFT(torch.float64, dims, m=6, sigma=1.5, kernel=nufft.KaiserBesselKernel(), backend=nufft.ROCBackend(0))
+    ua = torch.empty(pa.shape, dtype=torch.complex128, device="cuda")
+    ub = torch.empty(pb.shape, dtype=torch.complex128, device="cuda")
+    nufft.set_points(pa, xs); nufft.set_points(pb, xs)
+    nufft.exec_type1(ua, pa, v); nufft.exec_type1(ub, pb, v)
+    torch.cuda.synchronize()
+    ref_a, ref_b = ua.clone(), ub.clone()
+    assert float((ua - ub).norm() / ua.norm()) < 1e-6          # same transform, two accuracies
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ua.zero_(); ub.zero_()
+        nufft.set_points(pb, xs)
+        nufft.exec_type1(ub, pb, v)
+        nufft.set_points(pa, xs)
+        nufft.exec_type1(ua, pa, v)
+    side.synchronize()
+    assert float((ua - ref_a).norm() / ref_a.norm()) < 1e-12
+    assert float((ub - ref_b).norm() / ref_b.norm()) < 1e-12
+    # grow, then shrink the point set of one plan
+    g = torch.Generator(device="cuda").manual_seed(5)
+    big = tuple(torch.rand(200000, dtype=torch.float64, device="cuda", generator=g) * (2 * np.pi) for _ in dims)
+    vb = torch.randn(200000, dtype=torch.float64, device="cuda", generator=g)
+    nufft.set_points(pa, big)
+    nufft.exec_type1(ua, pa, vb)
+    k = torch.tensor([3.0, -2.0, 5.0], dtype=torch.float64, device="cuda")
+    exact = (vb * torch.polar(torch.ones_like(vb), -(k[0] * big[0] + k[1] * big[1] + k[2] * big[2]))).sum()
+    assert float((ua[5, 38, 3] - exact).abs() / exact.abs()) < 1e-6
+    nufft.set_points(pa, xs)
+    nufft.exec_type1(ua, pa, v)
+    assert float((ua - ref_a).norm() / ref_a.norm()) < 1e-12
