@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import nufft_oracle as O  # noqa: E402
 
 
-def make(name, dims, Z, M, sigma, evalmode, Np, seed, ntransforms=1, special_points=None):
+def make(name, dims, Z, M, sigma, evalmode, Np, seed, ntransforms=1, special_points=None, kernel=O.KERNEL_BKB):
     Z = np.dtype(Z)
     is_real = Z.kind == "f"
     T = np.float32 if Z in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
@@ -31,7 +31,8 @@ def make(name, dims, Z, M, sigma, evalmode, Np, seed, ntransforms=1, special_poi
         vs = [rng.standard_normal(Np).astype(Z) for _ in range(ntransforms)]
     else:
         vs = [(rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Z) for _ in range(ntransforms)]
-    plan = O.OraclePlan(dims, is_real=is_real, dtype=T, M=M, sigma=sigma, evalmode=evalmode, ntransforms=ntransforms)
+    plan = O.OraclePlan(dims, is_real=is_real, dtype=T, M=M, sigma=sigma, evalmode=evalmode, ntransforms=ntransforms,
+                        kernel=kernel)
     O.set_points(plan, xs)
     shape = tuple(reversed(plan.size))
     ws = [(rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(plan.cdtype) for _ in range(ntransforms)]
@@ -43,7 +44,7 @@ def make(name, dims, Z, M, sigma, evalmode, Np, seed, ntransforms=1, special_poi
     exact1 = [O.nudft_type1(plan.ks, x64, v) for v in vs]
     exact2 = [O.nudft_type2_real(plan, x64, w) if is_real else O.nudft_type2(plan.ks, x64, w) for w in ws]
     out = dict(dims=np.array(dims), M=M, sigma=sigma, evalmode=evalmode, is_real=is_real, ntransforms=ntransforms,
-               dtype=str(Z), nover=np.array(plan.Nover))
+               dtype=str(Z), nover=np.array(plan.Nover), kernel=kernel)
     for d, x in enumerate(xs):
         out[f"x{d}"] = x
     for c in range(ntransforms):
@@ -72,3 +73,12 @@ if __name__ == "__main__":
     make("tiny3d_f64_nt3", (12, 16, 10), np.float64, 4, 2.0, O.DIRECT, 400, seed=5, ntransforms=3)
     make("small2d_c128_m6", (20, 27), np.complex128, 6, 2.0, O.DIRECT, 600, seed=6, special_points=edge)
     make("small1d_c128_m8", (32,), np.complex128, 8, 1.5, O.FAST_APPROXIMATION, 64, seed=7, special_points=edge)
+    # the other spreading kernels
+    make("kb_3d_f64_m4", (12, 16, 10), np.float64, 4, 2.0, O.DIRECT, 400, seed=8, kernel=O.KERNEL_KB, special_points=edge)
+    make("kb_2d_c64_m4_fast", (20, 27), np.complex64, 4, 2.0, O.FAST_APPROXIMATION, 400, seed=9, kernel=O.KERNEL_KB)
+    make("gaussian_3d_f64_m6", (12, 16, 10), np.float64, 6, 2.0, O.FAST_APPROXIMATION, 400, seed=10, kernel=O.KERNEL_GAUSSIAN,
+         special_points=edge)
+    make("gaussian_1d_c128_m8_direct", (64,), np.complex128, 8, 2.0, O.DIRECT, 200, seed=11, kernel=O.KERNEL_GAUSSIAN)
+    make("bspline_3d_f64_m6", (12, 16, 10), np.float64, 6, 2.0, O.DIRECT, 400, seed=12, kernel=O.KERNEL_BSPLINE,
+         special_points=edge)
+    make("bspline_2d_f32_m4", (20, 27), np.float32, 4, 2.0, O.FAST_APPROXIMATION, 400, seed=13, kernel=O.KERNEL_BSPLINE)
