@@ -262,8 +262,32 @@ constexpr __host__ __device__ FixedTileDims fixed_spread_tile(int real_bytes, in
 
 // Direct: reference src/Kernels/kaiser_bessel_backwards.jl:158-175.
 // j is 0-based (reference j = 1..2M), X ∈ [0, 1].
+// exp(x) for 0 <= x < 700 without the library's special-case handling: x = k ln2 + r, |r| <= ln2 / 2,
+// exp(r) = (exp(r / 2))^2 with a degree-11 Taylor polynomial of exp(r / 2) (|r / 2| <= 0.174: truncation
+// 2e-18), scaled by 2^k.  Relative error ~2e-16.  Float: the library exp.
+__device__ __forceinline__ double exp_pos(double x) {
+    const double k = rint(x * 1.4426950408889634074);              // log2(e)
+    double r = fma(k, -6.93147180369123816490e-01, x);              // ln2 high part
+    r = fma(k, -1.90821492927058770002e-10, r);                     // ln2 low part
+    const double h = 0.5 * r;
+    double p = 1.0 / 39916800.0;
+    p = fma(p, h, 1.0 / 3628800.0);
+    p = fma(p, h, 1.0 / 362880.0);
+    p = fma(p, h, 1.0 / 40320.0);
+    p = fma(p, h, 1.0 / 5040.0);
+    p = fma(p, h, 1.0 / 720.0);
+    p = fma(p, h, 1.0 / 120.0);
+    p = fma(p, h, 1.0 / 24.0);
+    p = fma(p, h, 1.0 / 6.0);
+    p = fma(p, h, 0.5);
+    p = fma(p, h, 1.0);
+    p = fma(p, h, 1.0);
+    return ldexp(p * p, (int)k);
+}
+__device__ __forceinline__ float exp_pos(float x) { return exp(x); }
+
 // sinh(x) / x for x >= 0 without the library sinh (ocml's double sinh costs ~2x the whole rest of the
-// evaluation): one exp and one reciprocal above 0.5, the even Taylor series below (no cancellation).
+// evaluation): one exp and one division above 0.5, the even Taylor series below (no cancellation).
 template <typename T>
 __device__ __forceinline__ T sinh_over_x(T x) {
     if (x < T(0.5)) {
@@ -277,8 +301,8 @@ __device__ __forceinline__ T sinh_over_x(T x) {
         p = fma(p, z, T(1.0 / 6.0));                          // 1/3!
         return fma(p, z, T(1));
     }
-    const T e = exp(x);
-    return T(0.5) * (e - T(1) / e) / x;
+    const T e = exp_pos(x);
+    return T(0.5) * fma(e, e, T(-1)) / (e * x);               // (e - 1/e) / (2x) with a single division
 }
 
 template <typename T, int M>
