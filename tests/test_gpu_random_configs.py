@@ -1,0 +1,97 @@
+"""Seeded random differential test: HIP path vs oracle over randomly drawn plan configurations (dimensions,
+sizes incl. primes and sizes smaller than a tile, M, sigma, kernel, evaluation mode, element type, ntransforms,
+fftshift, point distribution).  Complements the hand-picked matrix of tests/test_gpu_parity.py, which mirrors
+test/pseudo_gpu.jl."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import nufft_oracle as O  # noqa: E402
+
+KERNELS = [(O.KERNEL_BKB, "BackwardsKaiserBesselKernel"), (O.KERNEL_KB, "KaiserBesselKernel"),
+           (O.KERNEL_GAUSSIAN, "GaussianKernel"), (O.KERNEL_BSPLINE, "BSplineKernel")]
+
+
+def _draw(rng):
+    D = int(rng.integers(1, 4))
+    M = int(rng.integers(2, 11))
+    sigma = float(rng.choice([1.25, 1.5, 2.0, 2.0]))
+    hi = {1: 400, 2: 70, 3: 28}[D]
+    dims = tuple(int(rng.integers(max(2, int(np.ceil(2 * M / sigma))), hi)) for _ in range(D))
+    Z = [np.float64, np.complex128, np.float32, np.complex64][int(rng.integers(0, 4))]
+    kid, kname = KERNELS[int(rng.integers(0, 4))]
+    if kid in (O.KERNEL_GAUSSIAN, O.KERNEL_BSPLINE):
+        sigma = 2.0       # as in the reference's tests (test/accuracy.jl:51-76): at small sigma 1 / phi_hat spans 5 decades
+    mode = int(rng.integers(0, 2))
+    C = int(rng.choice([1, 1, 2, 3]))
+    fftshift = bool(rng.integers(0, 2))
+    dist = ["uniform", "cluster", "edges"][int(rng.integers(0, 3))]
+    return D, M, sigma, dims, Z, kid, kname, mode, C, fftshift, dist
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(seed):
+    from nufft_pkg import nufft
+    rng = np.random.default_rng(1000 + seed)
+    D, M, sigma, dims, Z, kid, kname, mode, C, fftshift, dist = _draw(rng)
+    Zt = np.dtype(Z)
+    is_real = Zt.kind == "f"
+    T = np.float32 if Zt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    # Float32 plans are checked against the Float32 oracle (same fold arithmetic: a point at a multiple of 2 pi may
+    # land on either side of the periodic boundary in Float32, which matters at the window-truncation level,
+    # 1e-2 at M = 2) unless its un-normalised windows overflow (D * M >= 21): then against the Float64 oracle.
+    big_window = kid in (O.KERNEL_BKB, O.KERNEL_KB)
+    To = np.float64 if (T == np.float64 or (big_window and D * M >= 21)) else np.float32
+    try:
+        oplan64 = O.OraclePlan(dims, is_real=is_real, dtype=To, M=M, sigma=sigma, evalmode=mode, ntransforms=C,
+                               kernel=kid, fftshift=fftshift)
+    except ValueError:
+        pytest.skip("oversampled size below 2M")
+    Np = int(rng.integers(1, 3000))
+    if dist == "uniform":
+        xs = [(rng.random(Np) * 3 - 1) * O.TWO_PI for _ in dims]
+    elif dist == "cluster":
+        xs = [rng.standard_normal(Np) * 0.05 + rng.random() * O.TWO_PI for _ in dims]
+    else:
+        edge = np.array([0.0, np.nextafter(O.TWO_PI, 0), O.TWO_PI, -1e-300, np.pi, 3 * O.TWO_PI])
+        xs = [rng.choice(edge, Np) for _ in dims]
+    xs = [x.astype(T) for x in xs]
+    vs = [(rng.standard_normal(Np) if is_real else rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Zt)
+          for _ in range(C)]
+    plan = nufft.PlanNUFFT(Zt, dims, m=M, sigma=sigma, ntransforms=C, kernel=getattr(nufft, kname)(), fftshift=fftshift,
+                           kernel_evalmode=nufft.Direct() if mode == O.DIRECT else nufft.FastApproximation(),
+                           backend=nufft.ROCBackend(0))
+    assert plan.oversampled_dims == oplan64.Nover
+    O.set_points(oplan64, [x.astype(To) for x in xs])
+    dev = plan.device
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
+    nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+    cT = np.complex128 if To == np.float64 else np.complex64
+    v64 = [v.astype(cT if not is_real else To) for v in vs]
+    ref = O.exec_type1(oplan64, v64 if C > 1 else v64[0])
+    ref = ref if C > 1 else [ref]
+    # Float64: 1e-7; Float32 vs Float32 oracle: 1e-5 of test/pseudo_gpu.jl:159-171 times a few (sums of up to 3000
+    # Float32 terms in different orders); Float32 vs Float64 oracle: coordinate rounding enters the phase
+    tol = 1e-7 if T == np.float64 else (5e-5 if To == np.float32 else 3e-4)
+    if dist == "edges" and T == np.float32 and To == np.float64:
+        pytest.skip("boundary points in Float32 against the Float64 oracle: either side of the period is valid")
+    for c in range(C):
+        denom = np.linalg.norm(ref[c].ravel())
+        err = np.linalg.norm((us[c].cpu().numpy() - ref[c]).ravel())
+        assert err <= tol * max(denom, 1e-30), (dims, M, sigma, kname, mode, Zt, dist)
+    ws = [(rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)).astype(np.complex64 if T == np.float32 else np.complex128)
+          for _ in range(C)]
+    out = tuple(torch.empty(Np, dtype=plan.Z, device=dev) for _ in range(C))
+    wd = tuple(torch.from_numpy(w).to(dev) for w in ws)
+    nufft.exec_type2(out if C > 1 else out[0], plan, wd if C > 1 else wd[0])
+    w64 = [w.astype(cT) for w in ws]
+    ref2 = O.exec_type2(oplan64, w64 if C > 1 else w64[0])
+    ref2 = ref2 if C > 1 else [ref2]
+    for c in range(C):
+        denom = np.linalg.norm(np.asarray(ref2[c]).ravel())
+        err = np.linalg.norm((out[c].cpu().numpy() - ref2[c]).ravel())
+        assert err <= tol * max(denom, 1e-30), (dims, M, sigma, kname, mode, Zt, dist)
