@@ -1,4 +1,4 @@
-// Pruned 1-D FFT passes over strided lines (power-of-two lengths), fused with deconvolution.
+// Pruned 1-D FFT passes over strided lines (lengths 2^a, 1.5 * 2^a, 1.25 * 2^a), fused with deconvolution.
 //
 // exec_type1! needs only N_d of the Ñ_d modes of the oversampled spectrum (N_d ≈ Ñ_d / σ), exec_type2!
 // feeds a spectrum that is zero outside those modes.  The reference runs the dense multi-dimensional FFT
@@ -19,7 +19,7 @@
 //
 // One workgroup transforms TA consecutive lines (consecutive in the contiguous index `a`), one wave per line:
 // global accesses are TA * 16-byte segments, the lines sit in LDS, each wave runs an in-place Stockham FFT
-// (radix 8, then 4 or 2) on its own line with twiddles from an LDS table.
+// (radix 8, then 4 or 2, then 3 / 5) on its own line with twiddles from an LDS table.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -68,6 +68,37 @@ template <int SIGN, typename T, typename C> __device__ __forceinline__ void dft8
     for (int t = 0; t < 4; ++t) { u[2 * t] = s[t]; u[2 * t + 1] = d[t]; }
 }
 
+// radix 3 and 5 (the oversampled sizes are products of 2, 3 and 5: nextprod((2, 3, 5), ...), src/plan.jl:485-498)
+template <int SIGN, typename T, typename C> __device__ __forceinline__ void dft3(C* u) {
+    const T s3 = T(0.86602540378443864676);            // sin(2 pi / 3)
+    const C t1 = cadd(u[1], u[2]);
+    C m1; m1.x = u[0].x - T(0.5) * t1.x; m1.y = u[0].y - T(0.5) * t1.y;
+    const C d = csub(u[1], u[2]);
+    C m2; m2.x = s3 * d.x; m2.y = s3 * d.y;
+    const C im2 = mul_i<SIGN>(m2);                     // SIGN * i * sin(2 pi / 3) * (u1 - u2)
+    u[0] = cadd(u[0], t1);
+    u[1] = cadd(m1, im2);
+    u[2] = csub(m1, im2);
+}
+template <int SIGN, typename T, typename C> __device__ __forceinline__ void dft5(C* u) {
+    const T c1 = T(0.30901699437494742410), c2 = T(-0.80901699437494742410);   // cos(2 pi / 5), cos(4 pi / 5)
+    const T s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);    // sin(2 pi / 5), sin(4 pi / 5)
+    const C a1 = cadd(u[1], u[4]), b1 = csub(u[1], u[4]);
+    const C a2 = cadd(u[2], u[3]), b2 = csub(u[2], u[3]);
+    C r1, r2, q1, q2;
+    r1.x = u[0].x + c1 * a1.x + c2 * a2.x; r1.y = u[0].y + c1 * a1.y + c2 * a2.y;
+    r2.x = u[0].x + c2 * a1.x + c1 * a2.x; r2.y = u[0].y + c2 * a1.y + c1 * a2.y;
+    q1.x = s1 * b1.x + s2 * b2.x; q1.y = s1 * b1.y + s2 * b2.y;
+    q2.x = s2 * b1.x - s1 * b2.x; q2.y = s2 * b1.y - s1 * b2.y;
+    const C iq1 = mul_i<SIGN>(q1), iq2 = mul_i<SIGN>(q2);
+    C u0; u0.x = u[0].x + a1.x + a2.x; u0.y = u[0].y + a1.y + a2.y;
+    u[0] = u0;
+    u[1] = cadd(r1, iq1);
+    u[4] = csub(r1, iq1);
+    u[2] = cadd(r2, iq2);
+    u[3] = csub(r2, iq2);
+}
+
 __device__ __forceinline__ int lpad(int e) { return e + (e >> 4); }   // one pad element per 16: spreads banks
 
 struct FftLineArgs {
@@ -91,9 +122,10 @@ struct FftLineArgs {
 // One radix-R Stockham stage of a line held in LDS (in place, wave-synchronous).
 // TWS: the twiddle table holds the roots of unity of order N * TWS (TWS = 2 for the half-length complex FFT
 // inside a real transform, whose table is shared with the real/complex split step).
-template <typename T, int N, int R, int SIGN, int TWS = 1>
-__device__ __forceinline__ void stage(typename Cplx2<T>::type* line, const typename Cplx2<T>::type* tw, int p, int lane) {
+template <typename T, int N, int R, int P, int SIGN, int TWS = 1>
+__device__ __forceinline__ void stage(typename Cplx2<T>::type* line, const typename Cplx2<T>::type* tw, int lane) {
     using C = typename Cplx2<T>::type;
+    constexpr int p = P;                              // product of the radices of the earlier stages
     constexpr int NB = N / R;                         // butterflies per line
     constexpr int PER = (NB + kWave - 1) / kWave;     // butterflies per lane
     C u[PER][R];
@@ -101,18 +133,20 @@ __device__ __forceinline__ void stage(typename Cplx2<T>::type* line, const typen
 #pragma unroll
     for (int b = 0; b < PER; ++b) {
         const int i = lane + b * kWave;
-        const int k = i & (p - 1);
+        const int k = i % p;
         jout[b] = (i - k) * R + k;
         if (i < NB) {
 #pragma unroll
             for (int t = 0; t < R; ++t) u[b][t] = line[lpad(i + t * NB)];
             if (p > 1) {
-                const int step = k * (N / (p * R));   // w_{pR}^{k t} = w_N^{k t N / (p R)}
+                const int step = k * (N / (p * R));   // w_{pR}^{k t} = w_N^{k t N / (p R)}; k t N / (p R) < N
 #pragma unroll
-                for (int t = 1; t < R; ++t) u[b][t] = cmul(u[b][t], tw[((step * t) & (N - 1)) * TWS]);
+                for (int t = 1; t < R; ++t) u[b][t] = cmul(u[b][t], tw[(step * t) * TWS]);
             }
             if constexpr (R == 8) dft8<SIGN, T>(u[b]);
+            else if constexpr (R == 5) dft5<SIGN, T>(u[b]);
             else if constexpr (R == 4) dft4<SIGN>(u[b]);
+            else if constexpr (R == 3) dft3<SIGN, T>(u[b]);
             else dft2<SIGN>(u[b]);
         }
     }
@@ -128,23 +162,27 @@ __device__ __forceinline__ void stage(typename Cplx2<T>::type* line, const typen
     wave_lds_fence();
 }
 
-template <typename T, int LOGN, int SIGN, int TWS = 1>
+// Stockham stages for N = 2^a 3^b 5^c: radix 8 while possible, then 4 / 2, then 3s and 5s.
+template <typename T, int N, int REM, int P, int SIGN, int TWS>
+__device__ __forceinline__ void fft_stages(typename Cplx2<T>::type* line, const typename Cplx2<T>::type* tw, int lane) {
+    if constexpr (REM > 1) {
+        constexpr int R = REM % 8 == 0 ? 8 : (REM % 4 == 0 ? 4 : (REM % 2 == 0 ? 2 : (REM % 3 == 0 ? 3 : 5)));
+        static_assert(REM % R == 0, "length must be a product of 2, 3 and 5");
+        stage<T, N, R, P, SIGN, TWS>(line, tw, lane);
+        fft_stages<T, N, REM / R, P * R, SIGN, TWS>(line, tw, lane);
+    }
+}
+
+template <typename T, int N, int SIGN, int TWS = 1>
 __device__ __forceinline__ void fft_line(typename Cplx2<T>::type* line, const typename Cplx2<T>::type* tw, int lane) {
-    constexpr int N = 1 << LOGN;
-    int p = 1;
-    constexpr int N8 = LOGN / 3;
-#pragma unroll
-    for (int s = 0; s < N8; ++s) { stage<T, N, 8, SIGN, TWS>(line, tw, p, lane); p *= 8; }
-    if constexpr (LOGN % 3 == 2) stage<T, N, 4, SIGN, TWS>(line, tw, p, lane);
-    if constexpr (LOGN % 3 == 1) stage<T, N, 2, SIGN, TWS>(line, tw, p, lane);
+    fft_stages<T, N, N, 1, SIGN, TWS>(line, tw, lane);
 }
 
 // FWD: full input (N along j), pruned output (nk along k').  BWD: pruned input, full output.
 // MULT: a real multiplier array (uniform callback menu) is applied on the pruned side.
-template <typename T, int LOGN, bool FWD, int TA, bool MULT>
+template <typename T, int N, bool FWD, int TA, bool MULT>
 __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     using C = typename Cplx2<T>::type;
-    constexpr int N = 1 << LOGN;
     constexpr int LINE = N + (N >> 4) + 1;            // padded line length (elements)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     C* tw = reinterpret_cast<C*>(smem);               // [N]
@@ -201,7 +239,7 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     }
     __syncthreads();
 
-    fft_line<T, LOGN, FWD ? -1 : 1>(lines + wave * LINE, tw, lane);
+    fft_line<T, N, FWD ? -1 : 1>(lines + wave * LINE, tw, lane);
     __syncthreads();
 
     if (FWD) {
@@ -241,10 +279,9 @@ struct RealLineArgs {
     const void* twiddle;    // complex<T>[N]: exp(SIGN 2πi m / N), N = 2M
 };
 
-template <typename T, int LOGM, bool FWD, int TL>
+template <typename T, int M, bool FWD, int TL>
 __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) {
     using C = typename Cplx2<T>::type;
-    constexpr int M = 1 << LOGM;
     constexpr int N = 2 * M;
     constexpr int LINE = M + (M >> 4) + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -263,11 +300,11 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         const C* zin = reinterpret_cast<const C*>(static_cast<const T*>(a.in) + line_id * N);
         for (int n = lane; n < M; n += kWave) line[lpad(n)] = zin[n];
         wave_lds_fence();
-        fft_line<T, LOGM, -1, 2>(line, tw, lane);
+        fft_line<T, M, -1, 2>(line, tw, lane);
         C* xout = static_cast<C*>(a.out) + line_id * a.k1;
         for (int k = lane; k < a.k1; k += kWave) {
-            const C zk = line[lpad(k & (M - 1))];
-            C zm = line[lpad((M - k) & (M - 1))];
+            const C zk = line[lpad(k == M ? 0 : k)];
+            C zm = line[lpad(k == 0 ? 0 : M - k)];
             zm.y = -zm.y;                                      // conj(Z[M - k])
             const C e = cadd(zk, zm), d = csub(zk, zm);
             // X[k] = (e - i w^k d) / 2,  w = exp(-2πi/N)
@@ -305,20 +342,23 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
             }
         }
         wave_lds_fence();
-        fft_line<T, LOGM, 1, 2>(line, tw, lane);
+        fft_line<T, M, 1, 2>(line, tw, lane);
         C* zout = reinterpret_cast<C*>(static_cast<T*>(a.out) + line_id * N);
         for (int n = lane; n < M; n += kWave) zout[n] = line[lpad(n)];
     }
 }
 
-template <typename T, int LOGM, bool FWD>
-static hipError_t launch_real_logm(const RealLineArgs& a, hipStream_t stream) {
+// Line lengths instantiated: powers of two and 1.5 x / 1.25 x powers of two (sigma = 2, 1.5, 1.25 on power-of-two
+// grids).  Other products of 2, 3 and 5 use the general rocFFT path.
+#define NUFFT_FFT_SIZES(X) X(64) X(80) X(96) X(128) X(160) X(192) X(256) X(320) X(384) X(512) X(640) X(768) X(1024)
+
+template <typename T, int M, bool FWD>
+static hipError_t launch_real_m(const RealLineArgs& a, hipStream_t stream) {
     using C = typename Cplx2<T>::type;
-    constexpr int M = 1 << LOGM;
     constexpr int LINE = M + (M >> 4) + 1;
     constexpr int TL = (sizeof(C) * (16 * LINE + 2 * M) <= 150 * 1024) ? 16 : 8;
     const size_t lds = sizeof(C) * (size_t)(TL * LINE + 2 * M);
-    auto fn = real_lines_kernel<T, LOGM, FWD, TL>;
+    auto fn = real_lines_kernel<T, M, FWD, TL>;
     static bool prepared = false;
     if (!prepared) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -330,44 +370,51 @@ static hipError_t launch_real_logm(const RealLineArgs& a, hipStream_t stream) {
 }
 
 template <typename T, bool FWD>
-static hipError_t launch_real_t(int logm, const RealLineArgs& a, hipStream_t stream) {
-    switch (logm) {
-        case 6: return launch_real_logm<T, 6, FWD>(a, stream);
-        case 7: return launch_real_logm<T, 7, FWD>(a, stream);
-        case 8: return launch_real_logm<T, 8, FWD>(a, stream);
-        case 9: return launch_real_logm<T, 9, FWD>(a, stream);
-        case 10: return launch_real_logm<T, 10, FWD>(a, stream);
+static hipError_t launch_real_t(int m, const RealLineArgs& a, hipStream_t stream) {
+    switch (m) {
+#define NUFFT_CASE(NN) case NN: return launch_real_m<T, NN, FWD>(a, stream);
+        NUFFT_FFT_SIZES(NUFFT_CASE)
+#undef NUFFT_CASE
         default: return hipErrorInvalidValue;
     }
 }
 
-bool real_lines_supported(int dtype, int64_t n) {
-    (void)dtype;
-    if (n < 128 || n > 2048) return false;
-    return (n & (n - 1)) == 0;
+static bool size_instantiated(int64_t n) {
+    switch (n) {
+#define NUFFT_CASE(NN) case NN:
+        NUFFT_FFT_SIZES(NUFFT_CASE)
+#undef NUFFT_CASE
+            return true;
+        default: return false;
+    }
 }
 
-hipError_t launch_real_lines(int dtype, int logn, bool forward, const void* in, void* out, int64_t nlines, int k1,
+// real line length n = 2 M
+bool real_lines_supported(int dtype, int64_t n) {
+    (void)dtype;
+    return n % 2 == 0 && size_instantiated(n / 2);
+}
+
+hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
                              const void* twiddle, hipStream_t stream) {
     RealLineArgs a;
     a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.twiddle = twiddle;
-    const int logm = logn - 1;
-    if (dtype == NUFFT_F32) return forward ? launch_real_t<float, true>(logm, a, stream) : launch_real_t<float, false>(logm, a, stream);
-    return forward ? launch_real_t<double, true>(logm, a, stream) : launch_real_t<double, false>(logm, a, stream);
+    const int m = (int)(n / 2);
+    if (dtype == NUFFT_F32) return forward ? launch_real_t<float, true>(m, a, stream) : launch_real_t<float, false>(m, a, stream);
+    return forward ? launch_real_t<double, true>(m, a, stream) : launch_real_t<double, false>(m, a, stream);
 }
 
-template <typename T, int LOGN, bool FWD, bool MULT>
-static hipError_t launch_logn_m(const FftLineArgs& a, hipStream_t stream) {
+template <typename T, int N, bool FWD, bool MULT>
+static hipError_t launch_n_m(const FftLineArgs& a, hipStream_t stream) {
     using C = typename Cplx2<T>::type;
-    constexpr int N = 1 << LOGN;
     constexpr int LINE = N + (N >> 4) + 1;
-    // TA lines per workgroup: 16 when they fit in ~150 KB of LDS, else 8 / 4
+    // TA lines per workgroup: as many as fit in the LDS limit (two workgroups per CU), at most 16
 #ifndef NUFFT_FFT_LDS_LIMIT
 #define NUFFT_FFT_LDS_LIMIT (80 * 1024)      // two workgroups per CU (70 KB at N = 512 Float64) beat one with 16 lines: measured
 #endif
     constexpr int TA = (sizeof(C) * (16 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 16 : ((sizeof(C) * (8 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 8 : 4);
     const size_t lds = sizeof(C) * (size_t)(TA * LINE + N);
-    auto fn = fft_lines_kernel<T, LOGN, FWD, TA, MULT>;
+    auto fn = fft_lines_kernel<T, N, FWD, TA, MULT>;
     static bool prepared = false;
     if (!prepared) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -380,29 +427,27 @@ static hipError_t launch_logn_m(const FftLineArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <typename T, int LOGN, bool FWD>
-static hipError_t launch_logn(const FftLineArgs& a, hipStream_t stream) {
-    return a.mult ? launch_logn_m<T, LOGN, FWD, true>(a, stream) : launch_logn_m<T, LOGN, FWD, false>(a, stream);
+template <typename T, int N, bool FWD>
+static hipError_t launch_n(const FftLineArgs& a, hipStream_t stream) {
+    return a.mult ? launch_n_m<T, N, FWD, true>(a, stream) : launch_n_m<T, N, FWD, false>(a, stream);
 }
 
 template <typename T, bool FWD>
-static hipError_t launch_t(int logn, const FftLineArgs& a, hipStream_t stream) {
-    switch (logn) {
-        case 6: return launch_logn<T, 6, FWD>(a, stream);
-        case 7: return launch_logn<T, 7, FWD>(a, stream);
-        case 8: return launch_logn<T, 8, FWD>(a, stream);
-        case 9: return launch_logn<T, 9, FWD>(a, stream);
-        case 10: return launch_logn<T, 10, FWD>(a, stream);
+static hipError_t launch_t(int n, const FftLineArgs& a, hipStream_t stream) {
+    switch (n) {
+#define NUFFT_CASE(NN) case NN: return launch_n<T, NN, FWD>(a, stream);
+        NUFFT_FFT_SIZES(NUFFT_CASE)
+#undef NUFFT_CASE
         default: return hipErrorInvalidValue;
     }
 }
 
 bool fft_lines_supported(int dtype, int64_t n) {
-    if (n < 64 || n > 1024) return false;
-    return (n & (n - 1)) == 0;
+    (void)dtype;
+    return size_instantiated(n);
 }
 
-hipError_t launch_fft_lines(int dtype, int logn, bool forward, const FftLinePass& p, hipStream_t stream) {
+hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePass& p, hipStream_t stream) {
     FftLineArgs a;
     a.in = p.in; a.out = p.out;
     a.a_total = p.a_total; a.a_out = p.a_out;
@@ -410,8 +455,8 @@ hipError_t launch_fft_lines(int dtype, int logn, bool forward, const FftLinePass
     a.out_stride_j = p.out_stride_j; a.out_stride_c = p.out_stride_c;
     a.nc = p.nc; a.nk = p.nk; a.map = p.map; a.fa = p.fa; a.ka = p.ka; a.fk = p.fk;
     a.twiddle = p.twiddle; a.scale = p.scale; a.mult = p.mult;
-    if (dtype == NUFFT_F32) return forward ? launch_t<float, true>(logn, a, stream) : launch_t<float, false>(logn, a, stream);
-    return forward ? launch_t<double, true>(logn, a, stream) : launch_t<double, false>(logn, a, stream);
+    if (dtype == NUFFT_F32) return forward ? launch_t<float, true>((int)n, a, stream) : launch_t<float, false>((int)n, a, stream);
+    return forward ? launch_t<double, true>((int)n, a, stream) : launch_t<double, false>((int)n, a, stream);
 }
 
 }  // namespace nufft

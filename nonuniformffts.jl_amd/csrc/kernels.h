@@ -119,9 +119,9 @@ struct FftLinePass {
 };
 bool fft_lines_supported(int dtype, int64_t n);
 bool real_lines_supported(int dtype, int64_t n);
-// r2c (forward) / c2r of `nlines` contiguous real lines of length 2^logn with a compact spectrum of k1 modes per line
-hipError_t launch_real_lines(int dtype, int logn, bool forward, const void* in, void* out, int64_t nlines, int k1,
+// r2c (forward) / c2r of `nlines` contiguous real lines of length n with a compact spectrum of k1 modes per line
+hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
                              const void* twiddle, hipStream_t stream);
-hipError_t launch_fft_lines(int dtype, int logn, bool forward, const FftLinePass& p, hipStream_t stream);
+hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePass& p, hipStream_t stream);
 
 }  // namespace nufft

@@ -613,14 +613,14 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
         // components are contiguous both in us (Ñ1 reals per line) and in the compact spectrum (N_out1 per line);
         // the per-component offset of the compact spectrum is nlines_per_component * N_out1 <= spec_elems
         if (p->C == 1) {
-            NUFFT_HIP(launch_real_lines(p->dtype, ilog2(p->Nover[0]), true, p->d_us, p->d_uhat, nlines, (int)p->Nout[0], p->d_tw_fw[0], stream));
+            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, p->d_us, p->d_uhat, nlines, (int)p->Nout[0], p->d_tw_fw[0], stream));
         } else {
             const int64_t per = nlines / p->C;
             const size_t rb = real_bytes(p);
             for (int c = 0; c < p->C; ++c) {
                 const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
                 void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
-                NUFFT_HIP(launch_real_lines(p->dtype, ilog2(p->Nover[0]), true, in, out, per, (int)p->Nout[0], p->d_tw_fw[0], stream));
+                NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], p->d_tw_fw[0], stream));
             }
         }
         return NUFFT_OK;
@@ -672,7 +672,7 @@ static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hi
         q.fk = p->d_invphi[dim];
         q.scale = 1.0;
     }
-    NUFFT_HIP(launch_fft_lines(p->dtype, ilog2(p->Nover[dim]), true, q, stream));
+    NUFFT_HIP(launch_fft_lines(p->dtype, p->Nover[dim], true, q, stream));
     return NUFFT_OK;
 }
 
@@ -709,7 +709,7 @@ static int pruned_backward_pass(nufft_plan* p, int c, int dim, const void* user_
     q.mult = first ? p->cb_mode_factors : nullptr;
     if (first) { q.fa = p->d_invphi[0]; q.ka = (int)K1; } else { q.fa = p->d_one; q.ka = 1; }
     q.fk = p->d_invphi[dim];
-    NUFFT_HIP(launch_fft_lines(p->dtype, ilog2(p->Nover[dim]), false, q, stream));
+    NUFFT_HIP(launch_fft_lines(p->dtype, p->Nover[dim], false, q, stream));
     return NUFFT_OK;
 }
 
@@ -1008,7 +1008,7 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
         for (int c = 0; c < p->C; ++c) {
             const void* in = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
             void* out = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
-            NUFFT_HIP(launch_real_lines(p->dtype, ilog2(p->Nover[0]), false, in, out, per, (int)p->Nout[0], p->d_tw_bw[0], stream));
+            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], false, in, out, per, (int)p->Nout[0], p->d_tw_bw[0], stream));
         }
         return NUFFT_OK;
     }

@@ -106,6 +106,12 @@ CASES = [
     (np.float32, (32, 64, 32), 4, 2.0, O.FAST_APPROXIMATION, 1),
     (np.float64, (64, 128), 6, 2.0, O.DIRECT, 1),                 # 2-D: 128 x 256
     (np.float64, (48, 128, 32), 4, 2.0, O.DIRECT, 1),             # dim 1 not a power of two (96), dims 2, 3 are
+    # oversampled sizes 1.5 * 2^a and 1.25 * 2^a: radix-3 / radix-5 stages of the pruned passes
+    (np.float64, (64, 64, 64), 4, 1.5, O.FAST_APPROXIMATION, 1),  # 96^3
+    (np.float64, (64, 128, 64), 4, 1.25, O.DIRECT, 2),            # 80 x 160 x 80, two transforms
+    (np.float32, (128, 256), 4, 1.5, O.FAST_APPROXIMATION, 1),    # 192 x 384
+    (np.float64, (256, 64, 32), 6, 1.5, O.DIRECT, 1),             # 384 x 96 x 48 (48: general path for that plan)
+    (np.float64, (63, 64, 128), 5, 1.5, O.FAST_APPROXIMATION, 1), # odd N1: 2 * nextprod(48) = 96, N_out1 = 32
 ]
 
 
@@ -148,6 +154,7 @@ def test_explicit_kernel_parameters_match_oracle():
 
 
 @pytest.mark.parametrize("Z,dims", [(np.float64, (35, 64, 40)), (np.complex128, (37, 41)), (np.float64, (32, 32, 32)),
+                                    (np.float64, (48, 48, 48)),
                                     (np.complex64, (100,)), (np.float64, (31, 33)), (np.complex128, (16, 15, 12))])
 def test_fftshift_ordering_matches_oracle(Z, dims):
     """fftshift = true: uniform data in increasing-frequency order (src/plan.jl:472,509-514,
