@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--evalmode", default="fast", choices=["direct", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-reference-protocol", action="store_true")
     ap.add_argument("--force-distributed", action="store_true",
                     help="take the multi-process code path (RCCL init, side-stream gather) even with one rank: "
                          "a single-GPU self-test of the N > 1 path")
@@ -270,6 +271,8 @@ def main():
                   "ms_per_step": dt2 / a.steps * 1e3},
     }
 
+    if world == 1 and not a.no_reference_protocol:
+        result["reference_protocol"] = reference_protocol(a, nufft, dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(a)
     if rank == 0:
@@ -278,6 +281,34 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def reference_protocol(a, nufft, dev):
+    """The reference's published benchmark protocol, for comparison with BASELINE.md (not the headline metric):
+    sigma = 1.5, BackwardsKaiserBessel with Direct() evaluation (the ROC defaults), coordinates ~ N(0, 1) folded
+    into the period, time = set_points! + exec! (benchmark/CPU+AMDGPU/run_benchmarks.jl:57-90), same Ns and Np."""
+    Np = int(a.np)
+    dims = (a.n, a.n, a.n)
+    plan = nufft.PlanNUFFT(torch.float64, dims, m=a.m, sigma=1.5, kernel_evalmode=nufft.Direct(), backend=nufft.ROCBackend(dev.index or 0))
+    g = torch.Generator(device=dev).manual_seed(4242)
+    xs = tuple(torch.randn(Np, dtype=torch.float64, device=dev, generator=g) for _ in dims)
+    v = torch.randn(Np, dtype=torch.float64, device=dev, generator=g)
+    u = torch.empty(plan.shape, dtype=torch.complex128, device=dev)
+    out = torch.empty(Np, dtype=torch.float64, device=dev)
+    res = {}
+    for name, fn in (("type1", lambda: nufft.exec_type1(u, plan, v)), ("type2", lambda: nufft.exec_type2(out, plan, u))):
+        for _ in range(2):
+            nufft.set_points(plan, xs); fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        K = 10
+        for _ in range(K):
+            nufft.set_points(plan, xs); fn()
+        torch.cuda.synchronize(dev)
+        res[name + "_pts_per_s"] = Np * K / (time.perf_counter() - t0)
+    res["config"] = f"Ns={a.n}^3, Np={Np:.0e} ~ N(0,1) folded, Float64, m={a.m}, sigma=1.5 (oversampled {plan.oversampled_dims}), Direct window, set_points! + exec!"
+    res["published_mi300a_pts_per_s"] = {"type1": "2.4e8-2.7e8", "type2": "6.2e8-9.6e8", "source": "BASELINE.md (Np = 1.7e7 ... 1.7e8)"}
+    return res
 
 
 def cpu_baseline(a):

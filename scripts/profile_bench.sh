@@ -9,9 +9,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 python3 bench.py > $R/gpurun_out/bench_$TAG.json 2> $OUT/bench_stderr.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_line.json 2> $OUT/stats_stderr.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch_line.json 2> $OUT/fetch_stderr.txt
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write_line.json 2> $OUT/write_stderr.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-reference-protocol > $OUT/stats_line.json 2> $OUT/stats_stderr.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-protocol > $OUT/fetch_line.json 2> $OUT/fetch_stderr.txt
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-protocol > $OUT/write_line.json 2> $OUT/write_stderr.txt
 cd $R
 # keep only the small csv files (the merged-back directory is capped at 64 MiB)
 find $OUT -name "*.db" -delete 2>/dev/null
