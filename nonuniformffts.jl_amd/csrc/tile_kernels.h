@@ -6,19 +6,26 @@
 // with an MI355X-first design (see DESIGN.md §4.1 for the measurements behind each choice):
 //
 //   * Points arrive sorted by fine bins (binsort.hip) as aligned records {r_1..r_D, idx}; a tile is a
-//     box of bins, so its points are a few contiguous runs of the sorted array.
+//     box of bins, so its points are a few contiguous runs of the sorted array, cut into ~64 work items
+//     that the waves of the workgroup pull from a shared LDS counter.  Heavy tiles of a non-uniform point
+//     set are shared by several workgroups (slices, balance.hip).
 //   * Lane mapping: G = nextpow2(ncomp * 2M) consecutive lanes own one point (one lane per
-//     (component, j1) of the stencil's first dimension); a wave works on 64 / G points at once and
-//     every lane loops over (j2, j3).  The D*2M window values of a point are evaluated once by its G
-//     lanes (direct sinh form, or the piecewise polynomial with the lane's coefficients held in
-//     registers), exchanged through a wave-private LDS strip, and kept in registers.
+//     (component, j1) of the stencil's first dimension); a wave works on 64 / G points at once.  The
+//     D*2M window values of a point are evaluated once by its G lanes (direct form, or the piecewise
+//     polynomial with the lane's coefficients held in registers).
 //   * Spreading is OUTPUT-DRIVEN: only the tile interior lives in LDS (Float64 accumulation with
 //     native ds_add_f64); the workgroup visits every point whose stencil touches the tile, clips the
 //     stencil to the tile, and finally stores the tile with plain coalesced stores.  There are no
 //     global atomics (memory-side float atomics run at 1.2 TB/s on MI355X, 3-5x below plain stores) and
-//     the grid needs no zero fill: every cell is written exactly once.
+//     the grid needs no zero fill: every cell is written exactly once.  The window values go through a
+//     wave-private LDS strip; accumulation walks the chunk's points one at a time with the 64 lanes on
+//     the (component, j1, j2) face of the stencil and a loop over j3 (dimension-3 values by DPP row
+//     broadcast).
 //   * Interpolation loads the padded tile (interior + 2M-1 halo) once, visits each point exactly once,
-//     gathers with the same loops and reduces over the G lanes with DPP / permlane-swap butterflies.
+//     gathers with the group mapping (window values exchanged by DPP broadcasts for real data) and
+//     reduces over the G lanes with DPP / permlane-swap butterflies.
+//   * Default configurations use compile-time tile shapes (fixed_spread_tile / fixed_interp_tile): LDS
+//     strides become immediates and the hot LDS instructions are issued from inline assembly.
 #pragma once
 
 #include <hip/hip_runtime.h>
