@@ -377,6 +377,22 @@ template <typename T, int N, int... J>
 __device__ __forceinline__ void row_bcast_all(T x, T (&w)[N], int base, std::integer_sequence<int, J...>) {
     ((w[base + J] = row_bcast_asm<J>(x)), ...);
 }
+// the common case N = 8 as one block: a single hazard no-op, nothing can be scheduled in between
+// (early-clobber outputs: none of them may alias the source)
+__device__ __forceinline__ void row_bcast_all(double x, double (&w)[8], int, std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b64_dpp %0, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %1, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %2, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %3, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %4, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %5, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %6, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %7, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+        : "v"(x));
+}
 
 // j must be a compile-time constant after unrolling (the switch folds away)
 template <typename T>
