@@ -154,6 +154,43 @@ def test_nonuniform_distributions_spot_check_and_balance(dist):
     assert float((out - out0).norm() / out0.norm()) < 1e-13
 
 
+def test_config_c4_ntransforms3_spot_check():
+    """BASELINE config C4: C2 with ntransforms = 3 (three value vectors spread / interpolated simultaneously,
+    one set of points).  Exact spot checks per component; component c must equal a single transform of v_c."""
+    from nufft_pkg import nufft
+    Np, C = 4_000_000, 3
+    plan = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, ntransforms=C, backend=nufft.ROCBackend(0),
+                           kernel_evalmode=nufft.FastApproximation())
+    g = torch.Generator(device="cuda").manual_seed(31)
+    xs = tuple(torch.rand(Np, dtype=torch.float64, device="cuda", generator=g) * (2 * np.pi) for _ in range(3))
+    vs = tuple(torch.randn(Np, dtype=torch.float64, device="cuda", generator=g) for _ in range(C))
+    nufft.set_points(plan, xs)
+    us = tuple(torch.empty(plan.shape, dtype=torch.complex128, device="cuda") for _ in range(C))
+    nufft.exec_type1(us, plan, vs)
+    k1, k2, k3 = _wavenumbers(plan)
+    rng = np.random.default_rng(9)
+    for c in range(C):
+        num = den = 0.0
+        for _ in range(8):
+            i1, i2, i3 = int(rng.integers(0, N // 2 + 1)), int(rng.integers(0, N)), int(rng.integers(0, N))
+            phase = k1[i1] * xs[0] + k2[i2] * xs[1] + k3[i3] * xs[2]
+            exact = torch.complex((vs[c] * torch.cos(phase)).sum(), -(vs[c] * torch.sin(phase)).sum())
+            num += float((us[c][i3, i2, i1] - exact).abs() ** 2)
+            den += float(exact.abs() ** 2)
+        assert np.sqrt(num / den) < 2 * CEIL
+    single = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, backend=nufft.ROCBackend(0),
+                             kernel_evalmode=nufft.FastApproximation())
+    nufft.set_points(single, xs)
+    u1 = torch.empty(plan.shape, dtype=torch.complex128, device="cuda")
+    nufft.exec_type1(u1, single, vs[1])
+    assert float((u1 - us[1]).norm() / u1.norm()) < 1e-12
+    outs = tuple(torch.empty(Np, dtype=torch.float64, device="cuda") for _ in range(C))
+    nufft.exec_type2(outs, plan, us)
+    o1 = torch.empty(Np, dtype=torch.float64, device="cuda")
+    nufft.exec_type2(o1, single, us[1])
+    assert float((o1 - outs[1]).norm() / o1.norm()) < 1e-12
+
+
 def test_config_c3_complexf32_m8_1024_cubed_spot_check():
     """BASELINE config C3 shape: 3-D, Ns = 512^3, ComplexF32, m = 8 (oversampled 1024^3, 8.6 GB grid; LDS pressure).
     Np is reduced to 2e7 to keep the test short; exact spot checks of type-1 modes and type-2 points in Float64.
