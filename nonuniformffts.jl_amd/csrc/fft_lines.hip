@@ -22,6 +22,7 @@
 // (radix 8, then 4 or 2, then 3 / 5) on its own line with twiddles from an LDS table.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <vector>
 
@@ -359,11 +360,15 @@ static hipError_t launch_real_m(const RealLineArgs& a, hipStream_t stream) {
     constexpr int TL = (sizeof(C) * (16 * LINE + 2 * M) <= 150 * 1024) ? 16 : 8;
     const size_t lds = sizeof(C) * (size_t)(TL * LINE + 2 * M);
     auto fn = real_lines_kernel<T, M, FWD, TL>;
-    static bool prepared = false;
-    if (!prepared) {
+    // the attribute is per device: remember which devices of this process have it (plans may live on several)
+    static std::atomic<unsigned long long> prepared{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(prepared.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        prepared = true;
+        prepared.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)((a.nlines + TL - 1) / TL)), dim3(TL * kWave), lds, stream, a);
     return hipGetLastError();
@@ -415,11 +420,15 @@ static hipError_t launch_n_m(const FftLineArgs& a, hipStream_t stream) {
     constexpr int TA = (sizeof(C) * (16 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 16 : ((sizeof(C) * (8 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 8 : 4);
     const size_t lds = sizeof(C) * (size_t)(TA * LINE + N);
     auto fn = fft_lines_kernel<T, N, FWD, TA, MULT>;
-    static bool prepared = false;
-    if (!prepared) {
+    // the attribute is per device: remember which devices of this process have it (plans may live on several)
+    static std::atomic<unsigned long long> prepared{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(prepared.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        prepared = true;
+        prepared.fetch_or(bit, std::memory_order_relaxed);
     }
     const int64_t acols = FWD ? a.a_total : a.a_out;
     dim3 grid((unsigned)((acols + TA - 1) / TA), (unsigned)a.nc, 1);
