@@ -349,6 +349,53 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
     }
 }
 
+// Dimension 1 of complex plans: c2c of contiguous lines with a compact spectrum (the K1 = N1 kept modes of each
+// line, in the caller's mode order: map[k'] is the FFT index of kept mode k').
+struct CplxLineArgs {
+    const void* in;
+    void* out;
+    int64_t nlines;
+    int k1;                 // kept modes per line
+    const int32_t* map;     // [k1]
+    const void* twiddle;    // complex<T>[N]
+};
+
+template <typename T, int N, bool FWD, int TL>
+__global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) {
+    using C = typename Cplx2<T>::type;
+    constexpr int LINE = N + (N >> 4) + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C* tw = reinterpret_cast<C*>(smem);                       // [N]
+    C* lines = tw + N;                                        // [TL][LINE]
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    const C* twg = static_cast<const C*>(a.twiddle);
+    for (int i = tid; i < N; i += TL * kWave) tw[i] = twg[i];
+    __syncthreads();
+    const int64_t line_id = (int64_t)blockIdx.x * TL + wave;
+    if (line_id >= a.nlines) return;
+    C* line = lines + wave * LINE;
+    if (FWD) {
+        const C* zin = static_cast<const C*>(a.in) + line_id * N;
+        for (int n = lane; n < N; n += kWave) line[lpad(n)] = zin[n];
+        wave_lds_fence();
+        fft_line<T, N, -1>(line, tw, lane);
+        C* xout = static_cast<C*>(a.out) + line_id * a.k1;
+        for (int k = lane; k < a.k1; k += kWave) xout[k] = line[lpad(a.map[k])];
+    } else {
+        C z; z.x = T(0); z.y = T(0);
+        for (int n = lane; n < N; n += kWave) line[lpad(n)] = z;
+        wave_lds_fence();
+        const C* xin = static_cast<const C*>(a.in) + line_id * a.k1;
+        for (int k = lane; k < a.k1; k += kWave) line[lpad(a.map[k])] = xin[k];
+        wave_lds_fence();
+        fft_line<T, N, 1>(line, tw, lane);
+        C* zout = static_cast<C*>(a.out) + line_id * N;
+        for (int n = lane; n < N; n += kWave) zout[n] = line[lpad(n)];
+    }
+}
+
 // Line lengths instantiated: powers of two and 1.5 x / 1.25 x powers of two (sigma = 2, 1.5, 1.25 on power-of-two
 // grids).  Other products of 2, 3 and 5 use the general rocFFT path.
 #define NUFFT_FFT_SIZES(X) X(64) X(80) X(96) X(128) X(160) X(192) X(256) X(320) X(384) X(512) X(640) X(768) X(1024)
@@ -407,6 +454,44 @@ hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in,
     const int m = (int)(n / 2);
     if (dtype == NUFFT_F32) return forward ? launch_real_t<float, true>(m, a, stream) : launch_real_t<float, false>(m, a, stream);
     return forward ? launch_real_t<double, true>(m, a, stream) : launch_real_t<double, false>(m, a, stream);
+}
+
+template <typename T, int N, bool FWD>
+static hipError_t launch_cplx_n(const CplxLineArgs& a, hipStream_t stream) {
+    using C = typename Cplx2<T>::type;
+    constexpr int LINE = N + (N >> 4) + 1;
+    constexpr int TL = (sizeof(C) * (16 * LINE + N) <= 80 * 1024) ? 16 : 8;
+    const size_t lds = sizeof(C) * (size_t)(TL * LINE + N);
+    auto fn = cplx_lines_kernel<T, N, FWD, TL>;
+    static std::atomic<unsigned long long> prepared{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(prepared.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        prepared.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)((a.nlines + TL - 1) / TL)), dim3(TL * kWave), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename T, bool FWD>
+static hipError_t launch_cplx_t(int n, const CplxLineArgs& a, hipStream_t stream) {
+    switch (n) {
+#define NUFFT_CASE(NN) case NN: return launch_cplx_n<T, NN, FWD>(a, stream);
+        NUFFT_FFT_SIZES(NUFFT_CASE)
+#undef NUFFT_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
+                             const int32_t* map, const void* twiddle, hipStream_t stream) {
+    CplxLineArgs a;
+    a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.map = map; a.twiddle = twiddle;
+    if (dtype == NUFFT_F32) return forward ? launch_cplx_t<float, true>((int)n, a, stream) : launch_cplx_t<float, false>((int)n, a, stream);
+    return forward ? launch_cplx_t<double, true>((int)n, a, stream) : launch_cplx_t<double, false>((int)n, a, stream);
 }
 
 template <typename T, int N, bool FWD, bool MULT>

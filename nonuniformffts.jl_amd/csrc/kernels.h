@@ -123,5 +123,8 @@ bool real_lines_supported(int dtype, int64_t n);
 hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
                              const void* twiddle, hipStream_t stream);
 hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePass& p, hipStream_t stream);
+// c2c of `nlines` contiguous complex lines of length n with a compact spectrum of k1 kept modes (map: kept -> FFT index)
+hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
+                             const int32_t* map, const void* twiddle, hipStream_t stream);
 
 }  // namespace nufft

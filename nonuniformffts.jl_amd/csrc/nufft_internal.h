@@ -119,6 +119,7 @@ struct nufft_plan {
     void* d_uhat = nullptr;            // C spectra complex<T>[Nspec] (real plans only)
     int64_t grid_elems = 0;            // elements (of Z) per component in d_us
     int64_t spec_elems = 0;            // complex elements per component in d_uhat (or d_us)
+    int64_t pspec_elems = 0;           // complex elements between components of the pruned-path spectrum (compact for complex plans)
 
     // bin sort
     int64_t Np = -1;

@@ -414,10 +414,18 @@ static int build_device(nufft_plan* p) {
         NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
     }
 
-    // pruned FFT path: real plans, D >= 2, every higher dimension a power of two in 64..1024
-    p->pruned_fft = !p->is_complex && D >= 2 && env_int("NUFFT_PRUNED_FFT", 1) != 0;
-    for (int d = 1; d < D && p->pruned_fft; ++d) p->pruned_fft = fft_lines_supported(p->dtype, p->Nover[d]);
-    if (p->pruned_fft) {
+    // pruned FFT path: D >= 2, every higher dimension (and dimension 1 of complex plans) of an instantiated length
+    p->pruned_fft = D >= 2 && env_int("NUFFT_PRUNED_FFT", 1) != 0;
+    for (int d = p->is_complex ? 0 : 1; d < D && p->pruned_fft; ++d) p->pruned_fft = fft_lines_supported(p->dtype, p->Nover[d]);
+    p->pspec_elems = p->spec_elems;
+    if (p->pruned_fft && p->is_complex) {
+        // complex plans transform in place on the general path; the pruned passes work out of place with a compact
+        // spectrum (N1 kept modes per line of dimension 1)
+        p->pspec_elems = p->Nout[0];
+        for (int d = 1; d < D; ++d) p->pspec_elems *= p->Nover[d];
+        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->pspec_elems * 2 * real_bytes(p) * p->C))) return rc;
+    }
+    if (p->pruned_fft && !p->is_complex) {
         size_t len1[1] = {(size_t)p->Nover[0]};
         size_t batch = (size_t)p->C;
         for (int d = 1; d < D; ++d) batch *= (size_t)p->Nover[d];
@@ -432,6 +440,8 @@ static int build_device(nufft_plan* p) {
             if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes))) return rc;
             NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
         }
+    }
+    if (p->pruned_fft) {
         for (int d = 0; d < D; ++d) {
             std::vector<double> inv(p->phihat[d].size());
             for (size_t i = 0; i < inv.size(); ++i) {
@@ -446,7 +456,7 @@ static int build_device(nufft_plan* p) {
             rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_one, one) : upload<double>(p, &p->d_one, one);
             if (rc) return rc;
         }
-        p->compact_dim1 = real_lines_supported(p->dtype, p->Nover[0]) && env_int("NUFFT_COMPACT_DIM1", 1) != 0;
+        p->compact_dim1 = p->is_complex || (real_lines_supported(p->dtype, p->Nover[0]) && env_int("NUFFT_COMPACT_DIM1", 1) != 0);
         for (int d = p->compact_dim1 ? 0 : 1; d < D; ++d) {
             const int64_t n = p->Nover[d];
             std::vector<double> twf(2 * (size_t)n), twb(2 * (size_t)n);
@@ -607,6 +617,17 @@ static int ilog2(int64_t n) {
 // ---- pruned FFT path (see fft_lines.hip) ---------------------------------------------------------
 // type 1, stage "FFT": rocFFT r2c along dim 1 and, for D = 3, the pruned pass along dim 2 into tmp2.
 static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
+    if (p->is_complex) {
+        int64_t per = 1;
+        for (int d = 1; d < p->D; ++d) per *= p->Nover[d];
+        const size_t cb = 2 * real_bytes(p);
+        for (int c = 0; c < p->C; ++c) {
+            const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * cb;
+            void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * cb;
+            NUFFT_HIP(launch_cplx_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], p->d_index_map[0], p->d_tw_fw[0], stream));
+        }
+        return NUFFT_OK;
+    }
     if (p->compact_dim1) {
         int64_t nlines = p->C;
         for (int d = 1; d < p->D; ++d) nlines *= p->Nover[d];
@@ -642,7 +663,7 @@ static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hi
     q.twiddle = p->d_tw_fw[dim];
     const bool last = dim == p->D - 1;
     if (dim == 1) {
-        q.in = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * cb;
+        q.in = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * cb;
         q.a_total = q.a_out = K1;
         q.in_stride_j = S1;
         q.in_stride_c = S1 * p->Nover[1];
@@ -702,7 +723,7 @@ static int pruned_backward_pass(nufft_plan* p, int c, int dim, const void* user_
         q.in_stride_j = K1;
         q.in_stride_c = K1 * p->Nout[1];
         q.nc = p->D == 3 ? (int)p->Nover[2] : 1;
-        q.out = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * cb;
+        q.out = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * cb;
         q.out_stride_j = S1;
         q.out_stride_c = S1 * p->Nover[1];
     }
@@ -1001,6 +1022,17 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_FFT, stream);
+    if (p->pruned_fft && p->is_complex) {
+        int64_t per = 1;
+        for (int d = 1; d < p->D; ++d) per *= p->Nover[d];
+        const size_t cb = 2 * real_bytes(p);
+        for (int c = 0; c < p->C; ++c) {
+            const void* in = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * cb;
+            void* out = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * cb;
+            NUFFT_HIP(launch_cplx_lines(p->dtype, p->Nover[0], false, in, out, per, (int)p->Nout[0], p->d_index_map[0], p->d_tw_bw[0], stream));
+        }
+        return NUFFT_OK;
+    }
     if (p->pruned_fft && p->compact_dim1) {
         int64_t per = 1;
         for (int d = 1; d < p->D; ++d) per *= p->Nover[d];

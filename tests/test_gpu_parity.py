@@ -112,6 +112,15 @@ CASES = [
     (np.float32, (128, 256), 4, 1.5, O.FAST_APPROXIMATION, 1),    # 192 x 384
     (np.float64, (256, 64, 32), 6, 1.5, O.DIRECT, 1),             # 384 x 96 x 48 (48: general path for that plan)
     (np.float64, (63, 64, 128), 5, 1.5, O.FAST_APPROXIMATION, 1), # odd N1: 2 * nextprod(48) = 96, N_out1 = 32
+    # complex plans on the pruned path (own c2c pass along dimension 1 with a compact spectrum)
+    (np.complex128, (32, 64, 32), 4, 2.0, O.DIRECT, 1),
+    (np.complex64, (64, 64), 4, 1.5, O.FAST_APPROXIMATION, 1),    # 96 x 96
+    (np.complex128, (64, 32, 64), 6, 1.25, O.FAST_APPROXIMATION, 2),  # 80 x 40(general: 40 unsupported -> whole plan general)
+    (np.complex128, (64, 64, 64), 4, 1.25, O.DIRECT, 2),          # 80^3, two transforms
+    (np.complex64, (33, 64, 47), 4, 2.0, O.DIRECT, 1),            # odd sizes: 66 (general)
+    (np.complex128, (127, 128), 5, 2.0, O.FAST_APPROXIMATION, 1), # odd N1 = 127 -> 254 (general); 
+    (np.complex128, (128, 127), 5, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.complex128, (48, 96), 5, 2.0, O.FAST_APPROXIMATION, 1),   # 96 x 192
 ]
 
 
@@ -154,7 +163,7 @@ def test_explicit_kernel_parameters_match_oracle():
 
 
 @pytest.mark.parametrize("Z,dims", [(np.float64, (35, 64, 40)), (np.complex128, (37, 41)), (np.float64, (32, 32, 32)),
-                                    (np.float64, (48, 48, 48)),
+                                    (np.float64, (48, 48, 48)), (np.complex128, (32, 64, 48)), (np.complex64, (31, 32)), (np.complex128, (64, 96)),
                                     (np.complex64, (100,)), (np.float64, (31, 33)), (np.complex128, (16, 15, 12))])
 def test_fftshift_ordering_matches_oracle(Z, dims):
     """fftshift = true: uniform data in increasing-frequency order (src/plan.jl:472,509-514,
@@ -194,7 +203,7 @@ def test_nfft_plan_interface():
     assert q.size == (24, 24)
 
 
-@pytest.mark.parametrize("Z,Ns,C", [(np.float32, (64, 32, 16), 1), (np.complex64, (64, 32, 16), 1),
+@pytest.mark.parametrize("Z,Ns,C", [(np.float32, (64, 32, 16), 1), (np.complex64, (64, 32, 16), 1), (np.complex128, (64, 32, 32), 2),
                                     (np.float64, (32, 32, 16), 2), (np.complex128, (40, 24), 1), (np.float64, (128,), 1)])
 def test_callbacks_menu(Z, Ns, C):
     """test/callbacks.jl:6-66: random per-point weights as the non-uniform callback and 1/k² (0 at k = 0) as
