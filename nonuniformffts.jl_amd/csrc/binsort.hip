@@ -41,15 +41,56 @@ __device__ __forceinline__ uint32_t tile_of_point(const BinArgs<T, D>& a, int64_
     return bin;
 }
 
+// Histogram + rank.  A workgroup first aggregates the bins of a chunk of points in an LDS hash table (key =
+// bin, value = count; the slot's running count is the point's rank inside the chunk), then issues ONE global
+// atomic per distinct bin of the chunk, and finally combines the returned base with the local ranks.  For
+// well-spread points almost every bin of a chunk is distinct and this costs the same number of global atomics
+// as one atomic per point; for clustered points (all 1e7 points in a few bins: 14.5 ms of same-address
+// atomics before) it removes the contention.
+constexpr int kCountThreads = 256;
+constexpr int kCountPPT = 4;                               // points per thread and chunk
+constexpr int kCountSlots = 2048;                          // hash slots (load factor <= 0.5)
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+
 template <typename T, int D>
-__global__ __launch_bounds__(256) void bin_count_kernel(BinArgs<T, D> a, uint32_t* __restrict__ counts,
-                                                       uint2* __restrict__ binrank) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.np; p += stride) {
-        T r[D];
-        const uint32_t tile = tile_of_point<T, D>(a, p, r);
-        const uint32_t rank = atomicAdd(&counts[tile], 1u);
-        binrank[p] = make_uint2(tile, rank);
+__global__ __launch_bounds__(kCountThreads) void bin_count_kernel(BinArgs<T, D> a, uint32_t* __restrict__ counts,
+                                                                 uint2* __restrict__ binrank) {
+    __shared__ uint32_t keys[kCountSlots], cnt[kCountSlots], base[kCountSlots];
+    constexpr int kChunkPts = kCountThreads * kCountPPT;
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (a.np + kChunkPts - 1) / kChunkPts;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        for (int s = tid; s < kCountSlots; s += kCountThreads) { keys[s] = kEmptyKey; cnt[s] = 0; }
+        __syncthreads();
+        uint32_t bin[kCountPPT], lrank[kCountPPT];
+        int slot[kCountPPT];
+#pragma unroll
+        for (int k = 0; k < kCountPPT; ++k) {
+            const int64_t p = chunk * kChunkPts + (int64_t)k * kCountThreads + tid;
+            slot[k] = -1;
+            if (p < a.np) {
+                T r[D];
+                bin[k] = tile_of_point<T, D>(a, p, r);
+                int h = (int)((bin[k] * 2654435761u) >> 21);              // 11 bits
+                for (;;) {
+                    const uint32_t old = atomicCAS(&keys[h], kEmptyKey, bin[k]);
+                    if (old == kEmptyKey || old == bin[k]) break;
+                    h = (h + 1) & (kCountSlots - 1);
+                }
+                slot[k] = h;
+                lrank[k] = atomicAdd(&cnt[h], 1u);
+            }
+        }
+        __syncthreads();
+        for (int s = tid; s < kCountSlots; s += kCountThreads)
+            if (keys[s] != kEmptyKey) base[s] = atomicAdd(&counts[keys[s]], cnt[s]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kCountPPT; ++k) {
+            const int64_t p = chunk * kChunkPts + (int64_t)k * kCountThreads + tid;
+            if (slot[k] >= 0) binrank[p] = make_uint2(bin[k], base[slot[k]] + lrank[k]);
+        }
+        __syncthreads();
     }
 }
 
@@ -81,10 +122,9 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(s.counts, 0, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
     if (e != hipSuccess) return e;
     if (s.np > 0) {
-        const int threads = 256;
-        int64_t blocks = (s.np + threads - 1) / threads;
-        if (blocks > 256 * 32) blocks = 256 * 32;
-        hipLaunchKernelGGL((bin_count_kernel<T, D>), dim3((unsigned)blocks), dim3(threads), 0, stream, a, s.counts,
+        int64_t blocks = (s.np + kCountThreads * kCountPPT - 1) / (kCountThreads * kCountPPT);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL((bin_count_kernel<T, D>), dim3((unsigned)blocks), dim3(kCountThreads), 0, stream, a, s.counts,
                            static_cast<uint2*>(s.binrank));
     }
     size_t tmp = s.scan_tmp_bytes;
