@@ -38,6 +38,9 @@
 #ifndef NUFFT_W3_READLANE
 #define NUFFT_W3_READLANE 1
 #endif
+#ifndef NUFFT_SPREAD_ASM_STRIP
+#define NUFFT_SPREAD_ASM_STRIP 1    // compile-time-tile spreading: the strip reads of two points issued together (inline asm)
+#endif
 #ifndef NUFFT_INTERP_ASM_READS
 #define NUFFT_INTERP_ASM_READS 1    // compile-time-tile interpolation: hand-scheduled LDS reads with immediate offsets
 #endif
@@ -277,6 +280,54 @@ __device__ __forceinline__ void lds_add_planes(double* p, T w, const T (&w3)[L],
     (lds_add_imm<J * PLANE_BYTES>(addr, (double)(w * w3[J])), ...);
 }
 
+// Hand-scheduled LDS reads for the interpolation gather of the compile-time-tile variant: one base address,
+// immediate offsets (no address arithmetic) and explicit s_waitcnt, written as inline assembly so that the
+// compiler can neither pair them into ds_read2_b64 (whose two addresses share banks at an unaligned row
+// stride) nor serialise them.  The caller keeps at most two planes (2 * 2M reads) in flight.
+template <typename T, int OFF>
+__device__ __forceinline__ void lds_read_imm(T& dst, uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "LDS immediate offset out of range");
+    if constexpr (sizeof(T) == 8) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+    else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <typename T, int R, int FIRST_OFF, int ROW_BYTES, int... J>
+__device__ __forceinline__ void lds_read_rows(T (&b)[R], uint32_t addr, std::integer_sequence<int, J...>) {
+    (lds_read_imm<T, FIRST_OFF + J * ROW_BYTES>(b[J], addr), ...);
+}
+// wait until at most PENDING LDS operations are outstanding; the registers are operands so that their
+// consumers are ordered after the wait
+template <int PENDING, typename T, int R>
+__device__ __forceinline__ void lds_wait_rows(T (&b)[R]) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING));
+#pragma unroll
+    for (int j = 0; j < R; ++j) asm volatile("" : "+v"(b[j]));
+}
+
+// Row groups G, G + 1, ... of R rows each (group g = rows (g % (L / R)) * R ... of plane g / (L / R)):
+// `cur` was requested by the caller; request group G + 1 into `nxt`, wait for `cur`, consume it, swap.
+template <typename T, int L, int R, int PB, int RB, int G, typename F>
+__device__ __forceinline__ void interp_row_groups(T (&cur)[R], T (&nxt)[R], uint32_t baddr, F&& consume) {
+    constexpr int GPP = L / R, NG = L * GPP;
+    if constexpr (G + 1 < NG) {
+        lds_read_rows<T, R, ((G + 1) / GPP) * PB + ((G + 1) % GPP) * R * RB, RB>(nxt, baddr, std::make_integer_sequence<int, R>{});
+        lds_wait_rows<R>(cur);              // the R reads of group G + 1 may still be in flight
+        consume(cur, G);
+        interp_row_groups<T, L, R, PB, RB, G + 1>(nxt, cur, baddr, consume);
+    } else {
+        lds_wait_rows<0>(cur);
+        consume(cur, G);
+    }
+}
+
+// f(std::integral_constant<int, G0>) for G0 = 0, 2, 4, ... < N
+template <int G0, int N, typename F>
+__device__ __forceinline__ void for_each_pair(F&& f) {
+    if constexpr (G0 < N) {
+        f(std::integral_constant<int, G0>{});
+        for_each_pair<G0 + 2, N>(f);
+    }
+}
+
 // Splits the `nruns` runs of the item table (uint2 = [first, last) of the sorted array) in place into
 // work items: every run is cut into c * nslices pieces (c such that a slice has about kItemTarget
 // items; piece lengths a multiple of `ppw` points: full chunks), of which this workgroup — slice `slice`
@@ -490,23 +541,20 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
             wave_lds_fence();
 
 #if !defined(NUFFT_ABL_NO_VISIT)
-#pragma unroll
-            for (int gi = 0; gi < GP::PPW; ++gi) {
+            // one point of the chunk: w1v / w2v are the lane's window values of dimensions 1 and 2 (per pass),
+            // w3a the lane's share of the dimension-3 values (value l & 15 in lane l of every 16-lane row)
+            auto do_point = [&](int gi, const T (&w1v)[NPASS], const T (&w2v)[NPASS], T w3a) {
                 const int src = gi * GP::G;                    // first lane of the point's group
-                if (!((okmask >> src) & 1ull)) continue;
+                if (!((okmask >> src) & 1ull)) return;
                 const int S1 = __builtin_amdgcn_readlane(s[0], src);
                 const int S2 = D >= 2 ? __builtin_amdgcn_readlane(s[1], src) : 0;
                 const int S3 = D >= 3 ? __builtin_amdgcn_readlane(s[2], src) : 0;
                 const T Vre = readlane_t(vmine, src);
                 const T Vim = CPLX ? readlane_t(vmine, src + (CPLX ? 1 : 0)) : T(0);
                 const T* sp = strip_wave + gi * (D * L);
-                // the 2M window values of dimension 3: identical in every lane (broadcast LDS reads)
+                // the 2M window values of dimension 3 by DPP row broadcasts: one VALU instruction per value
                 T w3[L];
                 if constexpr (D >= 3) {
-#if NUFFT_W3_READLANE
-                    // one LDS read per 16 window values (lane l of a row holds value l), then DPP row
-                    // broadcasts: one VALU instruction per value instead of two v_readlane_b32
-                    const T w3a = sp[2 * L + min(lane & 15, L - 1)];
                     T w3b = T(0);
                     if constexpr (L > 16) w3b = sp[2 * L + min(16 + (lane & 15), L - 1)];
                     if constexpr (L <= 16) {
@@ -515,10 +563,6 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
 #pragma unroll
                         for (int j = 0; j < L; ++j) w3[j] = j < 16 ? row_bcast(w3a, j) : row_bcast(w3b, j - 16);
                     }
-#else
-#pragma unroll
-                    for (int j = 0; j < L; ++j) w3[j] = sp[2 * L + j];
-#endif
                 }
                 // valid planes as a bit mask (bit j3 set: plane S3 + j3 lies inside the tile).  One scalar
                 // unit serves the whole CU, so the per-plane control is kept to a bit test + branch.
@@ -537,13 +581,13 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                     int l1 = S1 + j1f[ps];
                     if (WRAP && wrapd[0]) { if (l1 < 0) l1 += g.Nover[0]; if (l1 >= g.Nover[0]) l1 -= g.Nover[0]; }
                     bool lane_ok = actf[ps] && (unsigned)l1 < (unsigned)neff[0];
-                    T w = sp[j1f[ps]] * (CPLX ? (cmpf[ps] ? Vim : Vre) : Vre);
+                    T w = w1v[ps] * (CPLX ? (cmpf[ps] ? Vim : Vre) : Vre);
                     A* addr = tile + l1 * NC + cmpf[ps];
                     if constexpr (D >= 2) {
                         int l2 = S2 + j2f[ps];
                         if (WRAP && wrapd[1]) { if (l2 < 0) l2 += g.Nover[1]; if (l2 >= g.Nover[1]) l2 -= g.Nover[1]; }
                         lane_ok = lane_ok && (unsigned)l2 < (unsigned)neff[1];
-                        w *= sp[L + j2f[ps]];
+                        w *= w2v[ps];
                         addr += l2 * RS;
                     }
                     if constexpr (D <= 2) {
@@ -583,6 +627,41 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                         }
                     }
                 }
+            };
+            if constexpr (FIXEDT && NUFFT_SPREAD_ASM_STRIP && NPASS == 1 && D == 3 && L <= 16 && GP::PPW % 2 == 0) {
+                // The three strip reads of a point are issued together for two points at a time, from inline
+                // assembly (the compiler otherwise sinks two of them behind the lane-mask branch, which costs a
+                // second LDS round trip per point), followed by one wait.
+                const uint32_t sb1 = (uint32_t)(uintptr_t)(strip_wave + j1f[0]);
+                const uint32_t sb2 = (uint32_t)(uintptr_t)(strip_wave + L + j2f[0]);
+                const uint32_t sb3 = (uint32_t)(uintptr_t)(strip_wave + 2 * L + min(lane & 15, L - 1));
+                constexpr int PB = D * L * (int)sizeof(T);     // bytes between the strips of consecutive points
+                for_each_pair<0, GP::PPW>([&](auto G0c) {
+                    constexpr int g0 = decltype(G0c)::value;
+                    T pre[6];
+                    lds_read_imm<T, (g0 + 0) * PB>(pre[0], sb1);
+                    lds_read_imm<T, (g0 + 0) * PB>(pre[1], sb2);
+                    lds_read_imm<T, (g0 + 0) * PB>(pre[2], sb3);
+                    lds_read_imm<T, (g0 + 1) * PB>(pre[3], sb1);
+                    lds_read_imm<T, (g0 + 1) * PB>(pre[4], sb2);
+                    lds_read_imm<T, (g0 + 1) * PB>(pre[5], sb3);
+                    lds_wait_rows<0>(pre);
+                    { const T a1[1] = {pre[0]}, a2[1] = {pre[1]}; do_point(g0, a1, a2, pre[2]); }
+                    { const T a1[1] = {pre[3]}, a2[1] = {pre[4]}; do_point(g0 + 1, a1, a2, pre[5]); }
+                });
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < GP::PPW; ++gi) {
+                    const T* sp = strip_wave + gi * (D * L);
+                    T w1v[NPASS], w2v[NPASS];
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        w1v[ps] = sp[j1f[ps]];
+                        w2v[ps] = D >= 2 ? sp[L + j2f[ps]] : T(1);
+                    }
+                    const T w3a = D >= 3 ? sp[2 * L + min(lane & 15, L - 1)] : T(0);
+                    do_point(gi, w1v, w2v, w3a);
+                }
             }
 #else
             asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(vmine));
@@ -618,45 +697,6 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                 if (v != T(0)) (void)__hip_atomic_fetch_add(&grid[rowbase + e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-    }
-}
-
-// Hand-scheduled LDS reads for the interpolation gather of the compile-time-tile variant: one base address,
-// immediate offsets (no address arithmetic) and explicit s_waitcnt, written as inline assembly so that the
-// compiler can neither pair them into ds_read2_b64 (whose two addresses share banks at an unaligned row
-// stride) nor serialise them.  The caller keeps at most two planes (2 * 2M reads) in flight.
-template <typename T, int OFF>
-__device__ __forceinline__ void lds_read_imm(T& dst, uint32_t addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "LDS immediate offset out of range");
-    if constexpr (sizeof(T) == 8) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-    else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <typename T, int R, int FIRST_OFF, int ROW_BYTES, int... J>
-__device__ __forceinline__ void lds_read_rows(T (&b)[R], uint32_t addr, std::integer_sequence<int, J...>) {
-    (lds_read_imm<T, FIRST_OFF + J * ROW_BYTES>(b[J], addr), ...);
-}
-// wait until at most PENDING LDS operations are outstanding; the registers are operands so that their
-// consumers are ordered after the wait
-template <int PENDING, typename T, int R>
-__device__ __forceinline__ void lds_wait_rows(T (&b)[R]) {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING));
-#pragma unroll
-    for (int j = 0; j < R; ++j) asm volatile("" : "+v"(b[j]));
-}
-
-// Row groups G, G + 1, ... of R rows each (group g = rows (g % (L / R)) * R ... of plane g / (L / R)):
-// `cur` was requested by the caller; request group G + 1 into `nxt`, wait for `cur`, consume it, swap.
-template <typename T, int L, int R, int PB, int RB, int G, typename F>
-__device__ __forceinline__ void interp_row_groups(T (&cur)[R], T (&nxt)[R], uint32_t baddr, F&& consume) {
-    constexpr int GPP = L / R, NG = L * GPP;
-    if constexpr (G + 1 < NG) {
-        lds_read_rows<T, R, ((G + 1) / GPP) * PB + ((G + 1) % GPP) * R * RB, RB>(nxt, baddr, std::make_integer_sequence<int, R>{});
-        lds_wait_rows<R>(cur);              // the R reads of group G + 1 may still be in flight
-        consume(cur, G);
-        interp_row_groups<T, L, R, PB, RB, G + 1>(nxt, cur, baddr, consume);
-    } else {
-        lds_wait_rows<0>(cur);
-        consume(cur, G);
     }
 }
 
