@@ -154,6 +154,34 @@ def test_nonuniform_distributions_spot_check_and_balance(dist):
     assert float((out - out0).norm() / out0.norm()) < 1e-13
 
 
+def test_c2_full_grid_rel_l2_against_c_oracle():
+    """Full rel-L2 over all 129 x 256 x 256 output modes of a C2-size transform (256^3, sigma = 2, m = 4, Float64;
+    Np = 4e6 to keep the CPU side at a few seconds) against the C restatement of the reference's blocked CPU
+    algorithm (oracle/nufft_oracle.c + pocketfft), and of type 2 over all points."""
+    from oracle import c_oracle as CO, nufft_oracle as O
+    from nufft_pkg import nufft
+    if not CO.available():
+        pytest.skip("oracle/libnufft_oracle.so not built")
+    Np = 4_000_000
+    rng = np.random.default_rng(2024)
+    xs = [rng.random(Np) * O.TWO_PI for _ in range(3)]
+    v = rng.standard_normal(Np)
+    oplan = O.OraclePlan((N, N, N), is_real=True, M=M, sigma=SIGMA, evalmode=O.FAST_APPROXIMATION)
+    O.set_points(oplan, xs)
+    ref = CO.exec_type1(oplan, v)
+    plan = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, backend=nufft.ROCBackend(0),
+                           kernel_evalmode=nufft.FastApproximation())
+    nufft.set_points(plan, tuple(torch.from_numpy(x).cuda() for x in xs))
+    u = torch.empty(plan.shape, dtype=torch.complex128, device="cuda")
+    nufft.exec_type1(u, plan, torch.from_numpy(v).cuda())
+    got = u.cpu().numpy()
+    assert np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel()) < 1e-11
+    out = torch.empty(Np, dtype=torch.float64, device="cuda")
+    nufft.exec_type2(out, plan, u)
+    ref2 = CO.exec_type2(oplan, got)
+    assert np.linalg.norm(out.cpu().numpy() - ref2) / np.linalg.norm(ref2) < 1e-11
+
+
 def test_config_c4_ntransforms3_spot_check():
     """BASELINE config C4: C2 with ntransforms = 3 (three value vectors spread / interpolated simultaneously,
     one set of points).  Exact spot checks per component; component c must equal a single transform of v_c."""
