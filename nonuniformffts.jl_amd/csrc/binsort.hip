@@ -112,6 +112,28 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs<T, D> a, const
     }
 }
 
+// Zero fill of the histogram as a kernel rather than hipMemsetAsync: a captured hipGraph that holds a memset node
+// faults on replay once other work has run in between (ROCm 7.2, scripts/graph_probe.py), kernel nodes do not.
+__global__ void zero_fill_kernel(uint4* __restrict__ dst, int64_t n16, uint32_t* __restrict__ tail, int ntail) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = first; i < n16; i += stride) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (first < ntail) tail[first] = 0u;
+}
+
+// dst: 16-byte aligned, bytes: multiple of 4
+hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    const int64_t n16 = (int64_t)(bytes / 16);
+    const int ntail = (int)((bytes % 16) / 4);
+    int64_t blocks = (n16 + 1023) / 1024;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<uint4*>(dst), n16,
+                       reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(dst) + n16 * 16), ntail);
+    return hipGetLastError();
+}
+
 template <typename T, int D>
 static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
     BinArgs<T, D> a;
@@ -119,7 +141,7 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
     a.np = s.np;
     a.g = s.g;
     a.point_transform = s.point_transform;
-    hipError_t e = hipMemsetAsync(s.counts, 0, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
+    hipError_t e = launch_zero_fill(s.counts, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
     if (e != hipSuccess) return e;
     if (s.np > 0) {
         int64_t blocks = (s.np + kCountThreads * kCountPPT - 1) / (kCountThreads * kCountPPT);

@@ -26,6 +26,8 @@ struct SortArgs {
 size_t binsort_scan_tmp_bytes(int nbins);
 size_t point_record_bytes(int dtype, int D);
 hipError_t launch_binsort(const SortArgs& s, hipStream_t stream);
+// zero fill by a kernel (hipGraph-safe, see binsort.hip); dst 16-byte aligned, bytes a multiple of 4
+hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);
 hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np, int32_t* perm_dev, hipStream_t stream);
 
 // ---- load balance (balance.hip) ----------------------------------------------------------------------

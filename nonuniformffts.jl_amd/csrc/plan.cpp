@@ -935,7 +935,7 @@ int nufft_fill_zeros(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_ZERO, stream);
-    NUFFT_HIP(hipMemsetAsync(p->d_us, 0, (size_t)p->grid_elems * value_bytes(p) * p->C, stream));
+    NUFFT_HIP(launch_zero_fill(p->d_us, (size_t)p->grid_elems * value_bytes(p) * p->C, stream));
     return NUFFT_OK;
 }
 

@@ -1,0 +1,84 @@
+"""hipGraph capture of the hot path.
+
+set_points! / exec_type1! / exec_type2! only enqueue work on the stream they are given (no allocation once the plan has
+seen a point set of that size, no host read-back, no synchronisation), so the whole sequence can be captured into a
+hipGraph once and replayed on new data in the same buffers — what a launch-bound caller (many small transforms) wants.
+The reference has no counterpart (KernelAbstractions launches eagerly); the parity bar is the same as for eager calls:
+GPU vs CPU oracle, rtol 1e-7 (Float64) / 1e-5 (Float32) on the 2-norm (test/pseudo_gpu.jl:159-171).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import nufft_oracle as O  # noqa: E402
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+
+
+@pytest.mark.parametrize("Z,dims,sigma,evalmode", [
+    (np.float64, (256,), 2.0, O.DIRECT),                     # C1 shape: rocFFT inside the captured sequence
+    (np.float64, (48, 40), 1.5, O.FAST_APPROXIMATION),       # general path (rocFFT + deconvolution kernels)
+    (np.float64, (32, 32, 32), 2.0, O.FAST_APPROXIMATION),   # pruned FFT passes
+    (np.complex64, (32, 64, 32), 2.0, O.DIRECT),
+])
+def test_graph_replay_matches_oracle_on_new_data(Z, dims, sigma, evalmode):
+    from nufft_pkg import nufft
+    Zt = np.dtype(Z)
+    is_real = Zt.kind == "f"
+    T = np.float32 if Zt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    Np = 3000
+    mode = nufft.Direct() if evalmode == O.DIRECT else nufft.FastApproximation()
+    plan = nufft.PlanNUFFT(Zt, dims, m=4, sigma=sigma, kernel_evalmode=mode, backend=nufft.ROCBackend(0))
+    oplan = O.OraclePlan(dims, is_real=is_real, dtype=T, M=4, sigma=sigma, evalmode=evalmode)
+    dev = plan.device
+
+    def inputs(seed):
+        rng = np.random.default_rng(seed)
+        xs = [((rng.random(Np) * 3 - 1) * O.TWO_PI).astype(T) for _ in dims]
+        v = rng.standard_normal(Np) if is_real else rng.standard_normal(Np) + 1j * rng.standard_normal(Np)
+        return xs, v.astype(Zt)
+
+    xs0, v0 = inputs(1)
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs0)
+    vd = torch.from_numpy(v0).to(dev)
+    ud = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    wd = torch.empty(Np, dtype=plan.Z, device=dev)
+
+    def step():
+        nufft.set_points(plan, xd)
+        nufft.exec_type1(ud, plan, vd)
+        nufft.exec_type2(wd, plan, ud)       # type 2 of the type-1 result: the graph chains both transforms
+
+    step()                                   # sizes the plan's point buffers (allocation is not capturable)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+
+    tol = 1e-7 if T == np.float64 else 1e-5
+    for seed in (2, 3):
+        xs, v = inputs(seed)
+        for d in range(len(dims)):
+            xd[d].copy_(torch.from_numpy(xs[d]))     # eager work between replays (new data, same buffers)
+        vd.copy_(torch.from_numpy(v))
+        ud.zero_(); wd.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        O.set_points(oplan, xs)
+        ref1 = O.exec_type1(oplan, v)
+        assert _rel(ud.cpu().numpy(), ref1) < tol
+        ref2 = O.exec_type2(oplan, ref1.astype(np.complex64 if T == np.float32 else np.complex128))
+        assert _rel(wd.cpu().numpy(), ref2) < tol
+    # many replays back to back, then an eager call on the same plan
+    for _ in range(20):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert _rel(wd.cpu().numpy(), ref2) < tol
+    step()
+    torch.cuda.synchronize()
+    assert _rel(wd.cpu().numpy(), ref2) < tol
