@@ -784,7 +784,15 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         // U rows per wave are in flight at once: all global loads of a batch are issued before the first
         // LDS store waits for them (one row at a time leaves the load latency fully exposed — with one
         // workgroup per CU nothing else hides it).
-        constexpr int U = 8;
+#ifndef NUFFT_INTERP_LOAD_ROUNDS
+#define NUFFT_INTERP_LOAD_ROUNDS 1
+#endif
+        // compile-time tile: as many rows per wave as it takes to load the tile in NUFFT_INTERP_LOAD_ROUNDS rounds
+        // (a mostly empty last round costs a full memory round trip)
+        constexpr int ROWS_PER_ROUND1 = 16 * (NC * (FD.n[0] + L - 1) <= 32 ? 2 : 1);   // 16 waves, U = 1
+        constexpr int ROWS_FIXED = (FD.n[1] + (D >= 2 ? L - 1 : 0)) * (FD.n[2] + (D >= 3 ? L - 1 : 0));
+        constexpr int U_FIXED = (ROWS_FIXED + ROWS_PER_ROUND1 * NUFFT_INTERP_LOAD_ROUNDS - 1) / (ROWS_PER_ROUND1 * NUFFT_INTERP_LOAD_ROUNDS);
+        constexpr int U = (FIXED && U_FIXED >= 4 && U_FIXED <= 18) ? U_FIXED : 8;
         const int w_row = NC * P[0];
         RowWalker rw(P[1], P[2], w_row, wave, nwaves, lane);
         const int o1 = org[0] - (M - 1), o2 = org[1] - (M - 1), o3 = org[2] - (M - 1);
