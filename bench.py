@@ -87,12 +87,37 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run
+    as a CHILD process — before this process has touched the GPU — relay their output (rank 0 prints the
+    JSON line) and exit with the child's code.  Never re-executes a process that has initialised HIP."""
+    import socket
+    import subprocess
+    n_visible = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if n_visible < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_visible} GPU(s) visible on this node; refusing to run "
+                         f"a smaller job under that name")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     a = parse()
+    if "RANK" not in os.environ and (a.gpus > 1 or a.force_distributed):
+        launch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or (a.force_distributed and "RANK" in os.environ)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
+    distributed = world > 1 or a.force_distributed
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
