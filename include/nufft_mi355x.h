@@ -102,13 +102,18 @@ typedef struct nufft_params {
     int32_t interp_threads;  /* workgroup size of the interpolation kernel                         */
     int32_t interp_tile_dims[3]; /* interpolation tile interior (cells)                            */
     int32_t bin_log2;        /* log2 of the bin edge of the point sort (default 2: 4^D cells)      */
-    int32_t reserved0;
+    int32_t spread_method;   /* NUFFT_SPREAD_* (0 = automatic: MFMA patches where they apply)       */
     double  kernel_param;    /* KaiserBesselKernel(β) / BackwardsKaiserBesselKernel(β) / GaussianKernel(ℓ):
                                 explicit shape parameter; 0 -> the optimal one for (M, σ)              */
     int32_t reserved[2];
 } nufft_params;
 
 /* What show(::PlanNUFFT) prints (src/plan.jl:362-392) plus sizes a caller needs. */
+/* Spreading engines (nufft_info.spread_method; nufft_params.spread_method selects, 0 = automatic):
+ *   LDS tiles    — output-driven LDS tile with native ds_add_f64 (every D, M, kernel, grid size)
+ *   MFMA patches — register-resident patches accumulated by v_mfma_f64_4x4x4_4b (3-D grids of 4-cell bins) */
+enum { NUFFT_SPREAD_AUTO = 0, NUFFT_SPREAD_LDS_TILES = 1, NUFFT_SPREAD_MFMA_PATCHES = 2 };
+
 typedef struct nufft_info {
     int32_t dtype, is_complex, ndim, half_support, ntransforms, evalmode, fftshift, device;
     int64_t N[3];            /* Ns                                                                 */
@@ -129,7 +134,8 @@ typedef struct nufft_info {
     int32_t npoly;           /* M + 4 polynomial coefficients per sub-interval                     */
     int32_t window_scale_log2[3]; /* device windows and phi_hat are scaled by 2^k_d (exact) */
     int32_t kernel;          /* NUFFT_KERNEL_*                                                     */
-    int32_t reserved[3];
+    int32_t spread_max_items, interp_max_items; /* capacity of the per-tile work-item tables (runs of sorted points) */
+    int32_t spread_method;   /* NUFFT_SPREAD_LDS_TILES or NUFFT_SPREAD_MFMA_PATCHES (what nufft_spread launches)      */
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */

@@ -42,7 +42,7 @@ class NufftParams(C.Structure):
         ("tile_dims", C.c_int32 * 3),
         ("lds_budget_bytes", C.c_int32), ("spread_threads", C.c_int32), ("interp_threads", C.c_int32),
         ("interp_tile_dims", C.c_int32 * 3), ("bin_log2", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("spread_method", C.c_int32),
         ("kernel_param", C.c_double),
         ("reserved", C.c_int32 * 2),
     ]
@@ -64,7 +64,8 @@ class NufftInfo(C.Structure):
         ("spread_threads", C.c_int32), ("interp_threads", C.c_int32),
         ("lds_bytes_spread", C.c_int64), ("lds_bytes_interp", C.c_int64),
         ("workspace_bytes", C.c_int64), ("num_points", C.c_int64),
-        ("npoly", C.c_int32), ("window_scale_log2", C.c_int32 * 3), ("kernel", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("npoly", C.c_int32), ("window_scale_log2", C.c_int32 * 3), ("kernel", C.c_int32),
+        ("spread_max_items", C.c_int32), ("interp_max_items", C.c_int32), ("spread_method", C.c_int32),
     ]
 
 

@@ -192,6 +192,26 @@ constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int tile_elem
     return l;
 }
 
+// Upper bound of the runs of the sorted array (work items before splitting) a tile looks up, from the same
+// arithmetic as the kernels.  Spreading (output-driven): the bins that cover the cells [org - M, org + n + M - 1)
+// of dimensions 2 and 3 — n / b + ceil(M / b) + floor((M - 2) / b) + 1 bin rows for a tile edge n that is a multiple
+// of the bin edge b (at most all nb bins of the axis) — times the two runs of a tile that wraps around dimension 1.
+// Interpolation: the tile's own bins.  nb = nullptr: grid unknown (compile-time tiles).
+constexpr __host__ __device__ int tile_bin_rows_bound(bool spreading, int n, int b, int M) {
+    if (!spreading) return (n + b - 1) / b + 1;
+    return (n + b - 1) / b + (M + b - 1) / b + (M >= 2 ? (M - 2) / b : 0) + 1;
+}
+constexpr __host__ __device__ long tile_items_bound(bool spreading, int D, int M, int b, const int (&n)[3], const int* nb) {
+    long items = spreading ? 2 : 1;
+    for (int d = 1; d < D; ++d) {
+        long rows = tile_bin_rows_bound(spreading, n[d], b, M);
+        if (nb && rows > nb[d]) rows = nb[d];
+        items *= rows;
+    }
+    return items + kItemTarget;      // room for splitting long runs (split_work_items)
+}
+constexpr int kMaxTileItems = 4096;
+
 // Compile-time interpolation tile for large grids (every edge shorter than the axis), 1024 threads and
 // the full 160 KiB of LDS: with constant row/plane strides all 2M x 2M LDS reads of a point use immediate
 // offsets from one base address.  Same cost model as the run-time search in plan_math.cpp (halo
@@ -210,9 +230,6 @@ constexpr __host__ __device__ int padded_row_stride(int inner_elems, int stencil
 struct FixedTileDims { int n[3]; int row_stride; };
 constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, int ncomp, int D, int M) {
     const int L = 2 * M, halo = L - 1, b = 4, nwaves = 16;
-    const int ppw = kWave / lanes_per_point(ncomp, M);
-    const int strips = nwaves * round_up(ppw * D * L * elem_bytes, 16) + 6144;
-    const long avail = (163840 - 256 - strips) / elem_bytes;
     const int cap = D == 1 ? 8192 : 96;
     FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0};
     double best_cost = 1e300;
@@ -221,7 +238,10 @@ constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, in
             for (int n1 = b; n1 <= cap; n1 += b) {
                 const int rs = ncomp * (n1 + halo);      // rows unpadded: LDS capacity beats bank alignment here
                 const long elems = (long)rs * (D >= 2 ? n2 + halo : 1) * (D >= 3 ? n3 + halo : 1);
-                if (elems > avail) break;
+                const int nn[3] = {n1, n2, n3};
+                const long items = tile_items_bound(false, D, M, b, nn, nullptr);
+                if (elems * elem_bytes > 163840 || items > kMaxTileItems ||
+                    lds_layout((int)elems, elem_bytes, elem_bytes, D, M, ncomp, nwaves, (int)items).total > 163840 - 256) break;
                 double cost = (double)(n1 + halo) / n1;
                 if (D >= 2) cost *= (double)(n2 + halo) / n2;
                 if (D >= 3) cost *= (double)(n3 + halo) / n3;
@@ -235,9 +255,6 @@ constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, in
 // same cost model as the run-time search (point visits per point); row stride padded for the LDS banks.
 constexpr __host__ __device__ FixedTileDims fixed_spread_tile(int real_bytes, int ncomp, int D, int M) {
     const int L = 2 * M, halo = L - 1, b = 4, nwaves = 16;
-    const int ppw = kWave / lanes_per_point(ncomp, M);
-    const int strips = nwaves * round_up(ppw * D * L * real_bytes, 16) + 6144;
-    const long avail = (163840 - 256 - strips) / 8;
     const int cap = D == 1 ? 8192 : 96;
     FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0};
     double best_cost = 1e300;
@@ -246,7 +263,10 @@ constexpr __host__ __device__ FixedTileDims fixed_spread_tile(int real_bytes, in
             for (int n1 = b; n1 <= cap; n1 += b) {
                 const int rs = D >= 2 ? padded_row_stride(ncomp * n1, ncomp * L, 8) : ncomp * n1;
                 const long elems = (long)rs * (D >= 2 ? n2 : 1) * (D >= 3 ? n3 : 1);
-                if (elems > avail) break;
+                const int nn[3] = {n1, n2, n3};
+                const long items = tile_items_bound(true, D, M, b, nn, nullptr);
+                if (elems * 8 > 163840 || items > kMaxTileItems ||
+                    lds_layout((int)elems, 8, real_bytes, D, M, ncomp, nwaves, (int)items).total > 163840 - 256) break;
                 double cost = (double)(n1 + halo) / n1;
                 if (D >= 2) cost *= (double)(n2 + halo) / n2;
                 if (D >= 3) cost *= (double)(n3 + halo) / n3;
@@ -302,6 +322,10 @@ __device__ __forceinline__ T sinh_over_x(T x) {
         return fma(p, z, T(1));
     }
     const T e = exp_pos(x);
+    if constexpr (sizeof(T) == 4) {
+        // Float32: e * e overflows for x > 44 (beta = 46.9 at M = 10, sigma = 2)
+        return T(0.5) * (e - T(1) / e) / x;
+    }
     return T(0.5) * fma(e, e, T(-1)) / (e * x);               // (e - 1/e) / (2x) with a single division
 }
 

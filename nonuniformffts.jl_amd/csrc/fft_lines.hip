@@ -400,11 +400,26 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
 // grids).  Other products of 2, 3 and 5 use the general rocFFT path.
 #define NUFFT_FFT_SIZES(X) X(64) X(80) X(96) X(128) X(160) X(192) X(256) X(320) X(384) X(512) X(640) X(768) X(1024)
 
+constexpr size_t kFftLdsLimit = 160 * 1024;      // gfx950: LDS per workgroup
+
+// lines per workgroup of the dimension-1 real passes: 16 below 150 KiB, else as many as fit (Float64 lines of
+// 2 x 1024 need 4: 8 would take 172 KB)
+template <typename T, int M>
+constexpr int real_lines_per_group() {
+    constexpr size_t c = 2 * sizeof(T);
+    constexpr int LINE = M + (M >> 4) + 1;
+    if (c * (16 * LINE + 2 * M) <= 150 * 1024) return 16;
+    if (c * (8 * LINE + 2 * M) <= kFftLdsLimit) return 8;
+    if (c * (4 * LINE + 2 * M) <= kFftLdsLimit) return 4;
+    return 0;
+}
+
 template <typename T, int M, bool FWD>
 static hipError_t launch_real_m(const RealLineArgs& a, hipStream_t stream) {
     using C = typename Cplx2<T>::type;
     constexpr int LINE = M + (M >> 4) + 1;
-    constexpr int TL = (sizeof(C) * (16 * LINE + 2 * M) <= 150 * 1024) ? 16 : 8;
+    constexpr int TL = real_lines_per_group<T, M>();
+    static_assert(TL >= 4 && sizeof(C) * (size_t)(TL * LINE + 2 * M) <= kFftLdsLimit, "line buffers exceed the 160 KiB of LDS");
     const size_t lds = sizeof(C) * (size_t)(TL * LINE + 2 * M);
     auto fn = real_lines_kernel<T, M, FWD, TL>;
     // the attribute is per device: remember which devices of this process have it (plans may live on several)
@@ -461,6 +476,7 @@ static hipError_t launch_cplx_n(const CplxLineArgs& a, hipStream_t stream) {
     using C = typename Cplx2<T>::type;
     constexpr int LINE = N + (N >> 4) + 1;
     constexpr int TL = (sizeof(C) * (16 * LINE + N) <= 80 * 1024) ? 16 : 8;
+    static_assert(sizeof(C) * (size_t)(TL * LINE + N) <= kFftLdsLimit, "line buffers exceed the 160 KiB of LDS");
     const size_t lds = sizeof(C) * (size_t)(TL * LINE + N);
     auto fn = cplx_lines_kernel<T, N, FWD, TL>;
     static std::atomic<unsigned long long> prepared{0};
@@ -503,6 +519,7 @@ static hipError_t launch_n_m(const FftLineArgs& a, hipStream_t stream) {
 #define NUFFT_FFT_LDS_LIMIT (80 * 1024)      // two workgroups per CU (70 KB at N = 512 Float64) beat one with 16 lines: measured
 #endif
     constexpr int TA = (sizeof(C) * (16 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 16 : ((sizeof(C) * (8 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 8 : 4);
+    static_assert(sizeof(C) * (size_t)(TA * LINE + N) <= kFftLdsLimit, "line buffers exceed the 160 KiB of LDS");
     const size_t lds = sizeof(C) * (size_t)(TA * LINE + N);
     auto fn = fft_lines_kernel<T, N, FWD, TA, MULT>;
     // the attribute is per device: remember which devices of this process have it (plans may live on several)

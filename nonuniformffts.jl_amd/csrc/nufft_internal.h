@@ -108,6 +108,7 @@ struct nufft_plan {
     nufft::TileGeom tile;
     bool interp_fixed = false;         // tile.ip is the compile-time tile of the kernel instantiation
     bool spread_fixed = false;         // tile.sp likewise
+    int spread_method = NUFFT_SPREAD_LDS_TILES;   // what nufft_spread launches (NUFFT_SPREAD_*)
     int64_t lds_spread = 0, lds_interp = 0;
 
     // device data

@@ -273,7 +273,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     // Default configuration on a large grid: take the compile-time interpolation tile, whose kernel
     // variant has constant LDS strides (fixed_interp_tile, device_common.h).
     int fixed_ip[4] = {0, 0, 0, 0};
-    if (forced_ip[0] <= 0 && bin_log2 <= 2 && p->interp_threads == 1024 && budget == kLdsLimit - 256 &&
+    if (forced_ip[0] <= 0 && bin_log2 == 2 && p->interp_threads == 1024 && budget == kLdsLimit - 256 &&
         env_int("NUFFT_INTERP_FIXED", 1)) {
         interp_fixed_dims(p->dtype, p->is_complex, p->D, p->M, fixed_ip);
         bool ok = fixed_ip[0] > 0;
@@ -283,7 +283,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     }
     // the same for the spreading tile (fixed_spread_tile): every edge must leave room for the clipped halo
     int fixed_sp[4] = {0, 0, 0, 0};
-    if (forced_sp[0] <= 0 && bin_log2 <= 2 && p->spread_threads == 1024 && budget == kLdsLimit - 256 &&
+    if (forced_sp[0] <= 0 && bin_log2 == 2 && p->spread_threads == 1024 && budget == kLdsLimit - 256 &&
         env_int("NUFFT_SPREAD_FIXED", 1)) {
         spread_fixed_dims(p->dtype, p->is_complex, p->D, p->M, fixed_sp);
         bool ok = fixed_sp[0] > 0;
@@ -294,9 +294,18 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     // Tile edges are multiples of the bin edge; when even one bin plus halo overflows the LDS (large M,
     // complex Float64) retry with smaller bins down to single cells.
     bool found = false;
-    for (; bin_log2 >= 0 && !found; --bin_log2)
+    for (; bin_log2 >= 0 && !found; --bin_log2) {
         found = choose_tiles(p->D, p->M, ncomp, rb, p->Nover, budget, p->spread_threads / 64, p->interp_threads / 64,
                              forced_sp, forced_ip, bin_log2, p->tile);
+        if (!found && (fixed_sp[0] > 0 || fixed_ip[0] > 0)) {
+            // the compile-time tiles are not the caller's choice: fall back to the run-time search
+            if (fixed_sp[0] > 0) forced_sp[0] = forced_sp[1] = forced_sp[2] = 0;
+            if (fixed_ip[0] > 0) forced_ip[0] = forced_ip[1] = forced_ip[2] = 0;
+            fixed_sp[0] = fixed_ip[0] = 0;
+            found = choose_tiles(p->D, p->M, ncomp, rb, p->Nover, budget, p->spread_threads / 64, p->interp_threads / 64,
+                                 forced_sp, forced_ip, bin_log2, p->tile);
+        }
+    }
     if (!found) {
         return fail(NUFFT_ERR_LDS_TOO_SMALL,
                     "LDS is too small for the chosen problem (element type, half-support M, dimensions): "
@@ -842,6 +851,9 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->num_points = p->Np;
     o->npoly = p->npoly;
     o->kernel = p->kernel;
+    o->spread_max_items = p->tile.sp.max_items;
+    o->interp_max_items = p->tile.ip.max_items;
+    o->spread_method = p->spread_method;
     return NUFFT_OK;
 }
 
@@ -876,8 +888,10 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         if (np > 0 && !coords[d]) return fail(NUFFT_ERR_INVALID_ARG, "null coordinate vector");
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    p->Np = -1;      // no valid point set until everything below has been enqueued (a failed call leaves the plan without points)
     if (np > p->Np_capacity) {
-        // resize_no_copy!, src/blocking/blocking.jl:55-61 (old contents are discarded)
+        // resize_no_copy!, src/blocking/blocking.jl:55-61 (old contents are discarded).  hipFree / hipMalloc are not
+        // capturable: pre-size the plan with the largest point set before capturing set_points in a hipGraph.
         if (p->d_binrank) { (void)hipFree(p->d_binrank); p->workspace_bytes -= p->Np_capacity * 8; p->d_binrank = nullptr; }
         if (p->d_sorted) {
             (void)hipFree(p->d_sorted);

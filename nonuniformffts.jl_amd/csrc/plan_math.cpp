@@ -213,14 +213,6 @@ void non_oversampled_indices(const std::vector<double>& ks, int64_t n_axis, bool
     }
 }
 
-static int strip_bytes(int D, int M, int ncomp, int real_bytes, int nwaves) {
-    int g = 1;
-    while (g < ncomp * 2 * M) g <<= 1;
-    const int ppw = 64 / g;
-    const int per_wave = (ppw * D * 2 * M * real_bytes + 15) / 16 * 16;
-    return nwaves * per_wave + 6144;      // + reserve for the work-item table (checked exactly afterwards)
-}
-
 // Candidate tile edges along one axis: multiples of the bin size that leave room for the clipped halo
 // (n + 2M - 1 <= Ñ, so that a point has at most one periodic image next to the tile), or the whole axis.
 static void edge_candidates(int64_t N, int b, int M, int cap, std::vector<int>& out) {
@@ -252,16 +244,23 @@ static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, int real_bytes
     t.rows[0] = P[1];
     t.rows[1] = P[2];
     t.elems = (int64_t)t.row_stride * P[1] * P[2];
-    // upper bound of the contiguous runs of sorted points a tile works through
+    // upper bound of the contiguous runs of sorted points a tile works through (the kernels' own arithmetic)
     const int b = 1 << bin_log2;
-    int64_t items = padded ? 1 : 2;
-    for (int d = 1; d < D; ++d) {
-        const int64_t nb = (Nover[d] + b - 1) / b;
-        const int64_t rows = padded ? n[d] / b + 1 : n[d] / b + 4;
-        items *= std::min<int64_t>(nb, rows);
-    }
-    // room for splitting long runs into several work items (kItemTarget per tile, see split_work_items)
-    t.max_items = (int)std::min<int64_t>(items + kItemTarget, 4096);
+    int nbv[3] = {1, 1, 1};
+    for (int d = 0; d < D; ++d) nbv[d] = (int)((Nover[d] + b - 1) / b);
+    t.max_items = (int)tile_items_bound(!padded, D, M, b, t.n, nbv);
+}
+
+// exact LDS bytes of a candidate tile (tile + work-item table + window strips); -1: too many work items
+static int64_t candidate_lds(bool spreading, int D, int M, int ncomp, int real_bytes, int nwaves, int64_t elems,
+                             const int n[3], const int64_t* Nover, int bin_log2) {
+    const int b = 1 << bin_log2;
+    int nbv[3] = {1, 1, 1};
+    for (int d = 0; d < D; ++d) nbv[d] = (int)((Nover[d] + b - 1) / b);
+    const int nn[3] = {n[0], n[1], n[2]};
+    const long items = tile_items_bound(spreading, D, M, b, nn, nbv);
+    if (items > kMaxTileItems || elems > (int64_t)1 << 24) return -1;
+    return lds_layout((int)elems, spreading ? 8 : real_bytes, real_bytes, D, M, ncomp, nwaves, (int)items).total;
 }
 
 bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,
@@ -282,7 +281,10 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
     }
     // --- spreading tile: interior only, Float64 accumulation; cost = point visits per point ---
     {
-        const int64_t avail = ((int64_t)lds_budget_bytes - strip_bytes(D, M, ncomp, real_bytes, spread_waves)) / 8;
+        auto fits = [&](int64_t elems, const int n[3]) {
+            const int64_t tot = candidate_lds(true, D, M, ncomp, real_bytes, spread_waves, elems, n, Nover, bin_log2);
+            return tot >= 0 && tot <= lds_budget_bytes;
+        };
         double best = std::numeric_limits<double>::infinity();
         int bn[3] = {0, 0, 0};
         if (forced_sp && forced_sp[0] > 0) {
@@ -294,13 +296,13 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
                 }
                 bn[d] = n;
             }
-            if ((int64_t)(D >= 2 ? lds_row_stride(ncomp * bn[0], ncomp * 2 * M, 8) : ncomp * bn[0]) * bn[1] * bn[2] > avail) return false;
+            if (!fits((int64_t)(D >= 2 ? lds_row_stride(ncomp * bn[0], ncomp * 2 * M, 8) : ncomp * bn[0]) * bn[1] * bn[2], bn)) return false;
         } else {
             for (int n3 : cand[2]) for (int n2 : cand[1]) for (int n1 : cand[0]) {
                 const int64_t elems = (int64_t)(D >= 2 ? lds_row_stride(ncomp * n1, ncomp * 2 * M, 8) : ncomp * n1) * n2 * n3;
-                if (elems > avail) continue;
-                double cost = 1.0;
                 const int n[3] = {n1, n2, n3};
+                if (!fits(elems, n)) continue;
+                double cost = 1.0;
                 for (int d = 0; d < D; ++d)
                     if (n[d] < Nover[d]) cost *= (double)(n[d] + halo) / n[d];
                 // every tile also pays a fixed cost (zeroing + storing the LDS tile): prefer enough work per tile
@@ -313,7 +315,10 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
     }
     // --- interpolation tile: padded, grid precision; cost = halo amplification of the tile load ---
     {
-        const int64_t avail = ((int64_t)lds_budget_bytes - strip_bytes(D, M, ncomp, real_bytes, interp_waves)) / real_bytes;
+        auto fits = [&](int64_t elems, const int n[3]) {
+            const int64_t tot = candidate_lds(false, D, M, ncomp, real_bytes, interp_waves, elems, n, Nover, bin_log2);
+            return tot >= 0 && tot <= lds_budget_bytes;
+        };
         double best = std::numeric_limits<double>::infinity();
         int bn[3] = {0, 0, 0};
         if (forced_ip && forced_ip[0] > 0) {
@@ -327,7 +332,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
             }
             int64_t e = ncomp;
             for (int d = 0; d < D; ++d) e *= bn[d] + halo;
-            if (e > avail) return false;
+            if (!fits(e, bn)) return false;
         } else {
             std::vector<int> ic[3];
             for (int d = 0; d < 3; ++d) {
@@ -344,7 +349,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
                     elems *= n[d] + halo;
                     cost *= (double)(n[d] + halo) / n[d];
                 }
-                if (elems > avail) continue;
+                if (!fits(elems, n)) continue;
                 cost -= 1e-6 * n1;
                 if (cost < best) { best = cost; bn[0] = n1; bn[1] = n2; bn[2] = n3; }
             }

@@ -479,7 +479,8 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         else { seg[d].n = 1; seg[d].lo[0] = 0; seg[d].len[0] = 1; seg[d].lo[1] = 0; seg[d].len[1] = 0; }
     }
     const int R2 = seg[1].total(), R3 = seg[2].total();
-    const int nruns = min(R2 * R3 * seg[0].n, ts.max_items);
+    const int nruns = R2 * R3 * seg[0].n;
+    if (nruns > ts.max_items) __builtin_trap();     // the host sizes the table from the same arithmetic (tile_items_bound)
     for (int item = tid; item < nruns; item += nthreads) {
         const int sg = item % seg[0].n;
         const int r2 = (item / seg[0].n) % R2;
@@ -747,7 +748,8 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         blo[d] = d < D ? org[d] >> g.blog[d] : 0;
         bcnt[d] = d < D ? ((org[d] + neff[d] - 1) >> g.blog[d]) - blo[d] + 1 : 1;
     }
-    const int nruns = min(bcnt[1] * bcnt[2], ts.max_items);
+    const int nruns = bcnt[1] * bcnt[2];
+    if (nruns > ts.max_items) __builtin_trap();     // sized by the host from the same arithmetic (tile_items_bound)
 
     const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves, ts.max_items);
     T* tile = reinterpret_cast<T*>(smem);

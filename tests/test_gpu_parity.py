@@ -121,6 +121,17 @@ CASES = [
     (np.complex128, (127, 128), 5, 2.0, O.FAST_APPROXIMATION, 1), # odd N1 = 127 -> 254 (general); 
     (np.complex128, (128, 127), 5, 2.0, O.FAST_APPROXIMATION, 1),
     (np.complex128, (48, 96), 5, 2.0, O.FAST_APPROXIMATION, 1),   # 96 x 192
+    # wide support on multi-tile 3-D grids: every tile sees n / b + ceil(M / b) + floor((M - 2) / b) + 1 bin rows per
+    # dimension (the work-item table was sized for n / b + 4 and silently dropped runs for M >= 9)
+    (np.float64, (64, 64, 64), 10, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float64, (64, 64, 64), 9, 2.0, O.DIRECT, 1),
+    (np.float32, (64, 64, 64), 10, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.complex64, (64, 64, 64), 10, 2.0, O.DIRECT, 1),
+    (np.complex128, (64, 64, 64), 10, 2.0, O.FAST_APPROXIMATION, 1),   # 2-cell bins: n / 2 + 10 bin rows
+    (np.complex128, (48, 40, 56), 9, 1.5, O.DIRECT, 1),
+    # Float64 lines of 2 x 1024 in the dimension-1 r2c / c2r pass (4 lines per workgroup: 8 need 172 KB of LDS)
+    (np.float64, (1024, 32), 4, 2.0, O.DIRECT, 1),
+    (np.float32, (1024, 32), 4, 2.0, O.FAST_APPROXIMATION, 1),
 ]
 
 

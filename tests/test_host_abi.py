@@ -171,3 +171,53 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "nufft_oracle" not in text and "c_oracle" not in text and "import oracle" not in text, f
+
+
+def _bin_segments(lo, hi, N, b, nb):
+    """device_common.h bin_segments: runs of bins covering the cells [lo, hi) of a periodic axis -> (runs, bins)."""
+    if hi - lo >= N:
+        return 1, nb
+    if lo >= 0 and hi <= N:
+        return 1, ((hi - 1) // b) - (lo // b) + 1
+    lo2 = lo + N if lo < 0 else lo
+    hi2 = hi if lo < 0 else hi - N
+    a_first, b_last = lo2 // b, (hi2 - 1) // b
+    if b_last + 1 >= a_first:
+        return 1, nb
+    return 2, (nb - a_first) + (b_last + 1)
+
+
+@pytest.mark.parametrize("Z,dims,M,kw", [
+    (np.float64, (128, 128, 128), 10, {}), (np.float32, (128, 128, 128), 10, {}), (np.complex64, (128, 128, 128), 10, {}),
+    (np.complex128, (128, 128, 128), 10, {}), (np.complex128, (128, 128, 128), 9, {}), (np.float64, (128, 128, 128), 9, {}),
+    (np.float64, (96, 80, 72), 10, dict(bin_log2=1)), (np.float64, (64, 64, 64), 7, dict(tile_dims=(16, 16, 16))),
+    (np.float64, (256, 256, 256), 4, {}), (np.complex64, (512, 512, 512), 8, {}), (np.float64, (300, 200), 10, {}),
+])
+def test_work_item_tables_hold_every_run_a_tile_can_see(nufft, Z, dims, M, kw):
+    """the spreading work-item table was sized as n / b + 4 bin rows whatever M; for M >= 9
+    the kernel sees more runs and used to drop them silently.  The host bound must cover the kernel's own run
+    count (spread_tile_kernel: product over dims 2, 3 of the bins covering [org - M, org + n + M - 1), times the
+    runs of dimension 1) for every tile position, and the LDS request must include the table."""
+    p = nufft.PlanNUFFT(Z, dims, m=M, backend=None, **kw)
+    i = p.info()
+    D = len(dims)
+    worst = 0
+    for t1 in range(i.spread_ntiles[0]):
+        org1 = t1 * i.spread_tile[0]
+        n1 = min(i.spread_tile[0], i.N_over[0] - org1)
+        runs1, _ = _bin_segments(org1 - M, org1 + n1 + M - 1, i.N_over[0], i.bin_dims[0], i.nbins[0])
+        rows = 1
+        for d in range(1, D):
+            best = 0
+            for t in range(i.spread_ntiles[d]):
+                org = t * i.spread_tile[d]
+                n = min(i.spread_tile[d], i.N_over[d] - org)
+                best = max(best, _bin_segments(org - M, org + n + M - 1, i.N_over[d], i.bin_dims[d], i.nbins[d])[1])
+            rows *= best
+        worst = max(worst, runs1 * rows)
+    assert worst <= i.spread_max_items, (worst, i.spread_max_items)
+    rows = 1
+    for d in range(1, D):
+        rows *= -(-i.interp_tile[d] // i.bin_dims[d])
+    assert rows <= i.interp_max_items
+    assert i.lds_bytes_spread <= 163840 and i.lds_bytes_interp <= 163840
