@@ -88,6 +88,20 @@ hipError_t prepare_spread(int dtype, int is_complex, int D, int M, int lds_bytes
 hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes, bool other);
 bool needs_other_eval(int kernel, int evalmode);
 
+// ---- spreading on MFMA patches (patch_kernels.h, patch_*.hip) ------------------------------------------------------
+struct PatchPlan {
+    bool eligible;
+    int npx, npy, nseg, segl, ntasks;   // patch columns, segments of cube layers along dimension 3, wave tasks
+    int lds_bytes;                      // dynamic LDS per workgroup
+};
+PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other);
+hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other);
+// vsorted: C value vectors in sorted order (launch_gather_values), vstride_reals reals apart
+hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
+                               hipStream_t stream);
+hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* sorted, int64_t np, const void* vin,
+                                const void* weights, void* vout, hipStream_t stream);
+
 // ---- deconvolution (deconv.hip) ------------------------------------------------------------------
 struct DeconvArgs {
     int dtype, D, C;

@@ -109,6 +109,12 @@ struct nufft_plan {
     bool interp_fixed = false;         // tile.ip is the compile-time tile of the kernel instantiation
     bool spread_fixed = false;         // tile.sp likewise
     int spread_method = NUFFT_SPREAD_LDS_TILES;   // what nufft_spread launches (NUFFT_SPREAD_*)
+    int spread_method_req = NUFFT_SPREAD_AUTO;    // what the caller asked for
+    struct Patch {                                // decomposition of the MFMA-patch spreading (patch_kernels.h)
+        bool eligible = false;
+        int npx = 0, npy = 0, nseg = 0, segl = 0, ntasks = 0, lds_bytes = 0;
+    } patch;
+    void* d_vsorted = nullptr;         // C value vectors in sorted order (MFMA-patch spreading)
     int64_t lds_spread = 0, lds_interp = 0;
 
     // device data

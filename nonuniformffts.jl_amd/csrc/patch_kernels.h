@@ -1,0 +1,480 @@
+// Type-1 spreading on register-resident patches accumulated by the FP64 matrix pipe (gfx950, wave64).
+//
+// Replaces spread_from_points_shmem_kernel! (reference src/spreading/gpu.jl:237-377) + fill_with_zeros
+// (src/NonuniformFFTs.jl:161-167) for 3-D grids of 4-cell bins.  Same arithmetic as the reference — every point adds
+// v * w1[j1] * w2[j2] * w3[j3] to the (2M)^3 cells of its stencil — organised as a contraction over points:
+//
+//     G[(x, y), z] += sum_p  A[(x, y), p] * B[p, z],    A = w1_p[x] * w2_p[y],   B = v_p * w3_p[z]
+//
+// which v_mfma_f64_4x4x4_4b_f64 evaluates for a 4 x 4 x 4 cube of cells and four points per instruction (four
+// independent 4 x 4 x 4 blocks: block = y row of the cube, i = x, j = z, k = point).  Measured on MI355X
+// (scripts/microbench6.hip, profiles/round2_microbench.md): 18 cycles per instruction per SIMD, against 8.5 cycles per
+// CU for one ds_add_f64 wave instruction (64 cells of ONE point) of the LDS-tile kernel in tile_kernels.h.
+//
+//   * A wave owns a patch of PBX x PBY cube columns (16 x 4 PBY cells) and marches along dimension 3 through a
+//     segment of cube layers.  The accumulators of NCB = number of cube layers a stencil can touch live in
+//     registers (MFMA C/D operands); when a bin layer is finished its oldest cube layer is complete, leaves through
+//     a small LDS transposition as full 128-byte rows, and the ring of accumulators shifts.  No atomics anywhere
+//     (LDS or global), no zero fill of the grid: every cell is written exactly once.
+//   * Output-driven like the LDS-tile kernel: a patch visits the points of every bin whose stencils can reach
+//     it — per bin layer PBY + NCB - 1 rows of PBX + NCB - 1 bins, each row one contiguous run of the bin-sorted
+//     array.  The matrix work of a point is not duplicated by that (each cube belongs to one patch); only its
+//     window evaluation and operand set-up are.
+//   * Window values are evaluated with the group mapping of tile_kernels.h (WindowEval: next_pow2(2M) lanes own
+//     a point, polynomial coefficients in registers, or the direct forms) into zero-padded LDS rows; the operand
+//     of a cube is then a plain LDS read at (cube offset + lane coordinate - stencil start): cells outside the
+//     stencil read the padding.  Dimensions 2 and 3 are static offsets from one address (the row of bins and
+//     the cube layer fix the cube offsets), dimension 1 clamps its index into the padding.
+//   * Values arrive gathered in sorted order (gather_values_kernel), records and values of the next chunk of
+//     points are prefetched into registers while the current chunk is processed.
+//
+// Float32 plans evaluate their windows in Float32 and accumulate in Float64 (as the LDS-tile kernel does).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "device_common.h"
+#include "nufft_mi355x.h"
+#include "tile_kernels.h"
+
+namespace nufft {
+
+#ifndef NUFFT_PATCH_ACC_CAP
+#define NUFFT_PATCH_ACC_CAP 48      // accumulators (cubes) per wave
+#endif
+#ifndef NUFFT_PATCH_OCC
+#define NUFFT_PATCH_OCC 2           // waves per SIMD the register budget is sized for
+#endif
+
+constexpr __host__ __device__ int floor_div4(int a) { return a >= 0 ? a / 4 : -((-a + 3) / 4); }
+
+// rows of cube columns per patch: NC * NCB * PBX * PBY accumulators (two VGPRs each) must leave room for the rest
+constexpr __host__ __device__ int patch_rows(int ncomp, int ncb) {
+    int r = NUFFT_PATCH_ACC_CAP / (ncomp * ncb * 4);
+    return r < 1 ? 1 : (r > 4 ? 4 : r);
+}
+
+template <int NC, int M>
+struct PatchCfg {
+    static constexpr int L = 2 * M;
+    static constexpr int CLO = floor_div4(1 - M);      // cubes a stencil reaches relative to the bin of its point
+    static constexpr int CHI = floor_div4(3 + M);
+    static constexpr int NCB = CHI - CLO + 1;
+    static constexpr int PBX = 4;
+    static constexpr int PBY = patch_rows(NC, NCB);
+    static constexpr int NRB = PBY + NCB - 1;           // rows of bins visited per bin layer
+    static constexpr int NACC = NC * NCB * PBX * PBY;
+    static constexpr int PADB = 4 - M - 4 * CLO;        // zeros in front of / behind the 2M window values of a row
+    static constexpr int PADA = 4 * CHI + 3 - M;
+    static constexpr int LW = PADB + L + PADA;
+    static constexpr int G = next_pow2(L);              // lanes per point during window evaluation
+    static constexpr int PPW = kWave / G;
+    static constexpr int CH = M <= 5 ? 32 : 16;         // points per chunk (staged in LDS)
+    static constexpr int META = 32;                     // bytes: {sx, offy, offz, rbx} + value (re, im)
+    static constexpr int PSTRIDE = 3 * LW * 8 + META;   // bytes per staged point
+    static constexpr int WBYTES = (CH + 1) * PSTRIDE;   // + the all-zero point
+    static constexpr int ROWLEN = 16 * NC + 2;          // reals per row of the transposition buffer (+2: banks)
+    static constexpr int TBYTES = 4 * 4 * PBY * ROWLEN * 8;
+    static constexpr int STAGE_PT = 32 + 16;            // staged record (3 coordinates as double + pad) + value
+    static constexpr int WAVE_BYTES = round_up((WBYTES > TBYTES ? WBYTES : TBYTES), 16) + round_up(CH * STAGE_PT, 16);
+    static constexpr int NPOLY = M + 4;                 // coefficients per sub-interval (src/Kernels/kaiser_bessel_backwards.jl:98)
+    static_assert(PADB >= 1 && PADA >= 1, "padding");
+    static constexpr int table_bytes(int real_bytes) { return round_up(3 * NPOLY * L * real_bytes, 16); }
+    static constexpr int lds_bytes(int real_bytes, int nwaves) { return table_bytes(real_bytes) + nwaves * WAVE_BYTES; }
+};
+
+constexpr int kPatchWaves = 4;                           // waves per workgroup (independent tasks)
+
+struct PatchGeom {
+    int npx, npy, nseg, segl;       // patch columns, segments along dimension 3, cube layers per segment
+    int ntasks;
+};
+
+template <typename T>
+struct PatchArgs {
+    TileArgs<T> t;                  // geometry, sorted records, bin offsets, window parameters, grids
+    PatchGeom pg;
+    const T* vsorted[kMaxCompPerLaunch];   // values in sorted order (gather_values_kernel), NC reals per point
+};
+
+// Values in sorted order: vs[p] = v[idx[p]] (* weight[idx[p]]: callbacks.nonuniform, src/spreading/gpu.jl:289)
+template <typename T, int NC, int REC_BYTES>
+__global__ __launch_bounds__(256) void gather_values_kernel(const unsigned char* __restrict__ recs, int idx_off, int64_t np,
+                                                           const T* __restrict__ vin, const T* __restrict__ weights,
+                                                           T* __restrict__ vout) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += stride) {
+        const int32_t idx = *reinterpret_cast<const int32_t*>(recs + p * REC_BYTES + idx_off);
+        const T w = weights ? weights[idx] : T(1);
+        if constexpr (NC == 1) {
+            vout[p] = vin[idx] * w;
+        } else {
+            using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+            V2 v = reinterpret_cast<const V2*>(vin)[idx];
+            v.x *= w; v.y *= w;
+            reinterpret_cast<V2*>(vout)[p] = v;
+        }
+    }
+}
+
+// Window values of cube columns 0 .. N-1 of dimension 1: w[cx] = row[clamp(t8 / 8 + 4 cx, -1, L)] with `base` the LDS
+// byte address of row[0] and t8 = 8 (lane coordinate - stencil start); row[-1] and row[L] are padding zeros.
+// v_med3 clamps t8 against bounds shifted by the column, the column offset itself is the immediate of the read.
+template <int L, int N, int... CX>
+__device__ __forceinline__ void lds_read_clamped(double (&w)[N], uint32_t base, int t8, std::integer_sequence<int, CX...>) {
+    ((lds_read_imm<double, 32 * CX>(w[CX], base + (uint32_t)max(-8 - 32 * CX, min(t8, 8 * L - 32 * CX)))), ...);
+}
+
+// f(std::integral_constant<int, r>) for the run-time row r in [I, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void dispatch_row(int r, F&& f) {
+    if constexpr (I < N) {
+        if (r == I) f(std::integral_constant<int, I>{});
+        else dispatch_row<I + 1, N>(r, f);
+    }
+}
+
+__device__ __forceinline__ double mfma444(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <typename T, bool CPLX, int M, bool OTHERK>
+__global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH_OCC) void spread_patch_kernel(PatchArgs<T> a) {
+    constexpr int NC = CPLX ? 2 : 1;
+    using P = PatchCfg<NC, M>;
+    constexpr int L = P::L, CLO = P::CLO, CHI = P::CHI, NCB = P::NCB, PBX = P::PBX, PBY = P::PBY, NRB = P::NRB;
+    constexpr int PADB = P::PADB, LW = P::LW, CH = P::CH, PSTRIDE = P::PSTRIDE;
+    constexpr int WX = 0, WY = LW * 8, WZ = 2 * LW * 8, MT = 3 * LW * 8;      // byte offsets inside a staged point
+    using WE = WindowEval<T, 1, 3, M, P::G, OTHERK>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const Geom& g = a.t.g;
+    const PatchGeom& pg = a.pg;
+
+    // polynomial coefficients of the window: one copy per workgroup in LDS (re-read by every chunk evaluation)
+    T* ctab = reinterpret_cast<T*>(smem);
+    for (int i = threadIdx.x; i < 3 * P::NPOLY * L; i += kPatchWaves * kWave) ctab[i] = a.t.coefs[i];
+    __syncthreads();
+
+    // ---- task: (patch column px, py; segment) ----
+    const int nwg = (int)gridDim.x;
+    const int wg = xcd_remap_chunked((int)blockIdx.x, nwg, a.t.xcd_chunk);
+    const int task = wg * kPatchWaves + wave;
+    if (task >= pg.ntasks) return;
+    const int comp_id = blockIdx.y;
+    const int px = task % pg.npx, py = (task / pg.npx) % pg.npy, seg = task / (pg.npx * pg.npy);
+    const int ncx = min(PBX, g.nb[0] - px * PBX), ncy = min(PBY, g.nb[1] - py * PBY);   // cube columns that exist
+    const int z0 = seg * pg.segl, z1 = min(z0 + pg.segl, g.nb[2]);                      // owned cube layers
+    const int X0 = px * PBX * 4;
+    const int bx0 = px * PBX, by0 = py * PBY;
+
+    unsigned char* wmem = smem + P::table_bytes((int)sizeof(T)) + wave * P::WAVE_BYTES;                 // staged points / transposition buffer
+    unsigned char* stage = wmem + round_up((P::WBYTES > P::TBYTES ? P::WBYTES : P::TBYTES), 16);
+    const uint32_t wbase = (uint32_t)(uintptr_t)wmem;
+
+    auto zero_wmem = [&]() __attribute__((always_inline)) {
+        for (int o = lane * 16; o < P::WBYTES; o += kWave * 16) *reinterpret_cast<uint4*>(wmem + o) = make_uint4(0, 0, 0, 0);
+    };
+    zero_wmem();
+
+    // ---- accumulators: [component][ring slot][cube row][cube column] ----
+    double acc[NC][NCB][PBY][PBX];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int s = 0; s < NCB; ++s)
+#pragma unroll
+            for (int y = 0; y < PBY; ++y)
+#pragma unroll
+                for (int x = 0; x < PBX; ++x) acc[c][s][y][x] = 0.0;
+
+    // window evaluation roles (group mapping)
+    const int grp = lane / P::G, q = lane % P::G;
+    // matrix roles
+    const int mk = lane >> 4, mb = (lane >> 2) & 3, mi = lane & 3;
+
+    const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.t.sorted);
+    const T* vs = a.vsorted[comp_id];
+    T* grid = a.t.grid[comp_id];
+
+    // ---- runs of the sorted array: per bin layer, row r (relative bin row r - CHI) has up to two pieces (periodic
+    //      wrap along dimension 1); lane t < 4 NRB holds bound (r = t >> 2, piece = (t >> 1) & 1, end = t & 1) ----
+    const int gx0 = bx0 - CHI, gx1 = bx0 + ncx - 1 - CLO;            // visited bins along dimension 1 (unwrapped)
+    auto load_bounds = [&](int bz) __attribute__((always_inline)) -> uint32_t {
+        const int r = lane >> 2, piece = (lane >> 1) & 1, isend = lane & 1;
+        const int rb = r - CHI;
+        uint32_t val = 0;
+        if (lane < 4 * NRB && rb <= ncy - 1 - CLO) {
+            int lo, hi;                                              // bins [lo, hi] of this piece, or empty
+            if (gx0 < 0) { lo = piece ? 0 : gx0 + g.nb[0]; hi = piece ? gx1 : g.nb[0] - 1; }
+            else if (gx1 >= g.nb[0]) { lo = piece ? 0 : gx0; hi = piece ? gx1 - g.nb[0] : g.nb[0] - 1; }
+            else { lo = gx0; hi = piece ? -1 : gx1; }
+            if (hi >= lo) {
+                int by = by0 + rb;
+                if (by < 0) by += g.nb[1];
+                if (by >= g.nb[1]) by -= g.nb[1];
+                int bzw = bz % g.nb[2];
+                if (bzw < 0) bzw += g.nb[2];
+                const int64_t row = ((int64_t)bzw * g.nb[1] + by) * g.nb[0];
+                val = a.t.offsets[row + (isend ? hi + 1 : lo)];
+            }
+        }
+        return val;
+    };
+
+    const int bz_first = z0 - CHI, bz_last = z1 - 1 - CLO;
+
+    struct Cursor { int bz, u; uint32_t p, pe; };
+    uint32_t bnd = load_bounds(bz_first);
+    uint32_t bnd_next = load_bounds(bz_first + 1);
+    // next chunk after c (c.u = -1, c.p = c.pe = 0 to start); returns false at the end of the segment
+    auto advance = [&](Cursor& c) __attribute__((always_inline)) -> bool {
+        c.p += CH;
+        if (c.p < c.pe) return true;
+        for (;;) {
+            ++c.u;
+            if (c.u == 2 * NRB) {
+                c.u = 0;
+                ++c.bz;
+                if (c.bz > bz_last) return false;
+                bnd = bnd_next;
+                bnd_next = load_bounds(c.bz + 1);
+            }
+            c.p = (uint32_t)__builtin_amdgcn_readlane((int)bnd, 2 * c.u);
+            c.pe = (uint32_t)__builtin_amdgcn_readlane((int)bnd, 2 * c.u + 1);
+            if (c.p < c.pe) return true;
+        }
+    };
+
+    // ---- prefetch of a chunk: lane l < n holds record and value of point c.p + l ----
+    PointRec<T, 3> pf_rec;
+    T pf_v[NC];
+    auto issue_prefetch = [&](const Cursor& c) __attribute__((always_inline)) {
+        const uint32_t n = min((uint32_t)CH, c.pe - c.p);
+        const uint32_t pp = c.p + min((uint32_t)lane, n - 1);
+        pf_rec = sorted[pp];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) pf_v[cc] = vs[(int64_t)pp * NC + cc];
+    };
+    // lane l < CH = point l of the chunk: cell, cell fraction (staged for the window evaluation) and the point's
+    // meta data {-8 sx, byte offsets of dimensions 2 and 3, bin along dimension 1} + value, written next to its windows
+    auto commit_prefetch = [&]() __attribute__((always_inline)) {
+        if (lane < CH) {
+            int cell[3];
+            double* s = reinterpret_cast<double*>(stage + lane * P::STAGE_PT);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                cell[d] = cell_of(pf_rec.r[d], g.Nover[d]);
+                s[d] = (double)(pf_rec.r[d] - T(cell[d]));
+            }
+            int sx = cell[0] - (M - 1) - X0;                           // stencil start relative to the patch, unwrapped
+            if (sx > g.Nover[0] / 2) sx -= g.Nover[0];
+            if (sx < -(g.Nover[0] / 2)) sx += g.Nover[0];
+            int4 m;
+            m.x = -8 * sx;
+            m.y = (PADB + M - 1 - (cell[1] & 3) + 4 * CLO) * 8;        // cube offset CLO, lane row 0
+            m.z = (PADB + M - 1 - (cell[2] & 3) + 4 * CLO) * 8;
+            m.w = (sx + (M - 1)) >> 2;                                 // bin of the point relative to the patch
+            unsigned char* pw = wmem + lane * PSTRIDE + MT;
+            *reinterpret_cast<int4*>(pw) = m;
+            *reinterpret_cast<double2*>(pw + 16) = make_double2((double)pf_v[0], NC == 2 ? (double)pf_v[NC - 1] : 0.0);
+        }
+    };
+
+    // ---- retire the oldest cube layer (cz = bz + CLO) once bin layer bz is finished, shift the ring ----
+    auto retire = [&](int bz) __attribute__((always_inline)) {
+        const int cz = bz + CLO;
+        if (cz >= z0 && cz < z1) {
+            wave_lds_fence();
+            double* tb = reinterpret_cast<double*>(wmem);
+            // D layout of v_mfma_f64_4x4x4_4b: lane 16 i + 4 b + j holds cell (x = i, y = b, z = j) of the cube
+            const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int y = 0; y < PBY; ++y)
+#pragma unroll
+                    for (int x = 0; x < PBX; ++x)
+                        tb[(dj * (4 * PBY) + 4 * y + db) * P::ROWLEN + (4 * x + di) * NC + c] = acc[c][0][y][x];
+            wave_lds_fence();
+            // rows of 16 NC reals: 8 lanes per row (2 NC reals each), 8 rows per wave instruction
+            constexpr int NROWS = 4 * 4 * PBY;
+            const int sub = lane >> 3, e0 = (lane & 7) * 2 * NC;
+            const int nxr = ncx * 4 * NC, nyr = ncy * 4;
+#pragma unroll
+            for (int r0 = 0; r0 < NROWS; r0 += 8) {
+                const int row = r0 + sub;
+                const int pl = row / (4 * PBY), yy = row % (4 * PBY);
+                if (yy < nyr && e0 < nxr) {
+                    const double* src = tb + row * P::ROWLEN + e0;
+                    const int64_t gz = (int64_t)cz * 4 + pl, gy = (int64_t)by0 * 4 + yy;
+                    T* dst = grid + ((gz * g.Nover[1] + gy) * g.Nover[0] + X0) * NC + e0;
+                    if constexpr (NC == 1) {
+                        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(src[0], src[1]);
+                        else *reinterpret_cast<float2*>(dst) = make_float2((float)src[0], (float)src[1]);
+                    } else {
+                        if constexpr (sizeof(T) == 8) {
+                            reinterpret_cast<double2*>(dst)[0] = make_double2(src[0], src[1]);
+                            reinterpret_cast<double2*>(dst)[1] = make_double2(src[2], src[3]);
+                        } else {
+                            *reinterpret_cast<float4*>(dst) = make_float4((float)src[0], (float)src[1], (float)src[2], (float)src[3]);
+                        }
+                    }
+                }
+            }
+            wave_lds_fence();
+            zero_wmem();                    // the buffer aliases the staged points: restore their zero padding
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int y = 0; y < PBY; ++y)
+#pragma unroll
+                for (int x = 0; x < PBX; ++x) {
+#pragma unroll
+                    for (int s = 0; s + 1 < NCB; ++s) acc[c][s][y][x] = acc[c][s + 1][y][x];
+                    acc[c][NCB - 1][y][x] = 0.0;
+                }
+    };
+
+    // ---- one chunk of n <= CH staged points of bin row R: window evaluation, then K-batches of four points ----
+    auto eval_chunk = [&](int n) __attribute__((always_inline)) {
+        // the polynomial coefficients live in registers only while a chunk is evaluated (they are re-read from the
+        // LDS table per chunk): the matrix phase needs the room for its accumulators
+        WE we;
+        we.init(a.t, q, ctab);
+        wave_lds_fence();
+#pragma unroll 1
+        for (int t0 = 0; t0 < n; t0 += P::PPW) {
+            const int pt = t0 + grp;
+            const double* s = reinterpret_cast<const double*>(stage + min(pt, n - 1) * P::STAGE_PT);
+            const T X[3] = {(T)s[0], (T)s[1], (T)s[2]};
+            T v[WE::NSLOT];
+            we.eval_regs(a.t, X, v);
+            unsigned char* pw = wmem + pt * PSTRIDE;
+            if (pt < n) {
+#pragma unroll
+                for (int sl = 0; sl < WE::NSLOT; ++sl)
+                    if (we.has[sl]) *reinterpret_cast<double*>(pw + we.dsel[sl] * (LW * 8) + (PADB + we.jsel[sl]) * 8) = (double)v[sl];
+            }
+        }
+        wave_lds_fence();
+    };
+
+    // K-batches of four points (k = lane >> 4; the all-zero point pads the last one), software-pipelined: the LDS
+    // reads of batch i + 1 (operands) and i + 2 (point meta data) are in flight while the MFMAs of batch i issue.
+    auto batches = [&](auto RBc, int n) __attribute__((always_inline)) {
+        constexpr int RB = decltype(RBc)::value - CHI;                 // relative bin row: cubes RB + CLO .. RB + CHI
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v4i m;                       // {sx, byte offset dim 2, byte offset dim 3, bin along dim 1 relative to the patch}
+        v2d vv;                      // value (re, im)
+        double w3[NCB], w2[NCB], w1[PBX];
+        double vre = 0.0, vim = 0.0;
+        uint32_t cxmask = 0u;                                          // cube columns the batch can touch
+        auto issue_meta = [&](int b0) __attribute__((always_inline)) {
+            const int pidx = b0 + mk < n ? b0 + mk : CH;
+            const uint32_t ad = wbase + (uint32_t)(pidx * PSTRIDE + MT);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(m) : "v"(ad));
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(vv) : "v"(ad));
+        };
+        // operands of the batch whose meta data has arrived in (m, vv)
+        auto issue_ops = [&](int b0) __attribute__((always_inline)) {
+            const int pidx = b0 + mk < n ? b0 + mk : CH;
+            const uint32_t pb = wbase + (uint32_t)(pidx * PSTRIDE);
+            const int nvalid = max(1, min(4, n - b0));
+            // cube columns this batch can touch (points are sorted by bin along dimension 1)
+            {
+                const int lo = max(__builtin_amdgcn_readlane(m.w, 0) + CLO, 0);
+                const int hi = min(__builtin_amdgcn_readlane(m.w, 16 * (nvalid - 1)) + CHI, PBX - 1);
+                cxmask = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+#if defined(NUFFT_PATCH_NOGUARD)
+                cxmask = (1u << PBX) - 1u;
+#endif
+            }
+            vre = vv.x; vim = vv.y;
+            // dimension 3: ring slot s <-> cube offset CLO + s; dimension 2: cube offset CLO + o (static offsets from
+            // one address each); dimension 1: the window index is clamped into the zero padding
+            lds_read_rows<double, NCB, 0, 32>(w3, pb + WZ + (uint32_t)m.z + (uint32_t)mi * 8, std::make_integer_sequence<int, NCB>{});
+            lds_read_rows<double, NCB, 0, 32>(w2, pb + WY + (uint32_t)m.y + (uint32_t)mb * 8, std::make_integer_sequence<int, NCB>{});
+            const int t8 = mi * 8 + m.x;                               // 8 (x - sx) for cube column 0
+            const uint32_t pbx = pb + WX + PADB * 8;
+            lds_read_clamped<L, PBX>(w1, pbx, t8, std::make_integer_sequence<int, PBX>{});
+        };
+        auto wait_all = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(m), "+v"(vv));
+#pragma unroll
+            for (int s = 0; s < NCB; ++s) asm volatile("" : "+v"(w3[s]), "+v"(w2[s]));
+#pragma unroll
+            for (int cx = 0; cx < PBX; ++cx) asm volatile("" : "+v"(w1[cx]));
+        };
+        issue_meta(0);
+        wait_all();
+        issue_ops(0);
+        issue_meta(4);
+#pragma unroll 1
+        for (int b0 = 0; b0 < n; b0 += 4) {
+            wait_all();
+            // operands of this batch: A = w1 w2 per cube column, B = v w3 per ring slot
+            double A[NCB][PBX], bz_[NC][NCB];
+#pragma unroll
+            for (int s = 0; s < NCB; ++s) {
+                bz_[0][s] = w3[s] * vre;
+                if constexpr (NC == 2) bz_[NC - 1][s] = w3[s] * vim;
+            }
+#pragma unroll
+            for (int o = 0; o < NCB; ++o)
+#pragma unroll
+                for (int cx = 0; cx < PBX; ++cx) A[o][cx] = (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? w1[cx] * w2[o] : 0.0;
+            const uint32_t mask = cxmask;
+            issue_ops(b0 + 4);
+            issue_meta(b0 + 8);
+#if !defined(NUFFT_PATCH_NOSCHEDBAR)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int cx = 0; cx < PBX; ++cx) {
+                if (mask & (1u << cx)) {
+#pragma unroll
+                    for (int o = 0; o < NCB; ++o) {
+                        const int cy = RB + CLO + o;
+                        if (cy >= 0 && cy < PBY) {
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                                for (int s = 0; s < NCB; ++s) acc[c][s][cy][cx] = mfma444(A[o][cx], bz_[c][s], acc[c][s][cy][cx]);
+                        }
+                    }
+                }
+            }
+        }
+        wait_all();                  // the reads issued ahead of the last batch target live registers
+    };
+
+    // ---- main loop over the chunks of the segment ----
+    Cursor nxt{bz_first, -1, 0u, 0u};
+    bool has = advance(nxt);
+    if (has) issue_prefetch(nxt);
+    int bz_done = bz_first;
+    while (has) {
+        const Cursor cur = nxt;
+        while (bz_done < cur.bz) { retire(bz_done); ++bz_done; }      // (wipes the staged points: before the commit)
+        wave_lds_fence();
+        commit_prefetch();
+        has = advance(nxt);
+        if (has) issue_prefetch(nxt);
+        const int n = (int)min((uint32_t)CH, cur.pe - cur.p);
+        eval_chunk(n);
+        dispatch_row<0, NRB>(cur.u >> 1, [&](auto Rc) __attribute__((always_inline)) { batches(Rc, n); });
+    }
+    while (bz_done <= bz_last) { retire(bz_done); ++bz_done; }
+}
+
+}  // namespace nufft

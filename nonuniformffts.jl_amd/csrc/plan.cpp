@@ -321,6 +321,24 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     if (p->lds_spread > kLdsLimit || p->lds_interp > kLdsLimit)
         return fail(NUFFT_ERR_LDS_TOO_SMALL, "LDS is too small for the chosen problem: work-item table does not fit");
     if (p->tile.nbins >= ((int64_t)1 << 31) - 2) return fail(NUFFT_ERR_UNSUPPORTED, "too many bins");
+    // spreading engine: MFMA patches where they apply (3-D, 4-cell bins, default window evaluation), LDS tiles otherwise
+    {
+        int req = in->spread_method != NUFFT_SPREAD_AUTO ? in->spread_method : env_int("NUFFT_SPREAD_METHOD", NUFFT_SPREAD_AUTO);
+        if (req < NUFFT_SPREAD_AUTO || req > NUFFT_SPREAD_MFMA_PATCHES) return fail(NUFFT_ERR_INVALID_ARG, "unknown spread_method");
+        p->spread_method_req = req;
+        const PatchPlan pp = patch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
+        p->patch.eligible = pp.eligible;
+        p->patch.npx = pp.npx; p->patch.npy = pp.npy; p->patch.nseg = pp.nseg; p->patch.segl = pp.segl;
+        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes;
+        if (req == NUFFT_SPREAD_MFMA_PATCHES && !pp.eligible)
+            return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = MFMA patches needs a 3-D grid of 4-cell bins with every oversampled "
+                                               "axis a multiple of 4 and at least 2 (patch + stencil) bins long, and the default window evaluation");
+        // automatic choice, from the measurements in DESIGN.md section 4.4: the patches win where the stencil carries
+        // more matrix work per point visit (complex data, M >= 5: 1.15x ... 2x), the LDS tiles for real data at M <= 4
+        const bool prefer_patches = p->is_complex || p->M >= 5;
+        p->spread_method = (pp.eligible && (req == NUFFT_SPREAD_MFMA_PATCHES || (req == NUFFT_SPREAD_AUTO && prefer_patches)))
+                               ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
+    }
     return NUFFT_OK;
 }
 
@@ -493,6 +511,8 @@ static int build_device(nufft_plan* p) {
         NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp, other != 0));
     }
 
+    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false));
+
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
         hipEvent_t a, b;
         NUFFT_HIP(hipEventCreate(&a));
@@ -511,7 +531,7 @@ static void release(nufft_plan* p) {
         auto fr = [](void* q) { if (q) (void)hipFree(q); };
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
-        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted);
+        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -898,7 +918,13 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
             p->workspace_bytes -= p->Np_capacity * (int64_t)point_record_bytes(p->dtype, p->D);
             p->d_sorted = nullptr;
         }
+        if (p->d_vsorted) {
+            (void)hipFree(p->d_vsorted);
+            p->workspace_bytes -= p->Np_capacity * (int64_t)value_bytes(p) * p->C;
+            p->d_vsorted = nullptr;
+        }
         p->Np_capacity = 0;
+        if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES && (rc = dev_alloc(p, &p->d_vsorted, (size_t)np * value_bytes(p) * p->C))) return rc;
         if ((rc = dev_alloc(p, &p->d_binrank, (size_t)np * 8))) return rc;
         if ((rc = dev_alloc(p, &p->d_sorted, (size_t)np * point_record_bytes(p->dtype, p->D)))) return rc;
         p->Np_capacity = np;
@@ -964,6 +990,19 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
     StageTimer tm(p, NUFFT_STAGE_T1_SPREAD, stream);
     TileKernelArgs a = tile_args(p, false);
     a.values_in = values_in;
+    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
+        // values gathered into sorted order (per-point weights of the callback menu folded in), then the patches
+        const int64_t vstride = p->Np * (p->is_complex ? 2 : 1);
+        for (int c = 0; c < p->C; ++c)
+            NUFFT_HIP(launch_gather_values(p->dtype, p->is_complex, p->D, p->d_sorted, p->Np, values_in[c], p->cb_point_weights,
+                                           static_cast<char*>(p->d_vsorted) + (size_t)c * vstride * real_bytes(p), stream));
+        PatchPlan pp{};
+        pp.eligible = true;
+        pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
+        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes;
+        NUFFT_HIP(launch_spread_patch(a, pp, p->d_vsorted, vstride, stream));
+        return NUFFT_OK;
+    }
     if (p->balance_enabled)    // tiles shared by several workgroups accumulate with atomics: zero them first
         NUFFT_HIP(launch_zero_split_tiles(p->dtype, a.g, p->D, p->is_complex, p->C, p->bal.d_nslices, p->d_us,
                                           p->grid_elems * (p->is_complex ? 2 : 1), stream));

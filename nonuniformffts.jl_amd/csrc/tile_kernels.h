@@ -141,7 +141,10 @@ struct WindowEval {
     bool has[NSLOT];
     T beta_s[NSLOT], bop_s[NSLOT];
 
-    __device__ __forceinline__ void init(const TileArgs<T>& a, int q) {
+    __device__ __forceinline__ void init(const TileArgs<T>& a, int q) { init(a, q, a.coefs); }
+    // cf: the coefficient table [D][NP][2M] (a.coefs or a copy of it, e.g. in LDS)
+    template <typename CP>
+    __device__ __forceinline__ void init(const TileArgs<T>& a, int q, CP cf) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const int k = q + s * GS;
@@ -161,7 +164,7 @@ struct WindowEval {
                 cs[s][0] = exp(-(xm * xm) / bop_s[s]);
             } else if (poly) {
 #pragma unroll
-                for (int c = 0; c < NP; ++c) cs[s][c] = a.coefs[(dsel[s] * NP + c) * L + jsel[s]];
+                for (int c = 0; c < NP; ++c) cs[s][c] = cf[(dsel[s] * NP + c) * L + jsel[s]];
             } else {
 #pragma unroll
                 for (int c = 0; c < NP; ++c) cs[s][c] = T(0);

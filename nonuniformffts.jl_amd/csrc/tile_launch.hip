@@ -3,6 +3,7 @@
 
 #include "kernels.h"
 #include "tile_kernels.h"
+#include "patch_kernels.h"
 
 namespace nufft {
 
@@ -85,6 +86,34 @@ hipError_t prepare_interp(int dtype, int is_complex, int D, int M, int lds_bytes
     return prepare(true, dtype, is_complex, D, M, lds_bytes, other);
 }
 
+// kernel arguments of components c0 .. c0 + nc - 1
+template <typename T>
+static TileArgs<T> fill_tile_args(const TileKernelArgs& a, int c0, int nc) {
+    const int ncr = a.is_complex ? 2 : 1;
+    TileArgs<T> k{};
+    k.g = a.g;
+    k.sorted = a.sorted;
+    k.offsets = a.offsets;
+    k.coefs = static_cast<const T*>(a.coefs);
+    for (int d = 0; d < 3; ++d) {
+        k.beta[d] = (T)a.beta[d];
+        k.bop[d] = (T)a.beta_over_pi[d];
+    }
+    for (int c = 0; c < nc; ++c) {
+        k.grid[c] = static_cast<T*>(a.grid) + (int64_t)(c0 + c) * a.grid_stride * ncr;
+        k.vin[c] = a.values_in ? static_cast<const T*>(a.values_in[c0 + c]) : nullptr;
+        k.vout[c] = a.values_out ? static_cast<T*>(a.values_out[c0 + c]) : nullptr;
+    }
+    k.prefactor = (T)a.prefactor;
+    k.weights = static_cast<const T*>(a.weights);
+    k.desc = static_cast<const uint2*>(a.desc);
+    k.desc_total = a.desc_total;
+    k.xcd_chunk = a.xcd_chunk;
+    k.evalmode = a.evalmode;
+    k.kernel = a.kernel;
+    return k;
+}
+
 template <typename T>
 static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t stream) {
     bool wrap = false;
@@ -97,36 +126,117 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         if (ff) fn = ff;
     }
     if (!fn) return hipErrorInvalidValue;
-    const int ncr = a.is_complex ? 2 : 1;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
-        TileArgs<T> k{};
-        k.g = a.g;
-        k.sorted = a.sorted;
-        k.offsets = a.offsets;
-        k.coefs = static_cast<const T*>(a.coefs);
-        for (int d = 0; d < 3; ++d) {
-            k.beta[d] = (T)a.beta[d];
-            k.bop[d] = (T)a.beta_over_pi[d];
-        }
-        for (int c = 0; c < nc; ++c) {
-            k.grid[c] = static_cast<T*>(a.grid) + (int64_t)(c0 + c) * a.grid_stride * ncr;
-            k.vin[c] = a.values_in ? static_cast<const T*>(a.values_in[c0 + c]) : nullptr;
-            k.vout[c] = a.values_out ? static_cast<T*>(a.values_out[c0 + c]) : nullptr;
-        }
-        k.prefactor = (T)a.prefactor;
-        k.weights = static_cast<const T*>(a.weights);
-        k.desc = static_cast<const uint2*>(a.desc);
-        k.desc_total = a.desc_total;
-        k.xcd_chunk = a.xcd_chunk;
-        k.evalmode = a.evalmode;
-        k.kernel = a.kernel;
+        TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
         void* params[] = {&k};
         hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
                                        params, (size_t)a.lds_bytes, stream);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// ---- spreading on MFMA patches (patch_kernels.h) ------------------------------------------------------------------
+const void* patch_kernel_f32r(int M, bool other, int* lds_bytes, int* pby);
+const void* patch_kernel_f32c(int M, bool other, int* lds_bytes, int* pby);
+const void* patch_kernel_f64r(int M, bool other, int* lds_bytes, int* pby);
+const void* patch_kernel_f64c(int M, bool other, int* lds_bytes, int* pby);
+
+static const void* patch_kernel(int dtype, int is_complex, int M, bool other, int* lds_bytes, int* pby) {
+    if (dtype == NUFFT_F32) return is_complex ? patch_kernel_f32c(M, other, lds_bytes, pby) : patch_kernel_f32r(M, other, lds_bytes, pby);
+    return is_complex ? patch_kernel_f64c(M, other, lds_bytes, pby) : patch_kernel_f64r(M, other, lds_bytes, pby);
+}
+
+// Patch decomposition of a plan, or eligible = false: 3-D grids of 4-cell bins whose axes are multiples of the bin
+// edge and long enough that the bins a patch visits are distinct and a stencil cannot reach a patch from both
+// sides; default window evaluation without per-point weights (those use the LDS-tile kernel).
+PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other) {
+    PatchPlan pp{};
+    int lds = 0, pby = 0;
+    if (D != 3 || !patch_kernel(dtype, is_complex, M, other, &lds, &pby)) return pp;
+    const int clo = floor_div4(1 - M), chi = floor_div4(3 + M), ncb = chi - clo + 1;
+    const int pb[3] = {4, pby, 1};
+    for (int d = 0; d < 3; ++d) {
+        if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return pp;
+        if (g.nb[d] < 2 * (pb[d] + ncb)) return pp;
+    }
+    pp.npx = (g.nb[0] + 3) / 4;
+    pp.npy = (g.nb[1] + pby - 1) / pby;
+    // segments along dimension 3: enough tasks for ~4 rounds of the 2048 resident waves, at least 8 cube layers each
+    // (a segment visits ncb - 1 bin layers beyond its own)
+    const int cols = pp.npx * pp.npy;
+    int nseg = (8192 + cols - 1) / cols;
+    const int max_seg = g.nb[2] / 8 > 0 ? g.nb[2] / 8 : 1;
+    if (nseg > max_seg) nseg = max_seg;
+    if (nseg < 1) nseg = 1;
+    pp.segl = (g.nb[2] + nseg - 1) / nseg;
+    pp.nseg = (g.nb[2] + pp.segl - 1) / pp.segl;
+    pp.ntasks = cols * pp.nseg;
+    pp.lds_bytes = lds;
+    pp.eligible = true;
+    return pp;
+}
+
+hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other) {
+    int lds = 0, pby = 0;
+    const void* fn = patch_kernel(dtype, is_complex, M, other, &lds, &pby);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+template <typename T>
+static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
+                                 hipStream_t stream) {
+    int lds = 0, pby = 0;
+    const void* fn = patch_kernel(a.dtype, a.is_complex, a.M, false, &lds, &pby);
+    if (!fn) return hipErrorInvalidValue;
+    for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
+        const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
+        PatchArgs<T> k{};
+        k.t = fill_tile_args<T>(a, c0, nc);
+        k.pg.npx = pp.npx; k.pg.npy = pp.npy; k.pg.nseg = pp.nseg; k.pg.segl = pp.segl; k.pg.ntasks = pp.ntasks;
+        for (int c = 0; c < nc; ++c) k.vsorted[c] = static_cast<const T*>(vsorted) + (int64_t)(c0 + c) * vstride_reals;
+        void* params[] = {&k};
+        const unsigned nwg = (unsigned)((pp.ntasks + kPatchWaves - 1) / kPatchWaves);
+        hipError_t e = hipLaunchKernel(fn, dim3(nwg, (unsigned)nc, 1), dim3(kPatchWaves * kWave, 1, 1), params, (size_t)lds, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
+                               hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_patch_t<float>(a, pp, vsorted, vstride_reals, stream)
+                                : launch_patch_t<double>(a, pp, vsorted, vstride_reals, stream);
+}
+
+// values of one component in sorted order (times the per-point weights of the callback menu)
+template <typename T, int NC>
+static hipError_t gather_t(int D, const void* sorted, int64_t np, const void* vin, const void* weights, void* vout, hipStream_t stream) {
+    if (np <= 0) return hipSuccess;
+    const int rec_bytes = (int)sizeof(T) * D + 4 > 16 ? 32 : ((int)sizeof(T) * D + 4 > 8 ? 16 : 8);
+    const int idx_off = D * (int)sizeof(T);
+    int64_t blocks = (np + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const unsigned char* r = static_cast<const unsigned char*>(sorted);
+    const T* vi = static_cast<const T*>(vin);
+    const T* w = static_cast<const T*>(weights);
+    T* vo = static_cast<T*>(vout);
+    switch (rec_bytes) {
+        case 8: hipLaunchKernelGGL((gather_values_kernel<T, NC, 8>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo); break;
+        case 16: hipLaunchKernelGGL((gather_values_kernel<T, NC, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo); break;
+        default: hipLaunchKernelGGL((gather_values_kernel<T, NC, 32>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* sorted, int64_t np, const void* vin,
+                                const void* weights, void* vout, hipStream_t stream) {
+    if (dtype == NUFFT_F32) return is_complex ? gather_t<float, 2>(D, sorted, np, vin, weights, vout, stream)
+                                              : gather_t<float, 1>(D, sorted, np, vin, weights, vout, stream);
+    return is_complex ? gather_t<double, 2>(D, sorted, np, vin, weights, vout, stream)
+                      : gather_t<double, 1>(D, sorted, np, vin, weights, vout, stream);
 }
 
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream) {

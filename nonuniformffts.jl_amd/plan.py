@@ -32,6 +32,10 @@ class DimensionMismatch(ValueError):
 
 
 # ---- small value types of the reference's API (src/Kernels/Kernels.jl:8-46) -------------------
+#: spreading engines of the library (include/nufft_mi355x.h NUFFT_SPREAD_*)
+_SPREAD_METHODS = {"auto": 0, "lds_tiles": 1, "mfma_patches": 2}
+
+
 @dataclass(frozen=True)
 class HalfSupport:
     M: int
@@ -200,7 +204,8 @@ class PlanNUFFT:
                  kernel_evalmode=None, fftshift: bool = False, gpu_method: str = "shared_memory",
                  sort_points: bool = False, synchronise: bool = False, block_size=None, point_transform=None,
                  tile_dims: Optional[Sequence[int]] = None, interp_tile_dims: Optional[Sequence[int]] = None,
-                 bin_log2: int = 0, lds_budget_bytes: int = 0, spread_threads: int = 0, interp_threads: int = 0):
+                 bin_log2: int = 0, lds_budget_bytes: int = 0, spread_threads: int = 0, interp_threads: int = 0,
+                 spread_method: Union[str, int] = "auto"):
         if dims is None:           # PlanNUFFT(dims; ...) form: ComplexF64 by default (src/plan.jl:597-599)
             Z, dims = torch.complex128, Z
         if isinstance(dims, int):
@@ -283,6 +288,7 @@ class PlanNUFFT:
         prm.lds_budget_bytes = int(lds_budget_bytes)
         prm.spread_threads = int(spread_threads)
         prm.interp_threads = int(interp_threads)
+        prm.spread_method = spread_method if isinstance(spread_method, int) else _SPREAD_METHODS[spread_method]
         _check(lib.nufft_plan_create_ex(C.byref(self._handle), C.byref(prm)))
         self._info = _lib.NufftInfo()
         _check(lib.nufft_plan_info(self._handle, C.byref(self._info)))

@@ -155,14 +155,14 @@ def test_nonuniform_distributions_spot_check_and_balance(dist):
 
 
 def test_c2_full_grid_rel_l2_against_c_oracle():
-    """Full rel-L2 over all 129 x 256 x 256 output modes of a C2-size transform (256^3, sigma = 2, m = 4, Float64;
-    Np = 4e6 to keep the CPU side at a few seconds) against the C restatement of the reference's blocked CPU
+    """Full rel-L2 over all 129 x 256 x 256 output modes of the C2 transform at its stated size (256^3, sigma = 2, m = 4,
+    Float64, Np = 1e7) against the C restatement of the reference's blocked CPU
     algorithm (oracle/nufft_oracle.c + pocketfft), and of type 2 over all points."""
     from oracle import c_oracle as CO, nufft_oracle as O
     from nufft_pkg import nufft
     if not CO.available():
         pytest.skip("oracle/libnufft_oracle.so not built")
-    Np = 4_000_000
+    Np = NP
     rng = np.random.default_rng(2024)
     xs = [rng.random(Np) * O.TWO_PI for _ in range(3)]
     v = rng.standard_normal(Np)
@@ -186,7 +186,7 @@ def test_config_c4_ntransforms3_spot_check():
     """BASELINE config C4: C2 with ntransforms = 3 (three value vectors spread / interpolated simultaneously,
     one set of points).  Exact spot checks per component; component c must equal a single transform of v_c."""
     from nufft_pkg import nufft
-    Np, C = 4_000_000, 3
+    Np, C = NP, 3                      # the stated size: Np = 1e7
     plan = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, ntransforms=C, backend=nufft.ROCBackend(0),
                            kernel_evalmode=nufft.FastApproximation())
     g = torch.Generator(device="cuda").manual_seed(31)
@@ -221,10 +221,10 @@ def test_config_c4_ntransforms3_spot_check():
 
 def test_config_c3_complexf32_m8_1024_cubed_spot_check():
     """BASELINE config C3 shape: 3-D, Ns = 512^3, ComplexF32, m = 8 (oversampled 1024^3, 8.6 GB grid; LDS pressure).
-    Np is reduced to 2e7 to keep the test short; exact spot checks of type-1 modes and type-2 points in Float64.
+    at the stated Np = 1e8; exact spot checks of type-1 modes and type-2 points in Float64.
     The reference's un-normalised Float32 window overflows at this (D, M) — see DESIGN.md §2."""
     from nufft_pkg import nufft
-    Ns, Np, M8 = 512, 20_000_000, 8
+    Ns, Np, M8 = 512, 100_000_000, 8
     plan = nufft.PlanNUFFT(torch.complex64, (Ns, Ns, Ns), m=M8, sigma=2.0, backend=nufft.ROCBackend(0),
                            kernel_evalmode=nufft.FastApproximation())
     assert plan.oversampled_dims == (1024, 1024, 1024)

@@ -281,9 +281,51 @@ def test_type1_type2_match_oracle(Z, dims, M, sigma, evalmode, C):
     _check_type1_type2(Z, dims, M, sigma, evalmode, C)
 
 
-def _check_type1_type2(Z, dims, M, sigma, evalmode, C, **kw):
+# Both spreading engines (LDS tiles with ds_add_f64; register patches accumulated by v_mfma_f64_4x4x4) on the same
+# 3-D cases, whatever the automatic choice would be: every half-support (the cube ring of the patches is 3..7 layers
+# deep for M = 2..10), all element types, ntransforms > 1, both window evaluations.
+ENGINE_CASES = [
+    (np.float64, (32, 32, 32), 4, 2.0, O.DIRECT, 1),
+    (np.float64, (64, 64, 64), 4, 1.5, O.FAST_APPROXIMATION, 2),     # 96^3
+    (np.float32, (32, 64, 32), 4, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.complex128, (32, 64, 32), 4, 2.0, O.DIRECT, 1),
+    (np.complex64, (64, 64, 64), 8, 2.0, O.FAST_APPROXIMATION, 1),   # BASELINE C3's (element type, M)
+    (np.float64, (64, 64, 64), 10, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float64, (48, 128, 32), 6, 2.0, O.DIRECT, 1),                # 96 x 256 x 64
+    (np.float64, (40, 40, 40), 2, 2.0, O.DIRECT, 1),
+    (np.float64, (40, 40, 40), 3, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.complex128, (40, 40, 40), 5, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float32, (40, 40, 40), 7, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float64, (40, 40, 40), 9, 2.0, O.DIRECT, 1),
+    (np.complex64, (40, 48, 40), 6, 2.0, O.DIRECT, 3),
+]
+
+
+@pytest.mark.parametrize("engine", ["lds_tiles", "mfma_patches"])
+@pytest.mark.parametrize("Z,dims,M,sigma,evalmode,C", ENGINE_CASES)
+def test_both_spreading_engines_match_oracle(engine, Z, dims, M, sigma, evalmode, C):
+    _check_type1_type2(Z, dims, M, sigma, evalmode, C, spread_method=engine, expect_engine=engine)
+
+
+def test_spreading_engine_selection():
+    nufft = _nufft()
+    # explicit request on a plan the patches cannot serve (2-D; odd oversampled size) -> ArgumentError, nothing silent
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.float64, (64, 64), spread_method="mfma_patches", backend=nufft.ROCBackend(0))
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.complex128, (35, 64, 40), sigma=1.5, spread_method="mfma_patches", backend=nufft.ROCBackend(0))
+    # automatic choice: patches for complex data or M >= 5 where eligible, LDS tiles otherwise
+    assert nufft.PlanNUFFT(np.float64, (64, 64, 64), backend=nufft.ROCBackend(0)).info().spread_method == 1
+    assert nufft.PlanNUFFT(np.complex128, (64, 64, 64), backend=nufft.ROCBackend(0)).info().spread_method == 2
+    assert nufft.PlanNUFFT(np.float64, (64, 64, 64), m=6, backend=nufft.ROCBackend(0)).info().spread_method == 2
+    assert nufft.PlanNUFFT(np.complex128, (35, 64, 40), sigma=1.5, backend=nufft.ROCBackend(0)).info().spread_method == 1
+
+
+def _check_type1_type2(Z, dims, M, sigma, evalmode, C, expect_engine=None, **kw):
     Np = 2000
     nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, sigma, evalmode, C, Np, seed=42, **kw)
+    if expect_engine is not None:
+        assert plan.info().spread_method == {"lds_tiles": 1, "mfma_patches": 2}[expect_engine]
     dev = plan.device
     xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
     vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
