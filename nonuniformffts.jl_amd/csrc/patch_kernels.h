@@ -415,13 +415,15 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH_OCC) void spread_p
 #pragma unroll
             for (int cx = 0; cx < PBX; ++cx) asm volatile("" : "+v"(w1[cx]));
         };
+        // (the waits sit at the END of an iteration: registers that an inline-asm read has been issued into must not
+        // cross the loop back edge, where the compiler may copy them before the data has arrived)
         issue_meta(0);
         wait_all();
         issue_ops(0);
         issue_meta(4);
+        wait_all();
 #pragma unroll 1
         for (int b0 = 0; b0 < n; b0 += 4) {
-            wait_all();
             // operands of this batch: A = w1 w2 per cube column, B = v w3 per ring slot
             double A[NCB][PBX], bz_[NC][NCB];
 #pragma unroll
@@ -454,8 +456,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH_OCC) void spread_p
                     }
                 }
             }
+            wait_all();
         }
-        wait_all();                  // the reads issued ahead of the last batch target live registers
     };
 
     // ---- main loop over the chunks of the segment ----

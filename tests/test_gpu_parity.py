@@ -467,3 +467,37 @@ def test_errors_mirror_the_reference():
         nufft.exec_type1(torch.empty((16, 16), dtype=torch.complex128, device="cuda"), plan, x)
     with pytest.raises(nufft.DimensionMismatch):    # wrong number of values, :105-114
         nufft.exec_type1(torch.empty(plan.shape, dtype=torch.complex128, device="cuda"), plan, x[:3].contiguous())
+
+
+@pytest.mark.parametrize("Z,n,M,Np,C,dist", [
+    (torch.float64, 64, 4, 1_000_000, 1, "uniform"),       # 30 points per bin: several K-batches per chunk, several chunks per run
+    (torch.float64, 64, 4, 200_000, 1, "cluster"),
+    (torch.complex64, 64, 8, 1_000_000, 1, "uniform"),
+    (torch.complex128, 64, 6, 500_000, 2, "uniform"),
+    (torch.float32, 96, 5, 1_000_000, 1, "cluster"),
+    (torch.float64, 64, 10, 300_000, 1, "uniform"),
+])
+def test_spreading_engines_agree_on_dense_point_sets(Z, n, M, Np, C, dist):
+    """The oracle-sized cases above hold at most a point or two per bin.  Here the two engines (independent
+    implementations: LDS atomics vs matrix-pipe accumulation in registers) must agree on dense and clustered sets,
+    where a run of the sorted array spans many chunks and every K-batch of the patches is full."""
+    nufft = _nufft()
+    T = torch.float32 if Z in (torch.float32, torch.complex64) else torch.float64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    if dist == "uniform":
+        xs = tuple(torch.rand(Np, dtype=T, device="cuda", generator=g) * (2 * np.pi) for _ in range(3))
+    else:
+        xs = tuple(torch.randn(Np, dtype=T, device="cuda", generator=g) * 0.3 + np.pi for _ in range(3))
+    vs = tuple(torch.randn(Np, dtype=Z, device="cuda", generator=g) for _ in range(C))
+    outs = []
+    for eng in ("lds_tiles", "mfma_patches"):
+        p = nufft.PlanNUFFT(Z, (n, n, n), m=M, ntransforms=C, spread_method=eng, kernel_evalmode=nufft.FastApproximation(),
+                            backend=nufft.ROCBackend(0))
+        nufft.set_points(p, xs)
+        us = tuple(torch.empty(p.shape, dtype=p.eltype, device="cuda") for _ in range(C))
+        nufft.exec_type1(us if C > 1 else us[0], p, vs if C > 1 else vs[0])
+        outs.append(us)
+    tol = 5e-6 if T == torch.float32 else 1e-13
+    for c in range(C):
+        assert bool(torch.isfinite(torch.view_as_real(outs[1][c])).all())
+        assert float((outs[0][c] - outs[1][c]).norm() / outs[0][c].norm()) < tol
