@@ -98,6 +98,7 @@ struct PatchArgs {
     TileArgs<T> t;                  // geometry, sorted records, bin offsets, window parameters, grids
     PatchGeom pg;
     const T* vsorted[kMaxCompPerLaunch];   // values in sorted order (gather_values_kernel), NC reals per point
+    unsigned long long* prof;              // NUFFT_PATCH_PROFILE builds: cycles per phase, summed over the waves
 };
 
 // Values in sorted order: vs[p] = v[idx[p]] (* weight[idx[p]]: callbacks.nonuniform, src/spreading/gpu.jl:289)
@@ -460,6 +461,12 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH_OCC) void spread_p
         }
     };
 
+#if defined(NUFFT_PATCH_PROFILE)
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define NUFFT_PH(i) do { const unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; } while (0)
+#else
+#define NUFFT_PH(i) do { } while (0)
+#endif
     // ---- main loop over the chunks of the segment ----
     Cursor nxt{bz_first, -1, 0u, 0u};
     bool has = advance(nxt);
@@ -467,16 +474,27 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH_OCC) void spread_p
     int bz_done = bz_first;
     while (has) {
         const Cursor cur = nxt;
+        NUFFT_PH(0);
         while (bz_done < cur.bz) { retire(bz_done); ++bz_done; }      // (wipes the staged points: before the commit)
+        NUFFT_PH(1);
         wave_lds_fence();
         commit_prefetch();
+        NUFFT_PH(2);
         has = advance(nxt);
         if (has) issue_prefetch(nxt);
+        NUFFT_PH(0);
         const int n = (int)min((uint32_t)CH, cur.pe - cur.p);
         eval_chunk(n);
+        NUFFT_PH(3);
         dispatch_row<0, NRB>(cur.u >> 1, [&](auto Rc) __attribute__((always_inline)) { batches(Rc, n); });
+        NUFFT_PH(4);
     }
     while (bz_done <= bz_last) { retire(bz_done); ++bz_done; }
+    NUFFT_PH(1);
+#if defined(NUFFT_PATCH_PROFILE)
+    if (lane == 0 && a.prof)
+        for (int i = 0; i < 5; ++i) atomicAdd(a.prof + i, tph[i]);
+#endif
 }
 
 }  // namespace nufft

@@ -1,5 +1,6 @@
 // Host-side dispatch of the tile kernels over (precision, complex?, D, M).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include "kernels.h"
 #include "tile_kernels.h"
@@ -197,10 +198,25 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
         k.t = fill_tile_args<T>(a, c0, nc);
         k.pg.npx = pp.npx; k.pg.npy = pp.npy; k.pg.nseg = pp.nseg; k.pg.segl = pp.segl; k.pg.ntasks = pp.ntasks;
         for (int c = 0; c < nc; ++c) k.vsorted[c] = static_cast<const T*>(vsorted) + (int64_t)(c0 + c) * vstride_reals;
+        k.prof = nullptr;
+#if defined(NUFFT_PATCH_PROFILE)
+        static unsigned long long* prof_dev = nullptr;       // development builds: phase cycles of the last launch on stderr
+        if (!prof_dev) { (void)hipMalloc(&prof_dev, 8 * sizeof(unsigned long long)); }
+        (void)hipMemsetAsync(prof_dev, 0, 8 * sizeof(unsigned long long), stream);
+        k.prof = prof_dev;
+#endif
         void* params[] = {&k};
         const unsigned nwg = (unsigned)((pp.ntasks + kPatchWaves - 1) / kPatchWaves);
         hipError_t e = hipLaunchKernel(fn, dim3(nwg, (unsigned)nc, 1), dim3(kPatchWaves * kWave, 1, 1), params, (size_t)lds, stream);
         if (e != hipSuccess) return e;
+#if defined(NUFFT_PATCH_PROFILE)
+        unsigned long long h[8];
+        (void)hipMemcpyAsync(h, k.prof, sizeof(h), hipMemcpyDeviceToHost, stream);
+        (void)hipStreamSynchronize(stream);
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        fprintf(stderr, "patch phases (%% of wave cycles): advance+prefetch %.1f  retire %.1f  commit %.1f  eval %.1f  batches %.1f  (total %.3g cycles)\n",
+                100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, tot);
+#endif
     }
     return hipSuccess;
 }
