@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the NUFFT hot path on MI355X (driver contract: one JSON line on rank 0).
 
-Workload (BASELINE.json configs[1], "C2"): 3-D, Ns = 256^3, Np = 1e7 uniform-random points, Float64
-real data, m = HalfSupport(4), sigma = 2 (plan default) -> oversampled grid 512^3.
+Workloads (BASELINE.json ``configs``; ``--config``):
+  c2 (default, the configuration the metric is quoted on): 3-D type-1 + type-2, Ns = 256^3, Np = 1e7 uniform-random
+      points, Float64 real data, m = HalfSupport(4), sigma = 2 (plan default) -> oversampled grid 512^3
+  c3: 3-D type-1, Ns = 512^3, Np = 1e8, ComplexF32, m = 8 (oversampled 1024^3)
+  c4: c2 with ntransforms = 3 (three value vectors spread / interpolated with one set of points)
+  (configs[0] is the reference's CPU-only plumbing case and configs[4] = c2 on N GPUs: ``--gpus N``.)
 
 A *step* follows the reference's published protocol (benchmark/CPU+AMDGPU/run_benchmarks.jl:80-90):
-``set_points!`` + ``exec_type1!`` on inputs already resident in HBM.  ``value`` = whole-job NU-points/s
-of K such steps (max over ranks).  The same protocol for type-2 is timed in a second region and
-reported under ``type2``.  Stage times come from HIP events recorded on the launch stream *inside*
-the timed region (torch events on the current stream, which is the stream handed to the C ABI).
+``set_points!`` + ``exec_type1!`` on inputs already resident in HBM.  ``value`` = whole-job NU-points/s of K such
+steps (max over ranks) with the window evaluation the reference's ROC backend defaults to (``Direct()``,
+ext/NonuniformFFTsAMDGPUExt.jl:56); the same measurement with ``FastApproximation()`` (the reference's CPU default)
+is the sibling record ``fast_approximation`` — both are first-class.  Type-2 is timed the same way in a second
+region.  Stage times come from HIP events recorded on the launch stream *inside* the timed region (torch events
+on the current stream, which is the stream handed to the C ABI).
 
-N > 1: one process per GPU (torchrun), every rank owns an independent C2 problem with its own seed
-(BASELINE configs[4]: batch of independent plans, one per GPU; weak scaling).  No collective on the
-data path; the only RCCL call is the gather of the output spectra to rank 0, issued on a side stream
-and overlapped with the next step.
+N > 1 (``--gpus N``; without a launcher this script starts the N ranks itself): one process per GPU, every rank
+owns an independent problem with its own seed (BASELINE configs[4]: batch of independent plans, one per GPU; weak
+scaling).  No collective on the data path; the only RCCL call is the gather of the output spectra to rank 0,
+issued on a side stream and overlapped with the next step.
 """
 import argparse
 import json
@@ -27,45 +33,62 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s measured copy rate
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+CONFIGS = {
+    "c2": dict(Z="float64", n=256, np=1e7, m=4, sigma=2.0, C=1, steps=20,
+               label="C2: 3-D type-1+type-2, Ns=256^3, Np=1e7 uniform-random per GPU, Float64 real"),
+    "c3": dict(Z="complex64", n=512, np=1e8, m=8, sigma=2.0, C=1, steps=5,
+               label="C3: 3-D type-1, Ns=512^3, Np=1e8 uniform-random, ComplexF32 (high accuracy, LDS pressure)"),
+    "c4": dict(Z="float64", n=256, np=1e7, m=4, sigma=2.0, C=3, steps=10,
+               label="C4: 3-D ntransforms=3, Ns=256^3, Np=1e7 uniform-random, Float64 real (vector-valued simultaneous spread)"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0: the configuration's default)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=256, help="uniform grid size per dimension")
-    ap.add_argument("--np", type=float, default=1e7, help="non-uniform points per GPU")
-    ap.add_argument("--m", type=int, default=4)
-    ap.add_argument("--sigma", type=float, default=2.0)
-    ap.add_argument("--evalmode", default="fast", choices=["direct", "fast"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--n", type=int, default=0, help="override: uniform grid size per dimension")
+    ap.add_argument("--np", type=float, default=0, help="override: non-uniform points per GPU")
+    ap.add_argument("--m", type=int, default=0)
+    ap.add_argument("--sigma", type=float, default=0)
+    ap.add_argument("--evalmode", default="direct", choices=["direct", "fast"],
+                    help="window evaluation of the headline value (default: the reference's ROC default, Direct)")
+    ap.add_argument("--only-headline", action="store_true", help="skip the sibling evaluation mode, the reference "
+                    "protocol, the density sweep, the HBM probe and the CPU baseline (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-reference-protocol", action="store_true")
+    ap.add_argument("--no-density-sweep", action="store_true")
     ap.add_argument("--force-distributed", action="store_true",
                     help="take the multi-process code path (RCCL init, side-stream gather) even with one rank: "
                          "a single-GPU self-test of the N > 1 path")
     return ap.parse_args()
 
 
-def algorithmic_bytes(Np, Nover, Nout):
-    """SURVEY.md §8(d), Float64 real data, D = 3 (bytes per launch / per transform)."""
-    G = float(np.prod(Nover)) * 8                      # oversampled real grid
-    S = float((Nover[0] // 2 + 1) * Nover[1] * Nover[2]) * 16
-    Oo = float(np.prod(Nout)) * 16
-    P = Np * (3 * 8 + 8 + 4)                           # coordinates + value + permutation index
+def algorithmic_bytes(Np, Nover, Nout, is_complex, real_bytes, C):
+    """SURVEY.md §8(d) (bytes per launch / per transform), D = 3: G = oversampled grid of one component, S = its
+    spectrum, O = output, P = point data (coordinates + value + permutation index)."""
+    zb = real_bytes * (2 if is_complex else 1)
+    G = float(np.prod(Nover)) * zb
+    S = float(np.prod(Nover)) * 2 * real_bytes if is_complex else float((Nover[0] // 2 + 1) * Nover[1] * Nover[2]) * 2 * real_bytes
+    Oo = float(np.prod(Nout)) * 2 * real_bytes
+    Pc = Np * (3 * real_bytes + 4)                     # coordinates + permutation index: once
+    Pv = Np * zb                                       # value: per component
     return {
-        # SURVEY §8(d) "type-1 zero + spread" = W(G) zero + R(points) + RMW(G) flush = 3G + P.  The
-        # output-driven spreading kernel performs that whole stage in one launch (it writes every grid
-        # cell once and needs no zero fill), so its own compulsory traffic is only G + P
-        # ("spread_kernel_min"); both figures are reported.
-        "spread_kernel": 3 * G + P,
-        "spread_kernel_min": G + P,
-        "interp_kernel": G + P,                        # R(G) + R(coords) + W(values)
-        "type1_exec": 3 * G + P + (G + S) + 2 * Oo,    # zero + spread, FFT (single-pass ideal), deconv (SURVEY 5.96 GB)
-        "type2_exec": (S + 2 * Oo) + (S + G) + (G + P),
-        "set_points": 2.0 * Np * 3 * 8,
+        # SURVEY §8(d) "type-1 zero + spread" = W(G) zero + R(points) + RMW(G) flush = 3G + P per component.  Both
+        # spreading engines perform that whole stage in one launch per component, write every grid cell once and need
+        # no zero fill, so their own compulsory traffic is G + P ("spread_kernel_min"); both figures are reported.
+        "spread_kernel": C * (3 * G + Pv) + Pc,
+        "spread_kernel_min": C * (G + Pv) + Pc,
+        "interp_kernel": C * (G + Pv) + Pc,            # R(G) + R(coords) + W(values)
+        "type1_exec": C * (3 * G + Pv + (G + S) + 2 * Oo) + Pc,    # zero + spread, FFT (single-pass ideal), deconv
+        "type2_exec": C * ((S + 2 * Oo) + (S + G) + (G + Pv)) + Pc,
+        "set_points": 2.0 * Np * 3 * real_bytes,
+        "G": G,
     }
 
 
@@ -75,7 +98,7 @@ def pmc_traffic(kernel_substr):
     passes of this same command, with the gfx950 FETCH_SIZE correction).  Counters cannot be collected
     inside the timed run; None if no summary is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))      # round<N>_<letter>_...: newest last
     for f in reversed(files):
         try:
             ks = json.load(open(f))["kernels"]
@@ -107,6 +130,29 @@ def launch_ranks(a):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def hbm_probe(dev):
+    """Measured HBM roofline of this box (device-to-device copy / triad over buffers far larger than the
+    256 MB infinity cache).  GB/s of algorithmic bytes: copy moves 2 x, triad 3 x the buffer.  (The stand-alone
+    hand-written version of the same probe is scripts/hbm_roofline.hip; its output is in profiles/.)"""
+    n = (1 << 31) // 8                                  # 2 GiB per buffer
+    a_ = torch.empty(n, dtype=torch.float64, device=dev)
+    b_ = torch.ones(n, dtype=torch.float64, device=dev)
+    c_ = torch.ones(n, dtype=torch.float64, device=dev)
+    res = {}
+    for name, fn, moved in (("copy", lambda: a_.copy_(b_), 2.0), ("triad", lambda: torch.add(b_, c_, alpha=0.5, out=a_), 3.0)):
+        best = 1e30
+        for r in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); e1.synchronize()
+            if r:
+                best = min(best, e0.elapsed_time(e1))
+        res[name + "_GBs"] = moved * n * 8 / (best * 1e-3) / 1e9
+    del a_, b_, c_
+    torch.cuda.empty_cache()
+    res["peak_measured_GBs"] = max(res["copy_GBs"], res["triad_GBs"])
+    return res
+
+
 def main():
     a = parse()
     if "RANK" not in os.environ and (a.gpus > 1 or a.force_distributed):
@@ -128,178 +174,218 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from nufft_pkg import nufft
-
-    Np = int(a.np)
-    dims = (a.n, a.n, a.n)
-    mode = nufft.Direct() if a.evalmode == "direct" else nufft.FastApproximation()
-    plan = nufft.PlanNUFFT(torch.float64, dims, m=a.m, sigma=a.sigma, kernel_evalmode=mode,
-                           backend=nufft.ROCBackend(local_rank))
-    info = plan.info()
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
-    xs = tuple(torch.rand(Np, dtype=torch.float64, device=dev, generator=g) * (2 * np.pi) for _ in dims)
-    vp = torch.randn(Np, dtype=torch.float64, device=dev, generator=g)
-    uhat = [torch.empty(plan.shape, dtype=torch.complex128, device=dev) for _ in range(2)]   # double buffer
-    vout = torch.empty(Np, dtype=torch.float64, device=dev)
-
-    lib, C = nufft.lib, __import__("ctypes")
+    import ctypes as C
     from nonuniformffts_jl_amd.plan import _check, _ptr_table
+    lib = nufft.lib
+
+    cfg = dict(CONFIGS[a.config])
+    for k in ("n", "np", "m", "sigma"):
+        if getattr(a, k):
+            cfg[k] = getattr(a, k)
+    Z = getattr(torch, cfg["Z"])
+    is_complex = Z.is_complex
+    T = torch.float32 if Z in (torch.float32, torch.complex64) else torch.float64
+    CT = torch.complex64 if T == torch.float32 else torch.complex128
+    real_bytes = 4 if T == torch.float32 else 8
+    Np, Cn = int(cfg["np"]), int(cfg["C"])
+    dims = (cfg["n"],) * 3
+    steps = a.steps if a.steps > 0 else cfg["steps"]
+    full = world == 1 and not a.only_headline
+
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    xs = tuple(torch.rand(Np, dtype=T, device=dev, generator=g) * (2 * np.pi) for _ in dims)
+    vps = tuple(torch.randn(Np, dtype=Z, device=dev, generator=g) for _ in range(Cn))
 
     gather_stream = torch.cuda.Stream(device=dev) if distributed and not a.no_gather else None
-    gather_list = None
-    if gather_stream is not None and rank == 0:
-        # complex spectra travel as their (re, im) real views (same bytes; every backend supports reals)
-        gather_list = [[torch.empty_like(torch.view_as_real(uhat[0])) for _ in range(world)] for _ in range(2)]
-    gather_done = [None, None]
 
     def stream_ptr():
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-    def step_type1(k, events=None):
-        """set_points! + exec_type1! (the four stages of src/NonuniformFFTs.jl:157-186, called one by one
-        so that HIP events can be recorded between them on the launch stream)."""
-        out = uhat[k % 2]
-        if gather_done[k % 2] is not None:    # the gather that still reads this buffer must be done
-            torch.cuda.current_stream(dev).wait_event(gather_done[k % 2])
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if events is not None else None
-        s = stream_ptr()
-        if ev: ev[0].record()
-        nufft.set_points(plan, xs)
-        if ev: ev[1].record()
-        if ev: ev[2].record()      # "(0) fill with zeros" no longer exists: the spreading kernel writes every cell
-        _check(lib.nufft_spread(plan._handle, _ptr_table((vp,)), s))
-        if ev: ev[3].record()
-        _check(lib.nufft_fft_forward(plan._handle, s))
-        if ev: ev[4].record()
-        _check(lib.nufft_deconvolve_truncate(plan._handle, _ptr_table((out,)), s))
-        if ev: ev[5].record()
-        if events is not None:
-            events.append(ev)
-        if gather_stream is not None:
-            done = torch.cuda.Event()
-            done.record()
-            gather_stream.wait_event(done)
-            with torch.cuda.stream(gather_stream):
+    def measure(evalmode_name):
+        """K steps of set_points! + exec_type1!, then of set_points! + exec_type2!, with stage events."""
+        mode = nufft.Direct() if evalmode_name == "direct" else nufft.FastApproximation()
+        plan = nufft.PlanNUFFT(Z, dims, m=cfg["m"], sigma=cfg["sigma"], ntransforms=Cn, kernel_evalmode=mode,
+                               backend=nufft.ROCBackend(local_rank))
+        info = plan.info()
+        uhat = [tuple(torch.empty(plan.shape, dtype=CT, device=dev) for _ in range(Cn)) for _ in range(2)]   # double buffer
+        vout = tuple(torch.empty(Np, dtype=Z, device=dev) for _ in range(Cn))
+        gather_list = None
+        if gather_stream is not None and rank == 0:
+            # complex spectra travel as their (re, im) real views (same bytes; every backend supports reals)
+            gather_list = [[torch.empty_like(torch.view_as_real(uhat[0][0])) for _ in range(world)] for _ in range(2)]
+        gather_done = [None, None]
+        use_gather = [gather_stream is not None]
+
+        def step_type1(k, events=None):
+            """set_points! + exec_type1! (the stages of src/NonuniformFFTs.jl:157-186, called one by one so that
+            HIP events can be recorded between them on the launch stream)."""
+            out = uhat[k % 2]
+            if gather_done[k % 2] is not None:    # the gather that still reads this buffer must be done
+                torch.cuda.current_stream(dev).wait_event(gather_done[k % 2])
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if events is not None else None
+            s = stream_ptr()
+            if ev: ev[0].record()
+            nufft.set_points(plan, xs)
+            if ev: ev[1].record()
+            _check(lib.nufft_spread(plan._handle, _ptr_table(vps), s))      # writes every grid cell: no fill_with_zeros stage
+            if ev: ev[2].record()
+            _check(lib.nufft_fft_forward(plan._handle, s))
+            if ev: ev[3].record()
+            _check(lib.nufft_deconvolve_truncate(plan._handle, _ptr_table(out), s))
+            if ev: ev[4].record()
+            if events is not None:
+                events.append(ev)
+            if use_gather[0]:
                 import torch.distributed as dist
-                dist.gather(torch.view_as_real(out), gather_list[k % 2] if rank == 0 else None, dst=0)   # stream-ordered, host does not block
-                e = torch.cuda.Event()
-                e.record()
-                gather_done[k % 2] = e
+                done = torch.cuda.Event()
+                done.record()
+                gather_stream.wait_event(done)
+                with torch.cuda.stream(gather_stream):
+                    dist.gather(torch.view_as_real(out[0]), gather_list[k % 2] if rank == 0 else None, dst=0)   # stream-ordered, host does not block
+                    e = torch.cuda.Event()
+                    e.record()
+                    gather_done[k % 2] = e
 
-    def step_type2(k, events=None):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if events is not None else None
-        s = stream_ptr()
-        if ev: ev[0].record()
-        nufft.set_points(plan, xs)
-        if ev: ev[1].record()
-        _check(lib.nufft_deconvolve_pad(plan._handle, _ptr_table((uhat[0],)), s))
-        if ev: ev[2].record()
-        _check(lib.nufft_fft_backward(plan._handle, s))
-        if ev: ev[3].record()
-        _check(lib.nufft_interpolate(plan._handle, _ptr_table((vout,)), s))
-        if ev: ev[4].record()
-        if events is not None:
-            events.append(ev)
+        def step_type2(k, events=None):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if events is not None else None
+            s = stream_ptr()
+            if ev: ev[0].record()
+            nufft.set_points(plan, xs)
+            if ev: ev[1].record()
+            _check(lib.nufft_deconvolve_pad(plan._handle, _ptr_table(uhat[0]), s))
+            if ev: ev[2].record()
+            _check(lib.nufft_fft_backward(plan._handle, s))
+            if ev: ev[3].record()
+            _check(lib.nufft_interpolate(plan._handle, _ptr_table(vout), s))
+            if ev: ev[4].record()
+            if events is not None:
+                events.append(ev)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if distributed:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        def barrier():
+            torch.cuda.synchronize(dev)
+            if distributed:
+                import torch.distributed as dist
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
-    def timed(step_fn, K, W):
-        for k in range(W):
-            step_fn(k)
-        events = []
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(K):
-            step_fn(k, events)
-        if gather_stream is not None:
-            gather_stream.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        if distributed:
-            import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, events
+        def timed(step_fn, K, W):
+            for k in range(W):
+                step_fn(k)
+            events = []
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(K):
+                step_fn(k, events)
+            if use_gather[0]:
+                gather_stream.synchronize()
+            barrier()
+            dt = time.perf_counter() - t0
+            if distributed:
+                import torch.distributed as dist
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt, events
 
-    def stage_ms(events, names):
-        out = {}
-        for i, name in enumerate(names):
-            vals = [ev[i].elapsed_time(ev[i + 1]) for ev in events]
-            out[name] = float(np.mean(vals))
-        return out
+        def stage_ms(events, names):
+            return {name: float(np.mean([ev[i].elapsed_time(ev[i + 1]) for ev in events])) for i, name in enumerate(names)}
 
-    dt1, ev1 = timed(step_type1, a.steps, a.warmup)
-    st1 = stage_ms(ev1, ["set_points", "zero", "spread", "fft", "deconv"])
-    st1.pop("zero")      # empty interval: the spreading kernel writes every cell, no fill_with_zeros stage
-    gs_save, gather_stream = gather_stream, None      # type-2 region has no gather
-    dt2, ev2 = timed(step_type2, a.steps, a.warmup)
-    st2 = stage_ms(ev2, ["set_points", "deconv_pad", "fft", "interp"])
-    gather_stream = gs_save
+        dt1, ev1 = timed(step_type1, steps, a.warmup)
+        st1 = stage_ms(ev1, ["set_points", "spread", "fft", "deconv"])
+        use_gather[0] = False                              # the type-2 region has no gather
+        dt2, ev2 = timed(step_type2, steps, a.warmup)
+        st2 = stage_ms(ev2, ["set_points", "deconv_pad", "fft", "interp"])
+        exec1_ms = st1["spread"] + st1["fft"] + st1["deconv"]
+        exec2_ms = st2["deconv_pad"] + st2["fft"] + st2["interp"]
+        rec = {
+            "evalmode": "Direct" if evalmode_name == "direct" else "FastApproximation",
+            "value": world * Np * steps / dt1, "ms_per_step": dt1 / steps * 1e3,
+            "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt1},
+            "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt2,
+                      "ms_per_step": dt2 / steps * 1e3},
+            "spread_engine": {1: "lds_tiles", 2: "mfma_patches"}[int(info.spread_method)],
+            "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
+            "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
+        }
+        del plan, uhat, vout
+        torch.cuda.empty_cache()
+        return rec
 
-    ab = algorithmic_bytes(Np, plan.oversampled_dims, plan.size)
-    value = world * Np * a.steps / dt1
-    value2 = world * Np * a.steps / dt2
-    spread_s = st1["spread"] * 1e-3
+    head = measure(a.evalmode)
+    other = measure("fast" if a.evalmode == "direct" else "direct") if full else None
+
+    ab = algorithmic_bytes(Np, head["oversampled"], head["size"], is_complex, real_bytes, Cn)
+    st1, st2 = head["type1"]["stages_ms"], head["type2"]["stages_ms"]
     exec1_ms = st1["spread"] + st1["fft"] + st1["deconv"]
     exec2_ms = st2["deconv_pad"] + st2["fft"] + st2["interp"]
-    traffic_b, traffic_src = pmc_traffic("spread_tile_kernel<double, false, 3, 4")
-    traffic_gb = traffic_b / 1e9 if traffic_b is not None else None
+    # the dominant kernel of the step: spreading (one launch per component)
+    tname = {"float64": "double", "float32": "float", "complex64": "float", "complex128": "double"}[cfg["Z"]]
+    if head["spread_engine"] == "mfma_patches":
+        kname = f"spread_patch_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}"
+        binding = ("issue and latency of the per-visit point set-up at 8 waves per CU (VALU 36 %, LDS 44 %, FP64 matrix pipe 16 % "
+                   "busy), not HBM: see DESIGN.md section 4.4")
+    else:
+        kname = f"spread_tile_kernel<{tname}, {'true' if is_complex else 'false'}, 3, {cfg['m']}"
+        binding = ("LDS float atomics (ds_add_f64, 8.5 cycles per wave instruction per CU) and the scalar/vector issue of the "
+                   "clipped stencil loop, not HBM: see DESIGN.md section 4.2")
+    spread_s = st1["spread"] * 1e-3
+    traffic_b, traffic_src = pmc_traffic(kname)
+    probe = hbm_probe(dev) if full else None
+    peak_m = probe["peak_measured_GBs"] if probe else None
+    achieved = ab["spread_kernel"] / spread_s / 1e9
+    roofline = {
+        "bound": "hbm",
+        "kernel": kname + ", ...> (the zero + spread stage: one launch per component, C = %d)" % Cn,
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "peak_measured": peak_m, "frac_of_measured_peak": (achieved / peak_m) if peak_m else None,
+        "traffic": (traffic_b * Cn / 1e9) if traffic_b is not None else None,
+        "traffic_unit": "GB per stage (PMC FETCH_SIZE x2 + WRITE_SIZE per launch x C launches)", "traffic_source": traffic_src,
+        "binding_resource": binding,
+        "algorithmic_bytes_per_stage": ab["spread_kernel"],
+        "algorithmic_bytes_note": "SURVEY 8(d): zero + spread = 3G + P per component (what the reference's algorithm moves); the "
+                                  "kernel's own compulsory traffic is G + P (every cell written once, no zero fill): achieved_own_traffic",
+        "own_traffic_bytes_per_stage": ab["spread_kernel_min"],
+        "achieved_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9,
+        "frac_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9 / HBM_PEAK_GBS,
+        "kernel_ms": st1["spread"],
+        "type1_exec_frac": ab["type1_exec"] / (exec1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "type2_exec_frac": ab["type2_exec"] / (exec2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "type1_exec_frac_of_measured_peak": (ab["type1_exec"] / (exec1_ms * 1e-3) / 1e9 / peak_m) if peak_m else None,
+        "type2_exec_frac_of_measured_peak": (ab["type2_exec"] / (exec2_ms * 1e-3) / 1e9 / peak_m) if peak_m else None,
+        "hbm_probe": probe,
+    }
+    tname_z = {"float64": "Float64", "float32": "Float32", "complex64": "ComplexF32", "complex128": "ComplexF64"}[cfg["Z"]]
     result = {
-        "metric": "NU-points/s, type-1 NUFFT (set_points! + exec_type1!), 256^3 Float64 m=4",
-        "value": value,
+        "metric": f"NU-points/s, type-1 NUFFT (set_points! + exec_type1!), {cfg['n']}^3 {tname_z} m={cfg['m']}",
+        "value": head["value"],
         "unit": "NU-points/s",
         "n_gpus": world,
-        "steps": a.steps,
+        "steps": steps,
         "warmup": a.warmup,
-        "ms_per_step": dt1 / a.steps * 1e3,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": {"float64": "f64", "float32": "f32", "complex64": "c64 (f32 arithmetic, f64 accumulation)", "complex128": "c128"}[cfg["Z"]],
         "data": "synthetic",
         "config": {
-            "workload": f"C2: 3-D type-1+type-2, Ns={a.n}^3, Np={Np:.0e} uniform-random per GPU, Float64 real, "
-                        f"m={a.m}, sigma={a.sigma} (oversampled {plan.oversampled_dims}), "
-                        f"{'Direct' if a.evalmode == 'direct' else 'FastApproximation'} window",
+            "workload": f"{cfg['label']}, m={cfg['m']}, sigma={cfg['sigma']} (oversampled {tuple(head['oversampled'])}), "
+                        f"ntransforms={Cn}, {head['evalmode']} window (the reference's ROC-backend default is Direct)",
             "protocol": "set_points! + exec_type1! per step, inputs resident in HBM (reference benchmark protocol)",
-            "spread_tile": [int(info.spread_tile[d]) for d in range(3)],
-            "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
-            "lds_bytes": int(info.lds_bytes_spread),
-            "parallelism": f"{world} independent plan(s), one per GPU" + ("" if world == 1 or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
+            "spread_engine": head["spread_engine"], "spread_tile": head["spread_tile"], "interp_tile": head["interp_tile"],
+            "parallelism": f"{world} independent plan(s), one per GPU" + ("" if not distributed or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "spread_tile_kernel<double,false,3,4,false> (zero + spread stage, one launch)",
-            "achieved": ab["spread_kernel"] / spread_s / 1e9,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": ab["spread_kernel"] / spread_s / 1e9 / HBM_PEAK_GBS,
-            "traffic": traffic_gb,
-            "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-            "traffic_source": traffic_src,
-            "binding_resource": "LDS float atomics (ds_add_f64, 8.5 cycles per wave instruction per CU) and the "
-                                "scalar/vector issue of the clipped stencil loop, not HBM: see DESIGN.md section 4.2",
-            "algorithmic_bytes_per_launch": ab["spread_kernel"],
-            "min_traffic_bytes_per_launch": ab["spread_kernel_min"],
-            "achieved_min_traffic": ab["spread_kernel_min"] / spread_s / 1e9,
-            "kernel_ms": st1["spread"],
-            "type1_exec_frac": ab["type1_exec"] / (exec1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "type2_exec_frac": ab["type2_exec"] / (exec2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        },
-        "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": value},
-        "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": value2,
-                  "ms_per_step": dt2 / a.steps * 1e3},
+        "roofline": roofline,
+        "type1": head["type1"], "type2": head["type2"],
     }
-
-    if world == 1 and not a.no_reference_protocol:
-        result["reference_protocol"] = reference_protocol(a, nufft, dev)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(a)
+    if other is not None:
+        key = "fast_approximation" if other["evalmode"] == "FastApproximation" else "direct"
+        result[key] = {"evalmode": other["evalmode"], "value": other["value"], "ms_per_step": other["ms_per_step"],
+                       "type1": other["type1"], "type2": other["type2"], "spread_engine": other["spread_engine"]}
+    if full and a.config == "c2" and not a.no_reference_protocol:
+        result["reference_protocol"] = reference_protocol(cfg, nufft, dev, sweep=not a.no_density_sweep)
+    if rank == 0 and full and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if distributed:
@@ -308,45 +394,89 @@ def main():
         dist.destroy_process_group()
 
 
-def reference_protocol(a, nufft, dev):
+def published_rows():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_dat.json")))["sets"]
+    except Exception:
+        return {}
+
+
+def reference_protocol(cfg, nufft, dev, sweep=True):
     """The reference's published benchmark protocol, for comparison with BASELINE.md (not the headline metric):
     sigma = 1.5, BackwardsKaiserBessel with Direct() evaluation (the ROC defaults), coordinates ~ N(0, 1) folded
-    into the period, time = set_points! + exec! (benchmark/CPU+AMDGPU/run_benchmarks.jl:57-90), same Ns and Np."""
-    Np = int(a.np)
-    dims = (a.n, a.n, a.n)
-    plan = nufft.PlanNUFFT(torch.float64, dims, m=a.m, sigma=1.5, kernel_evalmode=nufft.Direct(), backend=nufft.ROCBackend(dev.index or 0))
-    g = torch.Generator(device=dev).manual_seed(4242)
-    xs = tuple(torch.randn(Np, dtype=torch.float64, device=dev, generator=g) for _ in dims)
-    v = torch.randn(Np, dtype=torch.float64, device=dev, generator=g)
+    into the period, time = set_points! + exec! + sync, median over repetitions
+    (benchmark/CPU+AMDGPU/run_benchmarks.jl:57-90), and its density sweep rho = Np / N^3 in 10^(-4:0.5:1) (:287-291)
+    next to the rows the reference published for MI300A (tests/golden/reference_dat.json)."""
+    n, m = cfg["n"], cfg["m"]
+    dims = (n, n, n)
+    plan = nufft.PlanNUFFT(torch.float64, dims, m=m, sigma=1.5, kernel_evalmode=nufft.Direct(), backend=nufft.ROCBackend(dev.index or 0))
     u = torch.empty(plan.shape, dtype=torch.complex128, device=dev)
-    out = torch.empty(Np, dtype=torch.float64, device=dev)
-    res = {}
-    for name, fn in (("type1", lambda: nufft.exec_type1(u, plan, v)), ("type2", lambda: nufft.exec_type2(out, plan, u))):
-        for _ in range(2):
+    pub = {r["Np"]: r for r in published_rows().get("Float64_ROC_shared", {}).get("rows", [])}
+
+    def run(Np, reps):
+        g = torch.Generator(device=dev).manual_seed(4242)
+        xs = tuple(torch.randn(Np, dtype=torch.float64, device=dev, generator=g) for _ in dims)
+        v = torch.randn(Np, dtype=torch.float64, device=dev, generator=g)
+        out = torch.empty(Np, dtype=torch.float64, device=dev)
+        res = {}
+        for name, fn in (("type1", lambda: nufft.exec_type1(u, plan, v)), ("type2", lambda: nufft.exec_type2(out, plan, u))):
             nufft.set_points(plan, xs); fn()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        K = 10
-        for _ in range(K):
-            nufft.set_points(plan, xs); fn()
-        torch.cuda.synchronize(dev)
-        res[name + "_pts_per_s"] = Np * K / (time.perf_counter() - t0)
-    res["config"] = f"Ns={a.n}^3, Np={Np:.0e} ~ N(0,1) folded, Float64, m={a.m}, sigma=1.5 (oversampled {plan.oversampled_dims}), Direct window, set_points! + exec!"
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                nufft.set_points(plan, xs); fn()
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            res[name + "_s"] = float(np.median(ts))
+            res[name + "_pts_per_s"] = Np / res[name + "_s"]
+        return res
+
+    Np = int(cfg["np"])
+    res = run(Np, 10)
+    res["config"] = f"Ns={n}^3, Np={Np:.0e} ~ N(0,1) folded, Float64, m={m}, sigma=1.5 (oversampled {plan.oversampled_dims}), Direct window, set_points! + exec! + sync, median of 10"
     res["published_mi300a_pts_per_s"] = {"type1": "2.4e8-2.7e8", "type2": "6.2e8-9.6e8", "source": "BASELINE.md (Np = 1.7e7 ... 1.7e8)"}
+    if sweep:
+        rows = []
+        for k in range(11):                                   # rho = 10^(-4 + k / 2), Np = round(rho N^3): the reference's list
+            rho = 10.0 ** (-4 + 0.5 * k)
+            Npk = int(round(rho * n ** 3))
+            r = run(Npk, 5 if Npk > 2e7 else 8)
+            row = {"rho": rho, "Np": Npk, "type1_s": r["type1_s"], "type2_s": r["type2_s"],
+                   "type1_pts_per_s": r["type1_pts_per_s"], "type2_pts_per_s": r["type2_pts_per_s"]}
+            if Npk in pub:
+                row["mi300a_published"] = {"type1_s": pub[Npk]["type1_s"], "type2_s": pub[Npk]["type2_s"]}
+            rows.append(row)
+        res["density_sweep"] = rows
     return res
 
 
-def cpu_baseline(a):
+def cpu_baseline(cfg):
     """The oracle's C restatement of the reference's blocked CPU algorithm (+ pocketfft), timed on the
     host cores of this box on a bounded sample of the same workload (kind = "port": the reference's
     Julia CPU backend cannot run here — no Julia runtime)."""
+    note = {}
+    rows = published_rows().get("Float64_CPU", {})
+    if rows:
+        big = [r for r in rows["rows"] if r["Np"] >= 1.6e7][:1]
+        if big:
+            note = {"reference_published_cpu": {"pts_per_s_type1": big[0]["Np"] / big[0]["type1_s"], "Np": big[0]["Np"],
+                                                "device": rows["header"].get("Device"), "sigma": 1.5,
+                                                "source": "benchmark/CPU+AMDGPU/results.MI300A_adastra/" + rows["file"],
+                                                "note": "the reference's own CPU backend on its machine (other hardware, sigma = 1.5, denser "
+                                                        "points): 4-5x this port's figure, which merges 13.8k-cell padded blocks holding "
+                                                        "~300 points each at C2's density"}}
     try:
         from oracle import c_oracle as CO, nufft_oracle as O
+        if cfg["Z"] != "float64" or cfg["C"] != 1:
+            return dict({"value": None, "unit": "NU-points/s", "cores": 0, "kind": "port",
+                         "sample": "timed on the C2 workload only (bench.py --config c2)"}, **note)
         if not CO.available():
-            return {"value": None, "unit": "NU-points/s", "cores": 0, "kind": "port", "sample": "oracle/libnufft_oracle.so not built"}
+            return dict({"value": None, "unit": "NU-points/s", "cores": 0, "kind": "port", "sample": "oracle/libnufft_oracle.so not built"}, **note)
         cores = CO.num_threads()
-        dims = (a.n, a.n, a.n)
-        oplan = O.OraclePlan(dims, is_real=True, M=a.m, sigma=a.sigma, evalmode=O.FAST_APPROXIMATION)
+        n, m, sigma, Np_full = cfg["n"], cfg["m"], cfg["sigma"], int(cfg["np"])
+        dims = (n, n, n)
+        oplan = O.OraclePlan(dims, is_real=True, M=m, sigma=sigma, evalmode=O.FAST_APPROXIMATION)
         rng = np.random.default_rng(42)
 
         def run(Np):
@@ -360,16 +490,16 @@ def cpu_baseline(a):
         t_probe = run(200_000)                  # dominated by the 512^3 FFT: the fixed cost
         t_mid = run(1_000_000)
         per_pt = max((t_mid - t_probe) / 800_000, 1e-9)
-        Np_s = int(min(a.np, max(1_000_000, (12.0 - t_probe) / per_pt)))
+        Np_s = int(min(Np_full, max(1_000_000, (12.0 - t_probe) / per_pt)))
         t = run(Np_s)
-        return {"value": Np_s / t, "unit": "NU-points/s", "cores": cores, "kind": "port",
-                "sample": f"one set_points+type-1 transform, same grid ({a.n}^3, sigma={a.sigma}, m={a.m}), "
-                          f"Np={Np_s} of {int(a.np)} points, {t:.1f} s wall; C/OpenMP blocked spreading (plain adds under a lock, "
-                          f"the reference's default) + scipy pocketfft; threads = CPUs available to the process "
-                          f"(affinity capped by the cgroup quota: {CO.available_cpus()} of {os.cpu_count()} logical CPUs)",
-                "seconds": t}
+        return dict({"value": Np_s / t, "unit": "NU-points/s", "cores": cores, "kind": "port",
+                     "sample": f"one set_points+type-1 transform, same grid ({n}^3, sigma={sigma}, m={m}), "
+                               f"Np={Np_s} of {Np_full} points, {t:.1f} s wall; C/OpenMP blocked spreading (plain adds under a lock, "
+                               f"the reference's default) + scipy pocketfft, polynomial window (the reference's CPU default); threads = CPUs "
+                               f"available to the process (affinity capped by the cgroup quota: {CO.available_cpus()} of {os.cpu_count()} logical CPUs)",
+                     "seconds": t}, **note)
     except Exception as exc:  # the baseline is informative only
-        return {"value": None, "unit": "NU-points/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}
+        return dict({"value": None, "unit": "NU-points/s", "cores": 0, "kind": "port", "sample": f"failed: {exc!r}"}, **note)
 
 
 if __name__ == "__main__":
