@@ -131,6 +131,57 @@ hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Which spreading engine serves this point set (plans whose engine is the MFMA patches): the patches have no slices —
+// a wave owns its patch for a whole segment of cube layers — so a point set that concentrates in a few patches would
+// serialise on them (folded N(0, 1) coordinates, the reference's own benchmark distribution, put 15x the mean into the
+// central tasks).  One wave per patch task counts the points of its own bins; the last workgroup to finish compares
+// the heaviest task with an even share of the wave slots and writes the verdict: choice[2] = 1 (patches) and no
+// slots for the LDS-tile kernel, or choice[2] = 0 and the tile kernel runs as usual.  No host read-back.
+__global__ __launch_bounds__(256) void patch_choice_kernel(Geom g, PatchPlan pp, int pby, const uint32_t* __restrict__ offsets,
+                                                          unsigned long long np, unsigned long long slots_num,
+                                                          unsigned long long share_den, uint32_t* __restrict__ choice,
+                                                          uint32_t* __restrict__ slots_in_use) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (wave < pp.ntasks) {
+        const int px = wave % pp.npx, py = (wave / pp.npx) % pp.npy, seg = wave / (pp.npx * pp.npy);
+        const int bx0 = px * 4, by0 = py * pby;
+        const int ncx = min(4, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
+        const int z0 = seg * pp.segl, z1 = min(z0 + pp.segl, g.nb[2]);
+        uint32_t sum = 0;
+        for (int item = lane; item < ncy * (z1 - z0); item += kWave) {
+            const int by = by0 + item % ncy, bz = z0 + item / ncy;
+            const int64_t bin0 = ((int64_t)bz * g.nb[1] + by) * g.nb[0] + bx0;
+            sum += offsets[bin0 + ncx] - offsets[bin0];
+        }
+        for (int o = kWave / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, kWave);
+        if (lane == 0) atomicMax(&choice[0], sum);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t ticket = atomicAdd(&choice[1], 1u);
+        if (ticket == gridDim.x - 1) {
+            __threadfence();
+            const unsigned long long mx = atomicExch(&choice[0], 0u);
+            choice[1] = 0u;
+            // heaviest task <= (slots_num / share_den) even shares of the wave slots
+            const bool patches = mx * share_den <= np * slots_num || np == 0;
+            choice[2] = patches ? 1u : 0u;
+            if (patches) slots_in_use[0] = 0u;
+        }
+    }
+}
+
+hipError_t launch_patch_choice(const Geom& g, const PatchPlan& pp, int pby, const uint32_t* offsets, int64_t np, int wave_slots,
+                               uint32_t* choice, uint32_t* slots_in_use, hipStream_t stream) {
+    const int waves_per_block = 256 / kWave;
+    // patches while the heaviest task holds at most one even share: max_task <= np / wave_slots  (factor 1 / 1)
+    hipLaunchKernelGGL(patch_choice_kernel, dim3((unsigned)((pp.ntasks + waves_per_block - 1) / waves_per_block)), dim3(256), 0, stream,
+                       g, pp, pby, offsets, (unsigned long long)np, 1ull, (unsigned long long)wave_slots, choice, slots_in_use);
+    return hipGetLastError();
+}
+
 // Zero the interior of the spreading tiles that are processed by several slices (they accumulate with
 // atomics; tiles with one slice store every cell exactly once and need no zero fill).
 template <typename T>

@@ -93,14 +93,19 @@ struct PatchPlan {
     bool eligible;
     int npx, npy, nseg, segl, ntasks;   // patch columns, segments of cube layers along dimension 3, wave tasks
     int lds_bytes;                      // dynamic LDS per workgroup
+    int pby;                            // rows of cube columns per patch
 };
 PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other);
+// set_points: decides on the device which engine serves this point set (balance.hip); choice = uint32[4], zeroed once
+hipError_t launch_patch_choice(const Geom& g, const PatchPlan& pp, int pby, const uint32_t* offsets, int64_t np, int wave_slots,
+                               uint32_t* choice, uint32_t* slots_in_use, hipStream_t stream);
 hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other);
 // vsorted: C value vectors in sorted order (launch_gather_values), vstride_reals reals apart
+// enabled: device flag (null: always run); both kernels return at once when *enabled == 0
 hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
-                               hipStream_t stream);
+                               const uint32_t* enabled, hipStream_t stream);
 hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* sorted, int64_t np, const void* vin,
-                                const void* weights, void* vout, hipStream_t stream);
+                                const void* weights, void* vout, const uint32_t* enabled, hipStream_t stream);
 
 // ---- deconvolution (deconv.hip) ------------------------------------------------------------------
 struct DeconvArgs {

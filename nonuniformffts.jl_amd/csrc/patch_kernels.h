@@ -99,13 +99,15 @@ struct PatchArgs {
     PatchGeom pg;
     const T* vsorted[kMaxCompPerLaunch];   // values in sorted order (gather_values_kernel), NC reals per point
     unsigned long long* prof;              // NUFFT_PATCH_PROFILE builds: cycles per phase, summed over the waves
+    const uint32_t* enabled;               // device flag written by set_points (patch_choice_kernel); null: always run
 };
 
 // Values in sorted order: vs[p] = v[idx[p]] (* weight[idx[p]]: callbacks.nonuniform, src/spreading/gpu.jl:289)
 template <typename T, int NC, int REC_BYTES>
 __global__ __launch_bounds__(256) void gather_values_kernel(const unsigned char* __restrict__ recs, int idx_off, int64_t np,
                                                            const T* __restrict__ vin, const T* __restrict__ weights,
-                                                           T* __restrict__ vout) {
+                                                           T* __restrict__ vout, const uint32_t* __restrict__ enabled) {
+    if (enabled && *enabled == 0u) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += stride) {
         const int32_t idx = *reinterpret_cast<const int32_t*>(recs + p * REC_BYTES + idx_off);
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH_OCC) void spread_p
     const Geom& g = a.t.g;
     const PatchGeom& pg = a.pg;
 
+    if (a.enabled && *a.enabled == 0u) return;      // this point set goes to the LDS-tile kernel (patch_choice_kernel)
     // polynomial coefficients of the window: one copy per workgroup in LDS (re-read by every chunk evaluation)
     T* ctab = reinterpret_cast<T*>(smem);
     for (int i = threadIdx.x; i < 3 * P::NPOLY * L; i += kPatchWaves * kWave) ctab[i] = a.t.coefs[i];

@@ -329,7 +329,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         const PatchPlan pp = patch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
         p->patch.eligible = pp.eligible;
         p->patch.npx = pp.npx; p->patch.npy = pp.npy; p->patch.nseg = pp.nseg; p->patch.segl = pp.segl;
-        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes;
+        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes; p->patch.pby = pp.pby;
         if (req == NUFFT_SPREAD_MFMA_PATCHES && !pp.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = MFMA patches needs a 3-D grid of 4-cell bins with every oversampled "
                                                "axis a multiple of 4 and at least 2 (patch + stencil) bins long, and the default window evaluation");
@@ -511,7 +511,14 @@ static int build_device(nufft_plan* p) {
         NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp, other != 0));
     }
 
-    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false));
+    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
+        NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false));
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 4 * sizeof(uint32_t)))) return rc;
+        NUFFT_HIP(hipMemset(p->d_patch_choice, 0, 4 * sizeof(uint32_t)));
+        hipDeviceProp_t prop;
+        NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
+        p->wave_slots = prop.multiProcessorCount * 8;
+    }
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
         hipEvent_t a, b;
@@ -531,7 +538,7 @@ static void release(nufft_plan* p) {
         auto fr = [](void* q) { if (q) (void)hipFree(q); };
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
-        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted);
+        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -965,6 +972,15 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         q.scan_tmp_bytes = b.tmp_bytes;
         NUFFT_HIP(launch_balance(q, stream));
     }
+    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
+        // which engine serves this point set: decided on the device from the heaviest patch task (balance.hip)
+        PatchPlan pp{};
+        pp.eligible = true;
+        pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
+        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby;
+        const int slots = p->spread_method_req == NUFFT_SPREAD_MFMA_PATCHES ? 1 : p->wave_slots;    // explicit request: always the patches
+        NUFFT_HIP(launch_patch_choice(s.g, pp, p->patch.pby, p->d_offsets, np, slots, p->d_patch_choice, p->bal.d_slots, stream));
+    }
     p->Np = np;
     return NUFFT_OK;
 }
@@ -990,23 +1006,25 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
     StageTimer tm(p, NUFFT_STAGE_T1_SPREAD, stream);
     TileKernelArgs a = tile_args(p, false);
     a.values_in = values_in;
-    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
-        // values gathered into sorted order (per-point weights of the callback menu folded in), then the patches
-        const int64_t vstride = p->Np * (p->is_complex ? 2 : 1);
-        for (int c = 0; c < p->C; ++c)
-            NUFFT_HIP(launch_gather_values(p->dtype, p->is_complex, p->D, p->d_sorted, p->Np, values_in[c], p->cb_point_weights,
-                                           static_cast<char*>(p->d_vsorted) + (size_t)c * vstride * real_bytes(p), stream));
-        PatchPlan pp{};
-        pp.eligible = true;
-        pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
-        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes;
-        NUFFT_HIP(launch_spread_patch(a, pp, p->d_vsorted, vstride, stream));
-        return NUFFT_OK;
-    }
+    // LDS-tile engine.  On plans of the MFMA-patch engine set_points has decided on the device which of the two serves
+    // this point set (balance.hip): the other one finds no work (no slots / flag = 0) and returns at once.
     if (p->balance_enabled)    // tiles shared by several workgroups accumulate with atomics: zero them first
         NUFFT_HIP(launch_zero_split_tiles(p->dtype, a.g, p->D, p->is_complex, p->C, p->bal.d_nslices, p->d_us,
                                           p->grid_elems * (p->is_complex ? 2 : 1), stream));
     NUFFT_HIP(launch_spread(a, stream));
+    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
+        // values gathered into sorted order (per-point weights of the callback menu folded in), then the patches
+        const uint32_t* enabled = p->d_patch_choice + 2;
+        const int64_t vstride = p->Np * (p->is_complex ? 2 : 1);
+        for (int c = 0; c < p->C; ++c)
+            NUFFT_HIP(launch_gather_values(p->dtype, p->is_complex, p->D, p->d_sorted, p->Np, values_in[c], p->cb_point_weights,
+                                           static_cast<char*>(p->d_vsorted) + (size_t)c * vstride * real_bytes(p), enabled, stream));
+        PatchPlan pp{};
+        pp.eligible = true;
+        pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
+        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby;
+        NUFFT_HIP(launch_spread_patch(a, pp, p->d_vsorted, vstride, enabled, stream));
+    }
     return NUFFT_OK;
 }
 

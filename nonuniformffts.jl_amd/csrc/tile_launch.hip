@@ -175,6 +175,7 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
     pp.nseg = (g.nb[2] + pp.segl - 1) / pp.segl;
     pp.ntasks = cols * pp.nseg;
     pp.lds_bytes = lds;
+    pp.pby = pby;
     pp.eligible = true;
     return pp;
 }
@@ -188,7 +189,7 @@ hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other) {
 
 template <typename T>
 static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
-                                 hipStream_t stream) {
+                                 const uint32_t* enabled, hipStream_t stream) {
     int lds = 0, pby = 0;
     const void* fn = patch_kernel(a.dtype, a.is_complex, a.M, false, &lds, &pby);
     if (!fn) return hipErrorInvalidValue;
@@ -199,6 +200,7 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
         k.pg.npx = pp.npx; k.pg.npy = pp.npy; k.pg.nseg = pp.nseg; k.pg.segl = pp.segl; k.pg.ntasks = pp.ntasks;
         for (int c = 0; c < nc; ++c) k.vsorted[c] = static_cast<const T*>(vsorted) + (int64_t)(c0 + c) * vstride_reals;
         k.prof = nullptr;
+        k.enabled = enabled;
 #if defined(NUFFT_PATCH_PROFILE)
         static unsigned long long* prof_dev = nullptr;       // development builds: phase cycles of the last launch on stderr
         if (!prof_dev) { (void)hipMalloc(&prof_dev, 8 * sizeof(unsigned long long)); }
@@ -222,14 +224,15 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
 }
 
 hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
-                               hipStream_t stream) {
-    return a.dtype == NUFFT_F32 ? launch_patch_t<float>(a, pp, vsorted, vstride_reals, stream)
-                                : launch_patch_t<double>(a, pp, vsorted, vstride_reals, stream);
+                               const uint32_t* enabled, hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_patch_t<float>(a, pp, vsorted, vstride_reals, enabled, stream)
+                                : launch_patch_t<double>(a, pp, vsorted, vstride_reals, enabled, stream);
 }
 
 // values of one component in sorted order (times the per-point weights of the callback menu)
 template <typename T, int NC>
-static hipError_t gather_t(int D, const void* sorted, int64_t np, const void* vin, const void* weights, void* vout, hipStream_t stream) {
+static hipError_t gather_t(int D, const void* sorted, int64_t np, const void* vin, const void* weights, void* vout,
+                           const uint32_t* enabled, hipStream_t stream) {
     if (np <= 0) return hipSuccess;
     const int rec_bytes = (int)sizeof(T) * D + 4 > 16 ? 32 : ((int)sizeof(T) * D + 4 > 8 ? 16 : 8);
     const int idx_off = D * (int)sizeof(T);
@@ -240,19 +243,19 @@ static hipError_t gather_t(int D, const void* sorted, int64_t np, const void* vi
     const T* w = static_cast<const T*>(weights);
     T* vo = static_cast<T*>(vout);
     switch (rec_bytes) {
-        case 8: hipLaunchKernelGGL((gather_values_kernel<T, NC, 8>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo); break;
-        case 16: hipLaunchKernelGGL((gather_values_kernel<T, NC, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo); break;
-        default: hipLaunchKernelGGL((gather_values_kernel<T, NC, 32>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo); break;
+        case 8: hipLaunchKernelGGL((gather_values_kernel<T, NC, 8>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo, enabled); break;
+        case 16: hipLaunchKernelGGL((gather_values_kernel<T, NC, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo, enabled); break;
+        default: hipLaunchKernelGGL((gather_values_kernel<T, NC, 32>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, vi, w, vo, enabled); break;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* sorted, int64_t np, const void* vin,
-                                const void* weights, void* vout, hipStream_t stream) {
-    if (dtype == NUFFT_F32) return is_complex ? gather_t<float, 2>(D, sorted, np, vin, weights, vout, stream)
-                                              : gather_t<float, 1>(D, sorted, np, vin, weights, vout, stream);
-    return is_complex ? gather_t<double, 2>(D, sorted, np, vin, weights, vout, stream)
-                      : gather_t<double, 1>(D, sorted, np, vin, weights, vout, stream);
+                                const void* weights, void* vout, const uint32_t* enabled, hipStream_t stream) {
+    if (dtype == NUFFT_F32) return is_complex ? gather_t<float, 2>(D, sorted, np, vin, weights, vout, enabled, stream)
+                                              : gather_t<float, 1>(D, sorted, np, vin, weights, vout, enabled, stream);
+    return is_complex ? gather_t<double, 2>(D, sorted, np, vin, weights, vout, enabled, stream)
+                      : gather_t<double, 1>(D, sorted, np, vin, weights, vout, enabled, stream);
 }
 
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream) {

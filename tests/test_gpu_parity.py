@@ -501,3 +501,31 @@ def test_spreading_engines_agree_on_dense_point_sets(Z, n, M, Np, C, dist):
     for c in range(C):
         assert bool(torch.isfinite(torch.view_as_real(outs[1][c])).all())
         assert float((outs[0][c] - outs[1][c]).norm() / outs[0][c].norm()) < tol
+
+
+@pytest.mark.parametrize("dist", ["uniform", "cluster"])
+def test_automatic_engine_choice_per_point_set(dist):
+    """A plan whose engine is the MFMA patches (automatic for complex data) decides at set_points, on the device, which
+    engine spreads THIS point set: the patches for well-spread points, the LDS tiles (which can share a heavy tile
+    between workgroups) when a few patch tasks would hold most of the points.  Either way exactly one of the two
+    kernels does the work and the result equals the explicitly chosen LDS-tile engine; alternating point sets on one
+    plan must switch back and forth."""
+    nufft = _nufft()
+    n, Np = 64, 400_000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    sets = {
+        "uniform": tuple(torch.rand(Np, dtype=torch.float64, device="cuda", generator=g) * (2 * np.pi) for _ in range(3)),
+        "cluster": tuple(torch.randn(Np, dtype=torch.float64, device="cuda", generator=g) * 0.05 + np.pi for _ in range(3)),
+    }
+    v = torch.randn(Np, dtype=torch.complex128, device="cuda", generator=g)
+    auto = nufft.PlanNUFFT(torch.complex128, (n, n, n), backend=nufft.ROCBackend(0))
+    ref = nufft.PlanNUFFT(torch.complex128, (n, n, n), spread_method="lds_tiles", backend=nufft.ROCBackend(0))
+    assert auto.info().spread_method == 2 and ref.info().spread_method == 1
+    for name in (dist, "uniform" if dist == "cluster" else "cluster", dist):
+        nufft.set_points(auto, sets[name])
+        nufft.set_points(ref, sets[name])
+        ua = torch.empty(auto.shape, dtype=torch.complex128, device="cuda")
+        ur = torch.empty_like(ua)
+        nufft.exec_type1(ua, auto, v)
+        nufft.exec_type1(ur, ref, v)
+        assert float((ua - ur).norm() / ur.norm()) < 1e-12, name
