@@ -92,13 +92,14 @@ def algorithmic_bytes(Np, Nover, Nout, is_complex, real_bytes, C):
     }
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, config):
     """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/*_traffic.json,
     written by scripts/summarize_profile.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
     passes of this same command, with the gfx950 FETCH_SIZE correction).  Counters cannot be collected
     inside the timed run; None if no summary is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))      # round<N>_<letter>_...: newest last
+    # round<N>_<letter>_bench_<config>_traffic.json: newest last; only summaries of the same configuration
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if f"_{config}_" in os.path.basename(f))
     for f in reversed(files):
         try:
             ks = json.load(open(f))["kernels"]
@@ -329,17 +330,17 @@ def main():
         binding = ("LDS float atomics (ds_add_f64, 8.5 cycles per wave instruction per CU) and the scalar/vector issue of the "
                    "clipped stencil loop, not HBM: see DESIGN.md section 4.2")
     spread_s = st1["spread"] * 1e-3
-    traffic_b, traffic_src = pmc_traffic(kname)
+    traffic_b, traffic_src = pmc_traffic(kname, a.config)
     probe = hbm_probe(dev) if full else None
     peak_m = probe["peak_measured_GBs"] if probe else None
     achieved = ab["spread_kernel"] / spread_s / 1e9
     roofline = {
         "bound": "hbm",
-        "kernel": kname + ", ...> (the zero + spread stage: one launch per component, C = %d)" % Cn,
+        "kernel": kname + ", ...> (the zero + spread stage: one launch, gridDim.y = C = %d components)" % Cn,
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "peak_measured": peak_m, "frac_of_measured_peak": (achieved / peak_m) if peak_m else None,
-        "traffic": (traffic_b * Cn / 1e9) if traffic_b is not None else None,
-        "traffic_unit": "GB per stage (PMC FETCH_SIZE x2 + WRITE_SIZE per launch x C launches)", "traffic_source": traffic_src,
+        "traffic": (traffic_b / 1e9) if traffic_b is not None else None,
+        "traffic_unit": "GB per launch = per stage (PMC FETCH_SIZE x2 + WRITE_SIZE; one launch covers the C components)", "traffic_source": traffic_src,
         "binding_resource": binding,
         "algorithmic_bytes_per_stage": ab["spread_kernel"],
         "algorithmic_bytes_note": "SURVEY 8(d): zero + spread = 3G + P per component (what the reference's algorithm moves); the "
