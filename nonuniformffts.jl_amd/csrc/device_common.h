@@ -282,6 +282,19 @@ constexpr __host__ __device__ FixedTileDims fixed_spread_tile(int real_bytes, in
 
 // Direct: reference src/Kernels/kaiser_bessel_backwards.jl:158-175.
 // j is 0-based (reference j = 1..2M), X ∈ [0, 1].
+//
+// Double precision uses its own square root, exponential and division (each good to an ulp or two) instead of the
+// library's: the correctly rounded / special-case-proof versions cost 20 + 30 + 12 instructions per window value,
+// these 9 + 19 + 6 — Direct() is the reference's ROC default, so this is the headline path.
+
+// p <- p * h + c as ONE v_fma_f64 with the coefficient in a scalar register pair (the compiler otherwise keeps the
+// coefficients in vector registers and emits v_mov_b64 + v_fmac_f64 per Horner step)
+__device__ __forceinline__ double fma_sc(double p, double h, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(h), "s"(c));
+    return r;
+}
+
 // exp(x) for 0 <= x < 700 without the library's special-case handling: x = k ln2 + r, |r| <= ln2 / 2,
 // exp(r) = (exp(r / 2))^2 with a degree-11 Taylor polynomial of exp(r / 2) (|r / 2| <= 0.174: truncation
 // 2e-18), scaled by 2^k.  Relative error ~2e-16.  Float: the library exp.
@@ -291,20 +304,44 @@ __device__ __forceinline__ double exp_pos(double x) {
     r = fma(k, -1.90821492927058770002e-10, r);                     // ln2 low part
     const double h = 0.5 * r;
     double p = 1.0 / 39916800.0;
-    p = fma(p, h, 1.0 / 3628800.0);
-    p = fma(p, h, 1.0 / 362880.0);
-    p = fma(p, h, 1.0 / 40320.0);
-    p = fma(p, h, 1.0 / 5040.0);
-    p = fma(p, h, 1.0 / 720.0);
-    p = fma(p, h, 1.0 / 120.0);
-    p = fma(p, h, 1.0 / 24.0);
-    p = fma(p, h, 1.0 / 6.0);
+    p = fma_sc(p, h, 1.0 / 3628800.0);
+    p = fma_sc(p, h, 1.0 / 362880.0);
+    p = fma_sc(p, h, 1.0 / 40320.0);
+    p = fma_sc(p, h, 1.0 / 5040.0);
+    p = fma_sc(p, h, 1.0 / 720.0);
+    p = fma_sc(p, h, 1.0 / 120.0);
+    p = fma_sc(p, h, 1.0 / 24.0);
+    p = fma_sc(p, h, 1.0 / 6.0);
     p = fma(p, h, 0.5);
     p = fma(p, h, 1.0);
     p = fma(p, h, 1.0);
     return ldexp(p * p, (int)k);
 }
 __device__ __forceinline__ float exp_pos(float x) { return exp(x); }
+
+// sqrt(z) for 0 <= z <= 1: v_rsq_f64 (26 bits) + two coupled Newton steps (Goldschmidt); z = 0 is kept away from the
+// infinite reciprocal root by a floor far below anything the window needs (sqrt(1e-280) = 1e-140)
+__device__ __forceinline__ double sqrt_unit(double z) {
+    z = fmax(z, 1e-280);
+    const double r = __builtin_amdgcn_rsq(z);
+    double g = z * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-g, g, z);
+    return fma(e, h, g);
+}
+__device__ __forceinline__ float sqrt_unit(float z) { return sqrt(z > 0.f ? z : 0.f); }
+
+// n / d for normal, positive d: v_rcp_f64 + two Newton steps on the reciprocal + one correction of the quotient
+__device__ __forceinline__ double div_pos(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ float div_pos(float n, float d) { return n / d; }
 
 // sinh(x) / x for x >= 0 without the library sinh (ocml's double sinh costs ~2x the whole rest of the
 // evaluation): one exp and one division above 0.5, the even Taylor series below (no cancellation).
@@ -326,14 +363,14 @@ __device__ __forceinline__ T sinh_over_x(T x) {
         // Float32: e * e overflows for x > 44 (beta = 46.9 at M = 10, sigma = 2)
         return T(0.5) * (e - T(1) / e) / x;
     }
-    return T(0.5) * fma(e, e, T(-1)) / (e * x);               // (e - 1/e) / (2x) with a single division
+    return div_pos(T(0.5) * fma(e, e, T(-1)), e * x);         // (e - 1/e) / (2x) with a single division
 }
 
 template <typename T, int M>
 __device__ __forceinline__ T bkb_direct(T X, int j, T beta, T beta_over_pi) {
     const T y = (T(M - 1 - j) + X) / T(M);
     const T z = T(1) - y * y;
-    const T s = sqrt(z > T(0) ? z : T(0));
+    const T s = sqrt_unit(z > T(0) ? z : T(0));
     return sinh_over_x(beta * s) * beta_over_pi;
 }
 
