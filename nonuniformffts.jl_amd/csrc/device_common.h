@@ -317,7 +317,13 @@ __device__ __forceinline__ double exp_pos(double x) {
     p = fma(p, h, 1.0);
     return ldexp(p * p, (int)k);
 }
-__device__ __forceinline__ float exp_pos(float x) { return exp(x); }
+// Float32: the same range reduction, then the hardware exp2 on the small remainder (|r| <= 0.35: one ulp)
+__device__ __forceinline__ float exp_pos(float x) {
+    const float k = rintf(x * 1.44269504088896340736f);
+    float r = fmaf(k, -6.93145751953125e-1f, x);                    // ln2 high part (exact product for |k| < 2^12)
+    r = fmaf(k, -1.42860682030941723212e-6f, r);                    // ln2 low part
+    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896340736f), (int)k);
+}
 
 // sqrt(z) for 0 <= z <= 1: v_rsq_f64 (26 bits) + two coupled Newton steps (Goldschmidt); z = 0 is kept away from the
 // infinite reciprocal root by a floor far below anything the window needs (sqrt(1e-280) = 1e-140)
@@ -331,7 +337,7 @@ __device__ __forceinline__ double sqrt_unit(double z) {
     e = fma(-g, g, z);
     return fma(e, h, g);
 }
-__device__ __forceinline__ float sqrt_unit(float z) { return sqrt(z > 0.f ? z : 0.f); }
+__device__ __forceinline__ float sqrt_unit(float z) { return __builtin_amdgcn_sqrtf(z > 0.f ? z : 0.f); }   // v_sqrt_f32: one ulp
 
 // n / d for normal, positive d: v_rcp_f64 + two Newton steps on the reciprocal + one correction of the quotient
 __device__ __forceinline__ double div_pos(double n, double d) {
@@ -341,7 +347,7 @@ __device__ __forceinline__ double div_pos(double n, double d) {
     const double q = n * r;
     return fma(fma(-d, q, n), r, q);
 }
-__device__ __forceinline__ float div_pos(float n, float d) { return n / d; }
+__device__ __forceinline__ float div_pos(float n, float d) { return n * __builtin_amdgcn_rcpf(d); }   // v_rcp_f32: one ulp
 
 // sinh(x) / x for x >= 0 without the library sinh (ocml's double sinh costs ~2x the whole rest of the
 // evaluation): one exp and one division above 0.5, the even Taylor series below (no cancellation).
@@ -361,7 +367,7 @@ __device__ __forceinline__ T sinh_over_x(T x) {
     const T e = exp_pos(x);
     if constexpr (sizeof(T) == 4) {
         // Float32: e * e overflows for x > 44 (beta = 46.9 at M = 10, sigma = 2)
-        return T(0.5) * (e - T(1) / e) / x;
+        return div_pos(T(0.5) * (e - div_pos(T(1), e)), x);
     }
     return div_pos(T(0.5) * fma(e, e, T(-1)), e * x);         // (e - 1/e) / (2x) with a single division
 }
