@@ -298,6 +298,10 @@ ENGINE_CASES = [
     (np.float32, (40, 40, 40), 7, 2.0, O.FAST_APPROXIMATION, 1),
     (np.float64, (40, 40, 40), 9, 2.0, O.DIRECT, 1),
     (np.complex64, (40, 48, 40), 6, 2.0, O.DIRECT, 3),
+    # 72 x 100 x 80: 18 x 25 x 20 bins — the last patch column and the last patch row are partial
+    (np.float64, (36, 50, 40), 4, 2.0, O.DIRECT, 1),
+    (np.complex128, (36, 50, 40), 4, 2.0, O.FAST_APPROXIMATION, 1),
+    (np.float32, (36, 50, 40), 5, 2.0, O.FAST_APPROXIMATION, 2),
 ]
 
 
