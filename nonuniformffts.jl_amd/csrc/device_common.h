@@ -181,13 +181,17 @@ struct LdsLayout {
 // interpolation tile one per wave) the runs are split so that the 16 waves of a workgroup share the points.
 constexpr int kItemTarget = 64;
 
+// Spreading strips of real 3-D plans carry one zero in front of and behind the 2M window values of every
+// dimension (the cube accumulation of spread_tile_kernel clamps its window index into them).
+constexpr __host__ __device__ int spread_strip_pad(int D, int ncomp) { return (D == 3 && ncomp == 1) ? 1 : 0; }
+
 constexpr __host__ __device__ LdsLayout lds_layout(int tile_elems, int tile_elem_bytes, int real_bytes, int D, int M,
-                                                   int ncomp, int nwaves, int max_items) {
+                                                   int ncomp, int nwaves, int max_items, int strip_pad = 0) {
     LdsLayout l{};
     l.tile_bytes = round_up(tile_elems * tile_elem_bytes, 16);
     l.items_bytes = round_up(max_items * 8 + 16, 16);
     const int ppw = kWave / lanes_per_point(ncomp, M);           // points a wave works on at once
-    l.strip_bytes_per_wave = round_up(ppw * D * 2 * M * real_bytes, 16);
+    l.strip_bytes_per_wave = round_up(ppw * D * (2 * M + 2 * strip_pad) * real_bytes, 16);
     l.total = l.tile_bytes + l.items_bytes + nwaves * l.strip_bytes_per_wave;
     return l;
 }
@@ -227,11 +231,23 @@ constexpr __host__ __device__ int padded_row_stride(int inner_elems, int stencil
     return s;
 }
 
-struct FixedTileDims { int n[3]; int row_stride; };
+struct FixedTileDims { int n[3]; int row_stride; int plane_stride; };
+
+// Plane stride (in Float64 reals) of the spreading tile.  Real 3-D tiles are padded so that the stride is 2 (mod 32):
+// the cube accumulation of spread_tile_kernel adds 4 x 4 x 4 cubes (lane = 16 x + 4 y + z) with one ds_add_f64, and the
+// LDS serves 16 consecutive lanes at a time — one x, all (y, z): their doubles sit at z * plane + y * row, which with row
+// strides of 8 or 24 (mod 32) and a plane stride of 2 (mod 32) are 16 different bank pairs.  With the natural stride
+// rows * row_stride (0 mod 32 at C2) the four z planes collide (measured: kernel 10.0 ms; stride 4 mod 32: 6.2 ms).
+constexpr __host__ __device__ int spread_plane_stride(int row_stride, int rows, int D, int ncomp) {
+    int ps = row_stride * rows;
+    if (D == 3 && ncomp == 1)
+        while (ps % 32 != 2) ++ps;
+    return ps;
+}
 constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, int ncomp, int D, int M) {
     const int L = 2 * M, halo = L - 1, b = 4, nwaves = 16;
     const int cap = D == 1 ? 8192 : 96;
-    FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0};
+    FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0, 0};
     double best_cost = 1e300;
     for (int n3 = (D >= 3 ? b : 1); n3 <= (D >= 3 ? cap : 1); n3 += b)
         for (int n2 = (D >= 2 ? b : 1); n2 <= (D >= 2 ? cap : 1); n2 += b)
@@ -246,7 +262,10 @@ constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, in
                 if (D >= 2) cost *= (double)(n2 + halo) / n2;
                 if (D >= 3) cost *= (double)(n3 + halo) / n3;
                 cost -= 1e-6 * n1;
-                if (cost < best_cost) { best_cost = cost; best.n[0] = n1; best.n[1] = n2; best.n[2] = n3; best.row_stride = rs; }
+                if (cost < best_cost) {
+                    best_cost = cost; best.n[0] = n1; best.n[1] = n2; best.n[2] = n3; best.row_stride = rs;
+                    best.plane_stride = rs * (D >= 2 ? n2 + halo : 1);
+                }
             }
     return best;
 }
@@ -256,22 +275,23 @@ constexpr __host__ __device__ FixedTileDims fixed_interp_tile(int elem_bytes, in
 constexpr __host__ __device__ FixedTileDims fixed_spread_tile(int real_bytes, int ncomp, int D, int M) {
     const int L = 2 * M, halo = L - 1, b = 4, nwaves = 16;
     const int cap = D == 1 ? 8192 : 96;
-    FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0};
+    FixedTileDims best{{0, D >= 2 ? 0 : 1, D >= 3 ? 0 : 1}, 0, 0};
     double best_cost = 1e300;
     for (int n3 = (D >= 3 ? b : 1); n3 <= (D >= 3 ? cap : 1); n3 += b)
         for (int n2 = (D >= 2 ? b : 1); n2 <= (D >= 2 ? cap : 1); n2 += b)
             for (int n1 = b; n1 <= cap; n1 += b) {
                 const int rs = D >= 2 ? padded_row_stride(ncomp * n1, ncomp * L, 8) : ncomp * n1;
-                const long elems = (long)rs * (D >= 2 ? n2 : 1) * (D >= 3 ? n3 : 1);
+                const int ps = spread_plane_stride(rs, D >= 2 ? n2 : 1, D, ncomp);
+                const long elems = (long)ps * (D >= 3 ? n3 : 1);
                 const int nn[3] = {n1, n2, n3};
                 const long items = tile_items_bound(true, D, M, b, nn, nullptr);
                 if (elems * 8 > 163840 || items > kMaxTileItems ||
-                    lds_layout((int)elems, 8, real_bytes, D, M, ncomp, nwaves, (int)items).total > 163840 - 256) break;
+                    lds_layout((int)elems, 8, real_bytes, D, M, ncomp, nwaves, (int)items, spread_strip_pad(D, ncomp)).total > 163840 - 256) break;
                 double cost = (double)(n1 + halo) / n1;
                 if (D >= 2) cost *= (double)(n2 + halo) / n2;
                 if (D >= 3) cost *= (double)(n3 + halo) / n3;
                 cost -= 1e-6 * n1;
-                if (cost < best_cost) { best_cost = cost; best.n[0] = n1; best.n[1] = n2; best.n[2] = n3; best.row_stride = rs; }
+                if (cost < best_cost) { best_cost = cost; best.n[0] = n1; best.n[1] = n2; best.n[2] = n3; best.row_stride = rs; best.plane_stride = ps; }
             }
     return best;
 }

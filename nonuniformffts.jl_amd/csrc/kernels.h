@@ -75,12 +75,14 @@ struct TileKernelArgs {
     const uint32_t* desc_total;    // number of slots in use
     int xcd_chunk;
     int fixed_tile;            // the tile (g.ip / g.sp) equals the compile-time one (kernel variant with constant strides)
+    int cubes;                 // spreading with the compile-time tile: accumulate cube by cube with the FP64 matrix instruction
 };
 // Compile-time interpolation tile of an instantiation: n[0..2] cells (n[0] == 0: none), n[3] = LDS row
 // stride in reals; see fixed_interp_tile().
 void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n);
 // the same for the spreading tile (fixed_spread_tile())
 void spread_fixed_dims(int dtype, int is_complex, int D, int M, int* n);
+bool spread_cubes_available(int dtype, int is_complex, int D, int M);
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
 hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);
 // Sets the dynamic-LDS attribute of every instantiation that may be launched for this configuration.

@@ -47,6 +47,7 @@ struct TileShapeHost {
     int n[kMaxDim] = {1, 1, 1};        // interior cells
     int nt[kMaxDim] = {1, 1, 1};       // tiles per dimension
     int row_stride = 0;                // LDS row stride in reals
+    int plane_stride = 0;              // LDS plane stride in reals (>= row_stride * rows[0]: spreading tiles pad it for the banks)
     int rows[2] = {1, 1};              // LDS rows per plane, planes
     int64_t elems = 0;                 // LDS reals
     int64_t ntiles = 1;
@@ -108,6 +109,7 @@ struct nufft_plan {
     nufft::TileGeom tile;
     bool interp_fixed = false;         // tile.ip is the compile-time tile of the kernel instantiation
     bool spread_fixed = false;         // tile.sp likewise
+    bool spread_cubes = false;         // LDS-tile spreading accumulates cube by cube (v_mfma_f64_4x4x4 + one ds_add_f64 per cube)
     int spread_method = NUFFT_SPREAD_LDS_TILES;   // what nufft_spread launches (NUFFT_SPREAD_*)
     int spread_method_req = NUFFT_SPREAD_AUTO;    // what the caller asked for
     struct Patch {                                // decomposition of the MFMA-patch spreading (patch_kernels.h)

@@ -52,7 +52,7 @@ static TileShape make_shape(const nufft::TileShapeHost& h) {
         t.nt[d] = h.nt[d];
     }
     t.row_stride = h.row_stride;
-    t.plane_stride = h.row_stride * h.rows[0];
+    t.plane_stride = h.plane_stride;
     t.elems = (int)h.elems;
     t.ntiles = (int)h.ntiles;
     t.max_items = h.max_items;
@@ -282,7 +282,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         else fixed_ip[0] = 0;
     }
     // the same for the spreading tile (fixed_spread_tile): every edge must leave room for the clipped halo
-    int fixed_sp[4] = {0, 0, 0, 0};
+    int fixed_sp[5] = {0, 0, 0, 0, 0};
     if (forced_sp[0] <= 0 && bin_log2 == 2 && p->spread_threads == 1024 && budget == kLdsLimit - 256 &&
         env_int("NUFFT_SPREAD_FIXED", 1)) {
         spread_fixed_dims(p->dtype, p->is_complex, p->D, p->M, fixed_sp);
@@ -314,9 +314,16 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     p->interp_fixed = fixed_ip[0] > 0;
     for (int d = 0; d < p->D; ++d) p->interp_fixed = p->interp_fixed && p->tile.ip.n[d] == fixed_ip[d];
     p->interp_fixed = p->interp_fixed && p->tile.ip.row_stride == fixed_ip[3];
-    p->spread_fixed = fixed_sp[0] > 0 && p->tile.sp.row_stride == fixed_sp[3];
+    p->spread_fixed = fixed_sp[0] > 0 && p->tile.sp.row_stride == fixed_sp[3] && p->tile.sp.plane_stride == fixed_sp[4];
     for (int d = 0; d < p->D; ++d) p->spread_fixed = p->spread_fixed && p->tile.sp.n[d] == fixed_sp[d] && p->tile.sp.nt[d] > 1;
-    p->lds_spread = lds_layout((int)p->tile.sp.elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64, p->tile.sp.max_items).total;
+    // cube accumulation: the tile's cubes must be the grid's cubes (oversampled sizes that are multiples of 4)
+    // (opt-in: measured slower than the face mapping at C2, 3.94 against 3.09 ms — the LDS pipe is saturated either way,
+    // DESIGN.md section 4.4)
+    p->spread_cubes = p->spread_fixed && env_int("NUFFT_SPREAD_CUBES", 0) != 0 &&
+                      spread_cubes_available(p->dtype, p->is_complex, p->D, p->M);
+    for (int d = 0; d < p->D; ++d) p->spread_cubes = p->spread_cubes && p->Nover[d] % 4 == 0;
+    p->lds_spread = lds_layout((int)p->tile.sp.elems, 8, rb, p->D, p->M, ncomp, p->spread_threads / 64, p->tile.sp.max_items,
+                               spread_strip_pad(p->D, ncomp)).total;
     p->lds_interp = lds_layout((int)p->tile.ip.elems, rb, rb, p->D, p->M, ncomp, p->interp_threads / 64, p->tile.ip.max_items).total;
     if (p->lds_spread > kLdsLimit || p->lds_interp > kLdsLimit)
         return fail(NUFFT_ERR_LDS_TOO_SMALL, "LDS is too small for the chosen problem: work-item table does not fit");
@@ -596,6 +603,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.weights = p->cb_point_weights;
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
+    a.cubes = !interp && p->spread_cubes && !needs_other_eval(p->kernel, p->evalmode) && !p->cb_point_weights;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
     const nufft_plan::Balance& b = p->bal;
     const int nt = (int)(interp ? p->tile.ip.ntiles : p->tile.sp.ntiles);

@@ -243,7 +243,8 @@ static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, int real_bytes
     t.row_stride = (!padded && D >= 2) ? lds_row_stride(ncomp * P[0], ncomp * 2 * M, 8) : ncomp * P[0];
     t.rows[0] = P[1];
     t.rows[1] = P[2];
-    t.elems = (int64_t)t.row_stride * P[1] * P[2];
+    t.plane_stride = padded ? t.row_stride * P[1] : spread_plane_stride(t.row_stride, P[1], D, ncomp);
+    t.elems = (int64_t)t.plane_stride * P[2];
     // upper bound of the contiguous runs of sorted points a tile works through (the kernels' own arithmetic)
     const int b = 1 << bin_log2;
     int nbv[3] = {1, 1, 1};
@@ -260,7 +261,8 @@ static int64_t candidate_lds(bool spreading, int D, int M, int ncomp, int real_b
     const int nn[3] = {n[0], n[1], n[2]};
     const long items = tile_items_bound(spreading, D, M, b, nn, nbv);
     if (items > kMaxTileItems || elems > (int64_t)1 << 24) return -1;
-    return lds_layout((int)elems, spreading ? 8 : real_bytes, real_bytes, D, M, ncomp, nwaves, (int)items).total;
+    return lds_layout((int)elems, spreading ? 8 : real_bytes, real_bytes, D, M, ncomp, nwaves, (int)items,
+                      spreading ? spread_strip_pad(D, ncomp) : 0).total;
 }
 
 bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover, int lds_budget_bytes,
@@ -296,10 +298,10 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
                 }
                 bn[d] = n;
             }
-            if (!fits((int64_t)(D >= 2 ? lds_row_stride(ncomp * bn[0], ncomp * 2 * M, 8) : ncomp * bn[0]) * bn[1] * bn[2], bn)) return false;
+            if (!fits((int64_t)spread_plane_stride(D >= 2 ? lds_row_stride(ncomp * bn[0], ncomp * 2 * M, 8) : ncomp * bn[0], bn[1], D, ncomp) * bn[2], bn)) return false;
         } else {
             for (int n3 : cand[2]) for (int n2 : cand[1]) for (int n1 : cand[0]) {
-                const int64_t elems = (int64_t)(D >= 2 ? lds_row_stride(ncomp * n1, ncomp * 2 * M, 8) : ncomp * n1) * n2 * n3;
+                const int64_t elems = (int64_t)spread_plane_stride(D >= 2 ? lds_row_stride(ncomp * n1, ncomp * 2 * M, 8) : ncomp * n1, n2, D, ncomp) * n3;
                 const int n[3] = {n1, n2, n3};
                 if (!fits(elems, n)) continue;
                 double cost = 1.0;

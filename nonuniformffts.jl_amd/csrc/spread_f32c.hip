@@ -4,4 +4,5 @@
 #define NUFFT_KERNEL spread_tile_kernel
 #define NUFFT_GETTER spread_kernel_f32c
 #define NUFFT_SPREAD_FIXED_GETTER spread_fixed_f32c
+#define NUFFT_SPREAD_CUBES_GETTER spread_cubes_f32c
 #include "tile_inst.h"

@@ -30,6 +30,24 @@ static TileKernelPtr inst_fixed() {
     if constexpr (ok) return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, M, false, false, true>;
     else return nullptr;
 }
+// ... and its cube-accumulation variant (real data, 3-D, M <= 4: stencils of three cubes per dimension)
+template <int D, int M>
+static TileKernelPtr inst_cubes() {
+    constexpr FixedTileDims fd = fixed_spread_tile((int)sizeof(NUFFT_T), NUFFT_CPLX ? 2 : 1, D, M);
+    constexpr bool ok = !NUFFT_CPLX && D == 3 && M == 4 && fd.n[0] > 0 && fd.n[0] % 4 == 0 && fd.n[1] % 4 == 0 && fd.n[2] % 4 == 0 &&
+                        (kWave / lanes_per_point(1, M)) % 4 == 0 &&
+                        (8 * fd.plane_stride + 8 * fd.row_stride + fd.n[0]) * 8 < 65536;
+    if constexpr (ok) return NUFFT_KERNEL<NUFFT_T, NUFFT_CPLX, D, M, false, false, true, true>;
+    else return nullptr;
+}
+template <int D>
+static TileKernelPtr pick_m_cubes(int M) {
+    switch (M) {
+        case 2: return inst_cubes<D, 2>();  case 3: return inst_cubes<D, 3>();  case 4: return inst_cubes<D, 4>();
+        default: return nullptr;
+    }
+}
+
 template <int D>
 static TileKernelPtr pick_m_fixed(int M) {
     switch (M) {
@@ -78,12 +96,20 @@ const void* NUFFT_SPREAD_FIXED_GETTER(int D, int M, int* n) {
     const FixedTileDims fd = fixed_spread_tile((int)sizeof(NUFFT_T), NUFFT_CPLX ? 2 : 1, D, M);
     for (int d = 0; d < 3; ++d) n[d] = fd.n[d];
     n[3] = fd.row_stride;
+    n[4] = fd.plane_stride;
     switch (D) {
         case 1: return reinterpret_cast<const void*>(pick_m_fixed<1>(M));
         case 2: return reinterpret_cast<const void*>(pick_m_fixed<2>(M));
         case 3: return reinterpret_cast<const void*>(pick_m_fixed<3>(M));
         default: return nullptr;
     }
+}
+#endif
+
+#if defined(NUFFT_SPREAD_CUBES_GETTER)
+// cube-accumulation variant of the compile-time-tile spreading kernel (or null)
+const void* NUFFT_SPREAD_CUBES_GETTER(int D, int M) {
+    return D == 3 ? reinterpret_cast<const void*>(pick_m_cubes<3>(M)) : nullptr;
 }
 #endif
 

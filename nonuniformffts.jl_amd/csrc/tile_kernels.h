@@ -173,12 +173,17 @@ struct WindowEval {
     }
 
     // X[d]: cell fraction of this lane's point; strip: this group's NV slots in LDS.
+    // PAD: every dimension's row is [PAD zeros | 2M values | PAD zeros] (the zeros are written once by the caller)
+    template <int PAD = 0>
     __device__ __forceinline__ void eval_to_strip(const TileArgs<T>& a, const T (&X)[3], T* strip, int q) const {
         T v[NSLOT];
         eval_regs(a, X, v);
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s)
-            if (has[s]) strip[q + s * GS] = v[s];
+            if (has[s]) {
+                if constexpr (PAD == 0) strip[q + s * GS] = v[s];
+                else strip[dsel[s] * (L + 2 * PAD) + PAD + jsel[s]] = v[s];
+            }
     }
 
     // the same values left in registers: v[s] is window value k = q + s * GS of the lane's point
@@ -383,6 +388,98 @@ __device__ __forceinline__ void tile_coords(int tile_id, const TileShape& ts, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cube accumulation of one chunk of PPW points (real data, D = 3, stencils of three cubes per dimension)
+// ---------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_cubes(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_cubes<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ double bperm_t(double x, int src_lane) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double bperm_t(float x, int src_lane) {
+    return (double)__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double lds_ld_f64(const double* p) { return *p; }
+__device__ __forceinline__ double lds_ld_f64(const float* p) { return (double)*p; }
+
+// The chunk's points sit in the lane groups g = 0 .. PPW-1 (G lanes each; every lane of a group holds the group's
+// stencil start s[d] in tile coordinates and the value), their windows in the wave's strip (rows of 2M + 2 with a zero
+// at both ends).  Four points at a time (k = lane >> 4) against the cubes of the tile they can reach: the bins of the
+// chunk's points share dimensions 2 and 3 (a chunk never leaves its run of the sorted array) and ascend along
+// dimension 1, so the cube range is three cubes in y and z and [first bin - 1, last bin + 1] in x.  Lane roles of the
+// matrix instruction: operands (k, b, i / j), result (x = lane >> 4, y = (lane >> 2) & 3, z = lane & 3).
+template <typename T, int M, int G, int PPW, int N1, int N2, int N3, int RS, int PS>
+__device__ __forceinline__ void spread_cubes(double* tile, const T* strip_wave, const int (&s)[3], T value, unsigned long long okmask,
+                                             const int (&neff)[3], int lane) {
+    constexpr int L = 2 * M, SROW = L + 2;
+    constexpr int NCX = N1 / 4;
+    static_assert(N1 % 4 == 0 && N2 % 4 == 0 && N3 % 4 == 0 && PPW % 4 == 0, "cubes need 4-aligned tiles and K-batches of four points");
+    const int mk = lane >> 4, mb = (lane >> 2) & 3, mi = lane & 3;
+    // result roles of the matrix instruction: z = mi, y = mb, x = mk
+#pragma unroll
+    for (int bt = 0; bt < PPW / 4; ++bt) {
+        const unsigned okb = (unsigned)((okmask >> (bt * 4 * G)) & ((G * 4 >= 64) ? ~0ull : ((1ull << (4 * G)) - 1ull)));
+        if (okb == 0u) continue;                          // none of the four points touches the tile
+        // first / last point of the batch that touches the tile (group granularity: bit g * G of okb)
+        const int gfirst = (__builtin_ctz(okb) / G) + bt * 4, glast = ((31 - __builtin_clz(okb)) / G) + bt * 4;
+        const int s1f = __builtin_amdgcn_readlane(s[0], gfirst * G), s1l = __builtin_amdgcn_readlane(s[0], glast * G);
+        const int s2f = __builtin_amdgcn_readlane(s[1], gfirst * G), s3f = __builtin_amdgcn_readlane(s[2], gfirst * G);
+        // cubes (tile coordinates): bin of a point = (s + M - 1) >> 2, its stencil reaches bins - 1 .. + 1
+        const int cxlo = max(((s1f + M - 1) >> 2) - 1, 0), cxhi = min(((s1l + M - 1) >> 2) + 1, (neff[0] >> 2) - 1);
+        // (first cube of the y / z ranges, not below -1: a stencil that starts two cubes below the tile only reaches
+        // cube 0, which the shifted range still covers — and the atomics' base address stays inside the LDS)
+        const int cy0 = max(((s2f + M - 1) >> 2) - 1, -1), cz0 = max(((s3f + M - 1) >> 2) - 1, -1);
+#if defined(NUFFT_CUBES_DEBUG)
+        if (lane == 0) printf("cubes bt %d okb %08x gfirst %d glast %d s1f %d s1l %d s2f %d s3f %d cx [%d,%d] cy0 %d cz0 %d neff %d %d %d\n", bt, okb, gfirst, glast, s1f, s1l, s2f, s3f, cxlo, cxhi, cy0, cz0, neff[0], neff[1], neff[2]);
+#endif
+        // the lane's point: group bt * 4 + k
+        const int src = (bt * 4 + mk) * G;
+        const int p1 = __builtin_amdgcn_ds_bpermute(src << 2, s[0]);
+        const int p2 = __builtin_amdgcn_ds_bpermute(src << 2, s[1]);
+        const int p3 = __builtin_amdgcn_ds_bpermute(src << 2, s[2]);
+        const bool pok = (okmask >> src) & 1ull;
+        const double vsrc = bperm_t(value, src);         // unconditionally: ds_bpermute returns 0 from source lanes that are masked off
+        const double v = pok ? vsrc : 0.0;
+        const T* rows = strip_wave + (bt * 4 + mk) * (3 * SROW);
+        // window values: row[clamp(4 c + lane coordinate - s, -1, L) + 1]
+        double w1[NCX], w2[3], bz[3];
+#pragma unroll
+        for (int cx = 0; cx < NCX; ++cx) w1[cx] = lds_ld_f64(rows + 1 + max(-1, min(4 * cx + mi - p1, L)));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            w2[r] = lds_ld_f64(rows + SROW + 1 + max(-1, min(4 * (cy0 + r) + mb - p2, L)));
+            bz[r] = lds_ld_f64(rows + 2 * SROW + 1 + max(-1, min(4 * (cz0 + r) + mi - p3, L))) * v;
+        }
+        // cube (cx, cy0 + ry, cz0 + rz) = constant offset from the address of cube (0, cy0, cz0); cy0, cz0 >= -1: the
+        // caller keeps the tile at least 4 (PS + RS) doubles above the start of the LDS so that this base stays inside
+        // it.  (Compiler-issued atomics: the hazard between an MFMA and a reader of its result is the compiler's to
+        // handle, which it does not do for inline assembly.)
+        double* cube0 = tile + (mi * PS + mb * RS + mk) + (4 * cz0 * PS + 4 * cy0 * RS);
+        const unsigned ncy = (unsigned)(neff[1] >> 2), ncz = (unsigned)(neff[2] >> 2);
+        static_for_cubes<0, NCX * 3>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value, cx = I / 3, ry = I % 3;
+            if (cx >= cxlo && cx <= cxhi && (unsigned)(cy0 + ry) < ncy) {
+                const double A = w1[cx] * w2[ry];
+                double d[3];
+#pragma unroll
+                for (int rz = 0; rz < 3; ++rz) d[rz] = __builtin_amdgcn_mfma_f64_4x4x4f64(A, bz[rz], 0.0, 0, 0, 0);
+#pragma unroll
+                for (int rz = 0; rz < 3; ++rz)
+                    if ((unsigned)(cz0 + rz) < ncz) lds_atomic_add(cube0 + (4 * rz * PS + 4 * ry * RS + 4 * cx), d[rz]);
+            }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Spreading (output-driven)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float readlane_t(float x, int l) {
@@ -406,7 +503,12 @@ __device__ __forceinline__ double readlane_t(double x, int l) {
 // none of that code.
 // FIXEDT (only with !WRAP): the tile is the compile-time one of fixed_spread_tile(); the LDS atomics of a point
 // whose planes all lie inside the tile are then issued with immediate offsets from one address.
-template <typename T, bool CPLX, int D, int M, bool WRAP, bool OTHERK = false, bool FIXEDT = false>
+// CUBES (only with FIXEDT, real data, D = 3, M <= 4, oversampled sizes that are multiples of 4): four points at a time
+// are accumulated cube by cube — one v_mfma_f64_4x4x4_4b per 4 x 4 x 4 cube of cells forms the sum of the four points'
+// contributions (A = w1 w2, B = v w3, see patch_kernels.h for the operand layout), one ds_add_f64 adds it to the tile —
+// instead of one ds_add_f64 per point and stencil plane: 9 instead of 12.5 LDS atomics per point, and the products
+// leave the vector ALUs.
+template <typename T, bool CPLX, int D, int M, bool WRAP, bool OTHERK = false, bool FIXEDT = false, bool CUBES = false>
 __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
@@ -444,19 +546,30 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
         wrapd[d] = WRAP && ts.nt[d] == 1;   // a single tile spans the axis: wrap instead of clip
     }
     const int RS = FIXEDT ? FS.row_stride : ts.row_stride;
-    const int PS = FIXEDT ? FS.row_stride * FS.n[1] : ts.plane_stride;
+    const int PS = FIXEDT ? FS.plane_stride : ts.plane_stride;
 
-    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves, ts.max_items);
-    A* tile = reinterpret_cast<A*>(smem);
-    uint2* items = reinterpret_cast<uint2*>(smem + lay.tile_bytes);
+    static_assert(!CUBES || (FIXEDT && !CPLX && D == 3 && M <= 4), "cube accumulation: compile-time tile, real data, 3-D, M <= 4");
+    constexpr int SPAD = CUBES ? 1 : 0;                 // zeros around every dimension's window values in the strip
+    constexpr int SROW = L + 2 * SPAD;                  // strip row of one dimension
+    const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(A), (int)sizeof(T), D, M, NC, nwaves, ts.max_items, spread_strip_pad(D, NC));
+    // [tile | items | strips]; the cube variant puts the tile last: its immediate-offset atomics start from the address
+    // of a cube one cube row / layer below the tile origin, which must not fall below the start of the LDS
+    const int tile_off = CUBES ? lay.items_bytes + nwaves * lay.strip_bytes_per_wave : 0;
+    const int rest_off = CUBES ? 0 : lay.tile_bytes;
+    A* tile = reinterpret_cast<A*>(smem + tile_off);
+    uint2* items = reinterpret_cast<uint2*>(smem + rest_off);
     int* next_item = reinterpret_cast<int*>(items + ts.max_items);
-    T* strip_wave = reinterpret_cast<T*>(smem + lay.tile_bytes + lay.items_bytes + wave * lay.strip_bytes_per_wave);
+    T* strip_wave = reinterpret_cast<T*>(smem + rest_off + lay.items_bytes + wave * lay.strip_bytes_per_wave);
 
     for (int i = tid; i < ts.elems; i += nthreads) tile[i] = A(0);
+    if constexpr (CUBES) {
+        if (tile_off < 4 * (FS.plane_stride + FS.row_stride) * 8) __builtin_trap();                              // the padding zeros of the strips (never overwritten)
+        for (int i = lane; i < GP::PPW * D * 2; i += kWave) strip_wave[(i >> 1) * SROW + (i & 1) * (L + 1)] = T(0);
+    }
 
     // evaluation roles
     const int grp = lane / GP::G, q = lane % GP::G;
-    T* strip = strip_wave + grp * (D * L);
+    T* strip = strip_wave + grp * (D * SROW);
     WindowEval<T, NC, D, M, GP::G, OTHERK> we;
     we.init(a, q);
     // accumulation roles
@@ -540,10 +653,13 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
             if (okmask != 0ull) {                             // else nothing of this chunk touches the tile
             wave_lds_fence();
 #if !defined(NUFFT_ABL_NO_EVAL)
-            we.eval_to_strip(a, X, strip, q);
+            we.template eval_to_strip<SPAD>(a, X, strip, q);
 #endif
             wave_lds_fence();
 
+            if constexpr (CUBES) {
+                spread_cubes<T, M, GP::G, GP::PPW, FS.n[0], FS.n[1], FS.n[2], FS.row_stride, FS.plane_stride>(tile, strip_wave, s, vmine, okmask, neff, lane);
+            } else {
 #if !defined(NUFFT_ABL_NO_VISIT)
             // one point of the chunk: w1v / w2v are the lane's window values of dimensions 1 and 2 (per pass),
             // w3a the lane's share of the dimension-3 values (value l & 15 in lane l of every 16-lane row)
@@ -609,8 +725,8 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
                             } else {
                                 A* pl = addr + (S3 + first3) * PS;
                                 if (planes == (1u << L) - 1u) {      // all planes inside: no per-plane control
-                                    if constexpr (FIXEDT && (L - 1) * FS.row_stride * FS.n[1] * 8 < 65536) {
-                                        lds_add_planes<L, FS.row_stride * FS.n[1] * 8>(pl, w, w3, std::make_integer_sequence<int, L>{});
+                                    if constexpr (FIXEDT && (L - 1) * FS.plane_stride * 8 < 65536) {
+                                        lds_add_planes<L, FS.plane_stride * 8>(pl, w, w3, std::make_integer_sequence<int, L>{});
                                     } else {
 #pragma unroll
                                         for (int j3 = 0; j3 < L; ++j3) {
@@ -670,6 +786,7 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
 #else
             asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(vmine));
 #endif
+            }   // !CUBES
             }   // okmask != 0
             if (more && q < NC) {
                 vcur = vin[(int64_t)recn.idx * NC + q];

@@ -21,6 +21,10 @@ const void* spread_fixed_f32r(int D, int M, int* n);
 const void* spread_fixed_f32c(int D, int M, int* n);
 const void* spread_fixed_f64r(int D, int M, int* n);
 const void* spread_fixed_f64c(int D, int M, int* n);
+const void* spread_cubes_f32r(int D, int M);
+const void* spread_cubes_f32c(int D, int M);
+const void* spread_cubes_f64r(int D, int M);
+const void* spread_cubes_f64c(int D, int M);
 void interp_fixed_dims_f32r(int D, int M, int* n);
 void interp_fixed_dims_f32c(int D, int M, int* n);
 void interp_fixed_dims_f64r(int D, int M, int* n);
@@ -35,12 +39,19 @@ void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n) {
 
 // Kernel with the compile-time spreading tile (null: none) and the tile itself (n[0..2], n[3] = row stride).
 const void* spread_fixed_kernel(int dtype, int is_complex, int D, int M, int* n) {
-    n[0] = n[1] = n[2] = n[3] = 0;
+    n[0] = n[1] = n[2] = n[3] = n[4] = 0;
     if (M < 2 || M > 10 || D < 1 || D > 3) return nullptr;
     if (dtype == NUFFT_F32) return is_complex ? spread_fixed_f32c(D, M, n) : spread_fixed_f32r(D, M, n);
     return is_complex ? spread_fixed_f64c(D, M, n) : spread_fixed_f64r(D, M, n);
 }
 void spread_fixed_dims(int dtype, int is_complex, int D, int M, int* n) { (void)spread_fixed_kernel(dtype, is_complex, D, M, n); }
+// cube-accumulation variant of that kernel (real data, 3-D, M <= 4), or null
+const void* spread_cubes_kernel(int dtype, int is_complex, int D, int M) {
+    if (M < 2 || M > 10 || D != 3) return nullptr;
+    if (dtype == NUFFT_F32) return is_complex ? spread_cubes_f32c(D, M) : spread_cubes_f32r(D, M);
+    return is_complex ? spread_cubes_f64c(D, M) : spread_cubes_f64r(D, M);
+}
+bool spread_cubes_available(int dtype, int is_complex, int D, int M) { return spread_cubes_kernel(dtype, is_complex, D, M) != nullptr; }
 
 // `flag`: spreading = single-tile axis (wrap variant); interpolation = compile-time tile.
 // `other`: window evaluation of the non-default kernels (see needs_other_eval).
@@ -70,8 +81,13 @@ static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, 
         if (e != hipSuccess) return e;
     }
     if (!interp && !other) {
-        int n[4];
+        int n[5];
         const void* fn = spread_fixed_kernel(dtype, is_complex, D, M, n);
+        if (fn) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        fn = spread_cubes_kernel(dtype, is_complex, D, M);
         if (fn) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) return e;
@@ -122,9 +138,13 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
     const bool other = needs_other_eval(a.kernel, a.evalmode) || a.weights != nullptr;   // general variant
     const void* fn = pick(interp, a.dtype, a.is_complex, a.D, a.M, interp ? (a.fixed_tile != 0 && !other) : wrap, other);
     if (!interp && a.fixed_tile != 0 && !other && !wrap) {
-        int n[4];
+        int n[5];
         const void* ff = spread_fixed_kernel(a.dtype, a.is_complex, a.D, a.M, n);
         if (ff) fn = ff;
+        if (ff && a.cubes) {
+            const void* fc = spread_cubes_kernel(a.dtype, a.is_complex, a.D, a.M);
+            if (fc) fn = fc;
+        }
     }
     if (!fn) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {

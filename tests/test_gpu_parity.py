@@ -533,3 +533,29 @@ def test_automatic_engine_choice_per_point_set(dist):
         nufft.exec_type1(ua, auto, v)
         nufft.exec_type1(ur, ref, v)
         assert float((ua - ur).norm() / ur.norm()) < 1e-12, name
+
+
+def test_cube_accumulation_variant_of_the_tile_kernel(monkeypatch):
+    """NUFFT_SPREAD_CUBES=1 (opt-in): the LDS-tile kernel accumulates four points at a time cube by
+    cube (v_mfma_f64_4x4x4 + one ds_add_f64 per cube) instead of plane by plane.  Same sums: must agree with the default
+    face mapping on sparse, dense and one-cell point sets (partially filled K-batches, stencils two cubes below a tile)."""
+    nufft = _nufft()
+    plans = {}
+    for c in ("0", "1"):
+        monkeypatch.setenv("NUFFT_SPREAD_CUBES", c)
+        plans[c] = nufft.PlanNUFFT(torch.float64, (64, 64, 64), m=4, sigma=2.0, spread_method="lds_tiles",
+                                   kernel_evalmode=nufft.FastApproximation(), backend=nufft.ROCBackend(0))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cases = [tuple(torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * (2 * np.pi) for _ in range(3)) for n in (3000, 400_000)]
+    for n in (5, 6, 13):                                  # n points in one cell
+        cases.append(tuple((torch.full((n,), 70.3 / 128 * 2 * np.pi, dtype=torch.float64, device="cuda")
+                            + 1e-3 * torch.rand(n, dtype=torch.float64, device="cuda", generator=g)).contiguous() for _ in range(3)))
+    for xs in cases:
+        v = torch.randn(xs[0].numel(), dtype=torch.float64, device="cuda", generator=g)
+        outs = []
+        for c in ("0", "1"):
+            nufft.set_points(plans[c], xs)
+            u = torch.empty(plans[c].shape, dtype=torch.complex128, device="cuda")
+            nufft.exec_type1(u, plans[c], v)
+            outs.append(u)
+        assert float((outs[0] - outs[1]).norm() / outs[0].norm()) < 1e-13
