@@ -96,6 +96,7 @@ struct PatchPlan {
     int npx, npy, nseg, segl, ntasks;   // patch columns, segments of cube layers along dimension 3, wave tasks
     int lds_bytes;                      // dynamic LDS per workgroup
     int pby;                            // rows of cube columns per patch
+    int occ;                            // waves per SIMD the kernel is compiled for
 };
 PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other);
 // set_points: decides on the device which engine serves this point set (balance.hip); choice = uint32[4], zeroed once

@@ -42,18 +42,31 @@
 
 namespace nufft {
 
-#ifndef NUFFT_PATCH_ACC_CAP
-#define NUFFT_PATCH_ACC_CAP 48      // accumulators (cubes) per wave
+// Register budget of a patch: accumulators (cubes) per wave and the waves per SIMD the kernel is compiled for.
+// Two waves per SIMD and 48 accumulators everywhere except complex data at M >= 7, where a stencil reaches 5+ cubes
+// per dimension: the matrix work dominates there and a larger patch (fewer visits: each one re-evaluates 3 x 2M window
+// values per point) is worth more than the second wave (C3: 168 -> 156 ms, measured; every smaller case lost 8-40 %).
+// NUFFT_PATCH_ACC_CAP / NUFFT_PATCH_OCC override both for every instantiation (ablation builds).
+constexpr __host__ __device__ int patch_acc_cap(int ncomp, int M) {
+#if defined(NUFFT_PATCH_ACC_CAP)
+    return NUFFT_PATCH_ACC_CAP;
+#else
+    return (ncomp == 2 && M >= 7) ? 120 : 48;
 #endif
-#ifndef NUFFT_PATCH_OCC
-#define NUFFT_PATCH_OCC 2           // waves per SIMD the register budget is sized for
+}
+constexpr __host__ __device__ int patch_occupancy(int ncomp, int M) {
+#if defined(NUFFT_PATCH_OCC)
+    return NUFFT_PATCH_OCC;
+#else
+    return (ncomp == 2 && M >= 7) ? 1 : 2;
 #endif
+}
 
 constexpr __host__ __device__ int floor_div4(int a) { return a >= 0 ? a / 4 : -((-a + 3) / 4); }
 
 // rows of cube columns per patch: NC * NCB * PBX * PBY accumulators (two VGPRs each) must leave room for the rest
-constexpr __host__ __device__ int patch_rows(int ncomp, int ncb) {
-    int r = NUFFT_PATCH_ACC_CAP / (ncomp * ncb * 4);
+constexpr __host__ __device__ int patch_rows(int ncomp, int ncb, int cap) {
+    int r = cap / (ncomp * ncb * 4);
     return r < 1 ? 1 : (r > 4 ? 4 : r);
 }
 
@@ -64,7 +77,7 @@ struct PatchCfg {
     static constexpr int CHI = floor_div4(3 + M);
     static constexpr int NCB = CHI - CLO + 1;
     static constexpr int PBX = 4;
-    static constexpr int PBY = patch_rows(NC, NCB);
+    static constexpr int PBY = patch_rows(NC, NCB, patch_acc_cap(NC, M));
     static constexpr int NRB = PBY + NCB - 1;           // rows of bins visited per bin layer
     static constexpr int NACC = NC * NCB * PBX * PBY;
     static constexpr int PADB = 4 - M - 4 * CLO;        // zeros in front of / behind the 2M window values of a row
@@ -145,7 +158,7 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
 }
 
 template <typename T, bool CPLX, int M, bool OTHERK>
-__global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH_OCC) void spread_patch_kernel(PatchArgs<T> a) {
+__global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, M)) void spread_patch_kernel(PatchArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     using P = PatchCfg<NC, M>;
     constexpr int L = P::L, CLO = P::CLO, CHI = P::CHI, NCB = P::NCB, PBX = P::PBX, PBY = P::PBY, NRB = P::NRB;

@@ -336,7 +336,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         const PatchPlan pp = patch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
         p->patch.eligible = pp.eligible;
         p->patch.npx = pp.npx; p->patch.npy = pp.npy; p->patch.nseg = pp.nseg; p->patch.segl = pp.segl;
-        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes; p->patch.pby = pp.pby;
+        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes; p->patch.pby = pp.pby; p->patch.occ = pp.occ;
         if (req == NUFFT_SPREAD_MFMA_PATCHES && !pp.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = MFMA patches needs a 3-D grid of 4-cell bins with every oversampled "
                                                "axis a multiple of 4 and at least 2 (patch + stencil) bins long, and the default window evaluation");
@@ -524,7 +524,7 @@ static int build_device(nufft_plan* p) {
         NUFFT_HIP(hipMemset(p->d_patch_choice, 0, 4 * sizeof(uint32_t)));
         hipDeviceProp_t prop;
         NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
-        p->wave_slots = prop.multiProcessorCount * 8;
+        p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
     }
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {

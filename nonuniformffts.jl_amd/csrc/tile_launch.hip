@@ -196,6 +196,7 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
     pp.ntasks = cols * pp.nseg;
     pp.lds_bytes = lds;
     pp.pby = pby;
+    pp.occ = patch_occupancy(is_complex ? 2 : 1, M);
     pp.eligible = true;
     return pp;
 }
