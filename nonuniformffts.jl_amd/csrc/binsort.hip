@@ -97,8 +97,10 @@ __global__ __launch_bounds__(kCountThreads) void bin_count_kernel(BinArgs<T, D> 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs<T, D> a, const uint32_t* __restrict__ offsets,
                                                          const uint2* __restrict__ binrank,
-                                                         PointRec<T, D>* __restrict__ sorted) {
+                                                         PointRec<T, D>* __restrict__ sorted, uint32_t* __restrict__ counts, int ncounts) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the histogram has been scanned into `offsets`: clear it for the next set_points (saves that call's zero-fill launch)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncounts; i += stride) counts[i] = 0u;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.np; p += stride) {
         const uint2 br = binrank[p];
         PointRec<T, D> rec;
@@ -141,8 +143,11 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
     a.np = s.np;
     a.g = s.g;
     a.point_transform = s.point_transform;
-    hipError_t e = launch_zero_fill(s.counts, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (!s.counts_clean) {      // normally the previous call's scatter pass has left the histogram zeroed
+        e = launch_zero_fill(s.counts, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
+        if (e != hipSuccess) return e;
+    }
     if (s.np > 0) {
         int64_t blocks = (s.np + kCountThreads * kCountPPT - 1) / (kCountThreads * kCountPPT);
         if (blocks > 256 * 16) blocks = 256 * 16;
@@ -157,7 +162,7 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
         int64_t blocks = (s.np + threads - 1) / threads;
         if (blocks > 256 * 32) blocks = 256 * 32;
         hipLaunchKernelGGL((bin_scatter_kernel<T, D>), dim3((unsigned)blocks), dim3(threads), 0, stream, a, s.offsets,
-                           static_cast<const uint2*>(s.binrank), static_cast<PointRec<T, D>*>(s.sorted));
+                           static_cast<const uint2*>(s.binrank), static_cast<PointRec<T, D>*>(s.sorted), s.counts, s.g.nbins + 1);
     }
     return hipGetLastError();
 }

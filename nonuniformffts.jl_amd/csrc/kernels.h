@@ -17,6 +17,7 @@ struct SortArgs {
     const void* coords[3];
     Geom g;
     uint32_t* counts;      // [nbins + 1]
+    bool counts_clean;     // the histogram is all zero on entry (left so by the previous call's scatter pass)
     uint32_t* offsets;     // [nbins + 1]
     void* binrank;         // uint2[np]
     void* sorted;          // PointRec<T, D>[np]

@@ -136,6 +136,7 @@ struct nufft_plan {
     int64_t Np = -1;
     int64_t Np_capacity = 0;
     uint32_t* d_counts = nullptr;      // [ntiles + 1]  histogram
+    bool counts_clean = false;         // d_counts is all zero (plan creation; every completed set_points leaves it so)
     uint32_t* d_offsets = nullptr;     // [ntiles + 1]  exclusive scan
     void* d_binrank = nullptr;         // uint2[Np]: (tile, rank)
     void* d_sorted = nullptr;          // PointRec<T, D>[Np]

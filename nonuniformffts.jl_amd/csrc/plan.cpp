@@ -953,6 +953,8 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     for (int d = 0; d < 3; ++d) s.coords[d] = d < p->D ? coords[d] : nullptr;
     s.g = make_geom(p);
     s.counts = p->d_counts;
+    s.counts_clean = p->counts_clean;
+    p->counts_clean = false;
     s.offsets = p->d_offsets;
     s.binrank = p->d_binrank;
     s.sorted = p->d_sorted;
@@ -990,6 +992,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         NUFFT_HIP(launch_patch_choice(s.g, pp, p->patch.pby, p->d_offsets, np, slots, p->d_patch_choice, p->bal.d_slots, stream));
     }
     p->Np = np;
+    p->counts_clean = np > 0;      // the scatter pass has cleared the histogram (no point, no scatter pass: cleared next time)
     return NUFFT_OK;
 }
 
