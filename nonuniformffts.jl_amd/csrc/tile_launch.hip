@@ -1,6 +1,7 @@
 // Host-side dispatch of the tile kernels over (precision, complex?, D, M).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "tile_kernels.h"
@@ -187,7 +188,8 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
     // segments along dimension 3: enough tasks for ~4 rounds of the 2048 resident waves, at least 8 cube layers each
     // (a segment visits ncb - 1 bin layers beyond its own)
     const int cols = pp.npx * pp.npy;
-    int nseg = (8192 + cols - 1) / cols;
+    static const int task_target = [] { const char* e = std::getenv("NUFFT_PATCH_TASKS"); return e && *e ? std::atoi(e) : 8192; }();
+    int nseg = (task_target + cols - 1) / cols;
     const int max_seg = g.nb[2] / 8 > 0 ? g.nb[2] / 8 : 1;
     if (nseg > max_seg) nseg = max_seg;
     if (nseg < 1) nseg = 1;
