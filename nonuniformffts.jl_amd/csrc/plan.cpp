@@ -342,7 +342,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
                                                "axis a multiple of 4 and at least 2 (patch + stencil) bins long, and the default window evaluation");
         // automatic choice, from the measurements in DESIGN.md section 4.4: the patches win where the stencil carries
         // more matrix work per point visit (complex data, M >= 5: 1.15x ... 2x), the LDS tiles for real data at M <= 4
-        const bool prefer_patches = p->is_complex || p->M >= 5;
+        const bool prefer_patches = p->is_complex || p->M >= 5 || env_int("NUFFT_PREFER_PATCHES", 0) != 0;     // (the switch: test runs)
         p->spread_method = (pp.eligible && (req == NUFFT_SPREAD_MFMA_PATCHES || (req == NUFFT_SPREAD_AUTO && prefer_patches)))
                                ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
     }
