@@ -85,7 +85,17 @@ struct PatchCfg {
     static constexpr int LW = PADB + L + PADA;
     static constexpr int G = next_pow2(L);              // lanes per point during window evaluation
     static constexpr int PPW = kWave / G;
-    static constexpr int CH = M <= 5 ? 32 : 16;         // points per chunk (staged in LDS)
+    // points per chunk (staged in LDS): as much of a run of the sorted array as the LDS holds — every chunk pays the
+    // commit / prefetch / coefficient reload once (C3: 157 -> 137 ms going from 16 to 48 points).  One wave per SIMD =
+    // one workgroup per CU with 160 KiB, two waves per SIMD = two workgroups with 80 KiB each.
+    static constexpr int chunk_points() {
+        const int occ = patch_occupancy(NC, M);
+        const int budget = (occ == 1 ? 160 : 80) * 1024 - 512;
+        for (int ch = (occ == 1 ? 64 : 32); ch > 16; ch -= 8)
+            if (4 * ((ch + 1) * (3 * LW * 8 + 32) + ch * 48 + 32) + 3 * (M + 4) * L * 8 + 64 <= budget) return ch;
+        return 16;
+    }
+    static constexpr int CH = chunk_points();
     static constexpr int META = 32;                     // bytes: {sx, offy, offz, rbx} + value (re, im)
     static constexpr int PSTRIDE = 3 * LW * 8 + META;   // bytes per staged point
     static constexpr int WBYTES = (CH + 1) * PSTRIDE;   // + the all-zero point
