@@ -43,22 +43,25 @@
 namespace nufft {
 
 // Register budget of a patch: accumulators (cubes) per wave and the waves per SIMD the kernel is compiled for.
-// Two waves per SIMD and 48 accumulators everywhere except complex data at M >= 7, where a stencil reaches 5+ cubes
-// per dimension: the matrix work dominates there and a larger patch (fewer visits: each one re-evaluates 3 x 2M window
-// values per point) is worth more than the second wave (C3: 168 -> 156 ms, measured; every smaller case lost 8-40 %).
+// Two waves per SIMD and 48 accumulators by default; one wave per SIMD with 120 accumulators (a larger patch: fewer
+// visits, each of which re-evaluates 3 x 2M window values per point and sets the operands up again; and whole runs of
+// the sorted array per chunk, see chunk_points) where a stencil reaches 4+ cubes per dimension AND carries two
+// components, or 7 cubes.  Measured (spread stage at 256^3 -> 512^3, Np = 1e7, two waves vs one): ComplexF64 m = 4 4.9 vs
+// 5.8 ms, m = 5 11.5 vs 10.9, m = 6 19.3 vs 18.0, m = 7 20.5 vs 18.0 (with the larger chunks); Float64 m = 7 11.9 vs 12.8,
+// m = 8 11.4 vs 12.1, m = 9 18.5 vs 21.2, m = 10 39.3 vs 29.4; C3 (ComplexF32, m = 8) 168 vs 136 ms.
 // NUFFT_PATCH_ACC_CAP / NUFFT_PATCH_OCC override both for every instantiation (ablation builds).
 constexpr __host__ __device__ int patch_acc_cap(int ncomp, int M) {
 #if defined(NUFFT_PATCH_ACC_CAP)
     return NUFFT_PATCH_ACC_CAP;
 #else
-    return (ncomp == 2 && M >= 7) ? 120 : 48;
+    return ((ncomp == 2 && M >= 5) || M >= 10) ? 120 : 48;
 #endif
 }
 constexpr __host__ __device__ int patch_occupancy(int ncomp, int M) {
 #if defined(NUFFT_PATCH_OCC)
     return NUFFT_PATCH_OCC;
 #else
-    return (ncomp == 2 && M >= 7) ? 1 : 2;
+    return ((ncomp == 2 && M >= 5) || M >= 10) ? 1 : 2;
 #endif
 }
 
