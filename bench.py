@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-reference-protocol", action="store_true")
     ap.add_argument("--no-density-sweep", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact C3 / C4 records of the default run")
     ap.add_argument("--force-distributed", action="store_true",
                     help="take the multi-process code path (RCCL init, side-stream gather) even with one rank: "
                          "a single-GPU self-test of the N > 1 path")
@@ -185,27 +186,29 @@ def main():
     for k in ("n", "np", "m", "sigma"):
         if getattr(a, k):
             cfg[k] = getattr(a, k)
-    Z = getattr(torch, cfg["Z"])
-    is_complex = Z.is_complex
-    T = torch.float32 if Z in (torch.float32, torch.complex64) else torch.float64
-    CT = torch.complex64 if T == torch.float32 else torch.complex128
-    real_bytes = 4 if T == torch.float32 else 8
-    Np, Cn = int(cfg["np"]), int(cfg["C"])
-    dims = (cfg["n"],) * 3
     steps = a.steps if a.steps > 0 else cfg["steps"]
     full = world == 1 and not a.only_headline
-
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
-    xs = tuple(torch.rand(Np, dtype=T, device=dev, generator=g) * (2 * np.pi) for _ in dims)
-    vps = tuple(torch.randn(Np, dtype=Z, device=dev, generator=g) for _ in range(Cn))
 
     gather_stream = torch.cuda.Stream(device=dev) if distributed and not a.no_gather else None
 
     def stream_ptr():
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-    def measure(evalmode_name):
+    def prepare(cfg):
+        """Synthetic inputs of one configuration, resident in HBM (U[0, 2pi) coordinates, N(0, 1) values,
+        seed 42 + rank)."""
+        Z = getattr(torch, cfg["Z"])
+        T = torch.float32 if Z in (torch.float32, torch.complex64) else torch.float64
+        P = dict(Z=Z, T=T, CT=torch.complex64 if T == torch.float32 else torch.complex128, is_complex=Z.is_complex,
+                 real_bytes=4 if T == torch.float32 else 8, Np=int(cfg["np"]), Cn=int(cfg["C"]), dims=(cfg["n"],) * 3, cfg=cfg)
+        g = torch.Generator(device=dev).manual_seed(42 + rank)
+        P["xs"] = tuple(torch.rand(P["Np"], dtype=T, device=dev, generator=g) * (2 * np.pi) for _ in P["dims"])
+        P["vps"] = tuple(torch.randn(P["Np"], dtype=Z, device=dev, generator=g) for _ in range(P["Cn"]))
+        return P
+
+    def measure(P, evalmode_name, steps, gather):
         """K steps of set_points! + exec_type1!, then of set_points! + exec_type2!, with stage events."""
+        cfg, Z, CT, Np, Cn, dims, xs, vps = P["cfg"], P["Z"], P["CT"], P["Np"], P["Cn"], P["dims"], P["xs"], P["vps"]
         mode = nufft.Direct() if evalmode_name == "direct" else nufft.FastApproximation()
         plan = nufft.PlanNUFFT(Z, dims, m=cfg["m"], sigma=cfg["sigma"], ntransforms=Cn, kernel_evalmode=mode,
                                backend=nufft.ROCBackend(local_rank))
@@ -213,11 +216,12 @@ def main():
         uhat = [tuple(torch.empty(plan.shape, dtype=CT, device=dev) for _ in range(Cn)) for _ in range(2)]   # double buffer
         vout = tuple(torch.empty(Np, dtype=Z, device=dev) for _ in range(Cn))
         gather_list = None
-        if gather_stream is not None and rank == 0:
-            # complex spectra travel as their (re, im) real views (same bytes; every backend supports reals)
-            gather_list = [[torch.empty_like(torch.view_as_real(uhat[0][0])) for _ in range(world)] for _ in range(2)]
+        if gather and gather_stream is not None and rank == 0:
+            # complex spectra travel as their (re, im) real views (same bytes; every backend supports reals);
+            # one receive buffer per (double buffer, component, source rank)
+            gather_list = [[[torch.empty_like(torch.view_as_real(uhat[0][0])) for _ in range(world)] for _ in range(Cn)] for _ in range(2)]
         gather_done = [None, None]
-        use_gather = [gather_stream is not None]
+        use_gather = [gather and gather_stream is not None]
 
         def step_type1(k, events=None):
             """set_points! + exec_type1! (the stages of src/NonuniformFFTs.jl:157-186, called one by one so that
@@ -244,7 +248,8 @@ def main():
                 done.record()
                 gather_stream.wait_event(done)
                 with torch.cuda.stream(gather_stream):
-                    dist.gather(torch.view_as_real(out[0]), gather_list[k % 2] if rank == 0 else None, dst=0)   # stream-ordered, host does not block
+                    for c in range(Cn):     # every component's spectrum (stream-ordered, the host does not block)
+                        dist.gather(torch.view_as_real(out[c]), gather_list[k % 2][c] if rank == 0 else None, dst=0)
                     e = torch.cuda.Event()
                     e.record()
                     gather_done[k % 2] = e
@@ -300,13 +305,14 @@ def main():
         st2 = stage_ms(ev2, ["set_points", "deconv_pad", "fft", "interp"])
         exec1_ms = st1["spread"] + st1["fft"] + st1["deconv"]
         exec2_ms = st2["deconv_pad"] + st2["fft"] + st2["interp"]
+        engine_used = plan.spread_engine_used()          # the per-point-set decision read back from the device (after the timed regions)
         rec = {
             "evalmode": "Direct" if evalmode_name == "direct" else "FastApproximation",
             "value": world * Np * steps / dt1, "ms_per_step": dt1 / steps * 1e3,
             "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt1},
             "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt2,
                       "ms_per_step": dt2 / steps * 1e3},
-            "spread_engine": {1: "lds_tiles", 2: "mfma_patches"}[int(info.spread_method)],
+            "spread_engine": engine_used,
             "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
             "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
         }
@@ -314,8 +320,10 @@ def main():
         torch.cuda.empty_cache()
         return rec
 
-    head = measure(a.evalmode)
-    other = measure("fast" if a.evalmode == "direct" else "direct") if full else None
+    P = prepare(cfg)
+    Np, Cn, is_complex, real_bytes = P["Np"], P["Cn"], P["is_complex"], P["real_bytes"]
+    head = measure(P, a.evalmode, steps, True)
+    other = measure(P, "fast" if a.evalmode == "direct" else "direct", steps, True) if full else None
 
     ab = algorithmic_bytes(Np, head["oversampled"], head["size"], is_complex, real_bytes, Cn)
     st1, st2 = head["type1"]["stages_ms"], head["type2"]["stages_ms"]
@@ -388,6 +396,37 @@ def main():
                        "type1": other["type1"], "type2": other["type2"], "spread_engine": other["spread_engine"],
                        "roofline_frac": ab["spread_kernel"] / o_spread_s / 1e9 / HBM_PEAK_GBS,
                        "roofline_frac_of_measured_peak": (ab["spread_kernel"] / o_spread_s / 1e9 / peak_m) if peak_m else None}
+    # The ROC default window (Direct) as a scalar inside `config`, and the other single-GPU BASELINE configurations (C3, C4)
+    # as compact records there too, so that they are part of the driver-run line and not only of builder-run profiles.
+    direct_rec = head if head["evalmode"] == "Direct" else other
+    if direct_rec is not None:
+        result["config"]["direct_value"] = direct_rec["value"]
+        result["config"]["direct_ms_per_step"] = direct_rec["ms_per_step"]
+    if full and a.config == "c2" and not a.no_other_configs:
+        del P
+        torch.cuda.empty_cache()
+        others = {}
+        for name in ("c3", "c4"):
+            try:
+                oc = dict(CONFIGS[name])
+                Po = prepare(oc)
+                r = measure(Po, a.evalmode, 3, False)
+                abo = algorithmic_bytes(Po["Np"], r["oversampled"], r["size"], Po["is_complex"], Po["real_bytes"], Po["Cn"])
+                sp_ms, ip_ms = r["type1"]["stages_ms"]["spread"], r["type2"]["stages_ms"]["interp"]
+                others[name] = {
+                    "workload": oc["label"] + f", m={oc['m']}, sigma={oc['sigma']}, {r['evalmode']} window",
+                    "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": 3,
+                    "type2_value": r["type2"]["with_set_points_pts_per_s"], "type2_ms_per_step": r["type2"]["ms_per_step"],
+                    "spread_ms": sp_ms, "interp_ms": ip_ms, "spread_engine": r["spread_engine"],
+                    "roofline_frac": abo["spread_kernel"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "roofline_frac_own_traffic": abo["spread_kernel_min"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "interp_roofline_frac": abo["interp_kernel"] / (ip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                }
+                del Po
+                torch.cuda.empty_cache()
+            except Exception as exc:           # informative records: never lose the headline line over them
+                others[name] = {"error": repr(exc)}
+        result["config"]["other_configs"] = others
     if full and a.config == "c2" and not a.no_reference_protocol:
         result["reference_protocol"] = reference_protocol(cfg, nufft, dev, sweep=not a.no_density_sweep)
     if rank == 0 and full and not a.no_cpu_baseline:

@@ -238,7 +238,17 @@ int nufft_set_timing(nufft_plan* plan, int enable);
  * Synchronises on the recorded events. */
 int nufft_get_stage_times(nufft_plan* plan, float* ms_out);
 
+/* Which engine served the point set of the last nufft_set_points: NUFFT_SPREAD_LDS_TILES or NUFFT_SPREAD_MFMA_PATCHES.
+ * On plans whose nufft_info.spread_method is MFMA patches, set_points decides per point set on the device (a point
+ * set that concentrates in a few patches goes to the LDS tiles, whose heavy tiles are shared by several workgroups);
+ * this reads the decision back (4 bytes, synchronises `stream`).  Inspection only: nothing on the hot path needs it. */
+int nufft_spread_engine_used(nufft_plan* plan, int* engine_out, void* stream);
+
 /* ---- misc ----------------------------------------------------------------------------- */
+/* sizeof(nufft_params) / sizeof(nufft_info) of the library build: a binding that mirrors the structs by hand
+ * (ctypes, Julia) compares them with its own layout before the first call. */
+int64_t nufft_sizeof_params(void);
+int64_t nufft_sizeof_info(void);
 const char* nufft_strerror(int code);
 /* Last error message of the calling thread (more detail than nufft_strerror). */
 const char* nufft_last_error_message(void);

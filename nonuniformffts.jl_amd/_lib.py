@@ -98,6 +98,9 @@ SYMBOLS = {
     "nufft_get_sort_result": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_uint32), C.c_int64, _P]),
     "nufft_set_timing": (C.c_int, [_P, C.c_int]),
     "nufft_get_stage_times": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "nufft_spread_engine_used": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "nufft_sizeof_params": (C.c_int64, []),
+    "nufft_sizeof_info": (C.c_int64, []),
     "nufft_strerror": (C.c_char_p, [C.c_int]),
     "nufft_last_error_message": (C.c_char_p, []),
     "nufft_version": (C.c_int, []),
@@ -121,6 +124,11 @@ def _load():
         fn = getattr(lib, name)   # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
+    # the two structs are mirrored by hand above: refuse a library whose layout differs
+    for name, mirror in (("nufft_sizeof_params", NufftParams), ("nufft_sizeof_info", NufftInfo)):
+        if getattr(lib, name)() != C.sizeof(mirror):
+            raise ImportError(f"{LIB_PATH}: {name}() = {getattr(lib, name)()} but the ctypes mirror has {C.sizeof(mirror)} bytes "
+                              "(include/nufft_mi355x.h and _lib.py disagree)")
     return lib
 
 

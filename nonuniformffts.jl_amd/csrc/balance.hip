@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void patch_choice_kernel(Geom g, PatchPlan pp,
             __threadfence();
             const unsigned long long mx = atomicExch(&choice[0], 0u);
             choice[1] = 0u;
-            // heaviest task <= (slots_num / share_den) even shares of the wave slots
-            const bool patches = mx * share_den <= np * slots_num || np == 0;
+            // heaviest task <= np * slots_num / share_den (+ 64 points: tiny point sets fluctuate)
+            const bool patches = mx * share_den <= np * slots_num + 64ull * share_den || np == 0;
             choice[2] = patches ? 1u : 0u;
             if (patches) slots_in_use[0] = 0u;
         }
@@ -176,9 +176,14 @@ __global__ __launch_bounds__(256) void patch_choice_kernel(Geom g, PatchPlan pp,
 hipError_t launch_patch_choice(const Geom& g, const PatchPlan& pp, int pby, const uint32_t* offsets, int64_t np, int wave_slots,
                                uint32_t* choice, uint32_t* slots_in_use, hipStream_t stream) {
     const int waves_per_block = 256 / kWave;
-    // patches while the heaviest task holds at most one even share: max_task <= np / wave_slots  (factor 1 / 1)
+    // Patches while the heaviest task holds at most one even share of the wave slots, max_task <= np / wave_slots — or,
+    // on grids with fewer tasks than that (no point set could meet the first bound: the mean task already exceeds it),
+    // at most twice the mean task, max_task <= 2 np / ntasks.  A patch task is not shared between workgroups, so its
+    // heaviest task bounds the kernel; the LDS tiles split heavy tiles into slices.
+    unsigned long long num = 1ull, den = (unsigned long long)wave_slots;
+    if (2ull * (unsigned long long)wave_slots > (unsigned long long)pp.ntasks) { num = 2ull; den = (unsigned long long)pp.ntasks; }
     hipLaunchKernelGGL(patch_choice_kernel, dim3((unsigned)((pp.ntasks + waves_per_block - 1) / waves_per_block)), dim3(256), 0, stream,
-                       g, pp, pby, offsets, (unsigned long long)np, 1ull, (unsigned long long)wave_slots, choice, slots_in_use);
+                       g, pp, pby, offsets, (unsigned long long)np, num, den, choice, slots_in_use);
     return hipGetLastError();
 }
 

@@ -117,7 +117,7 @@ struct nufft_plan {
         int npx = 0, npy = 0, nseg = 0, segl = 0, ntasks = 0, lds_bytes = 0, pby = 0, occ = 2;
     } patch;
     uint32_t* d_patch_choice = nullptr;   // [4]: scratch of patch_choice_kernel; [2] = 1: this point set is spread by the patches
-    int wave_slots = 2048;             // resident waves of the patch kernel on this device (CUs x 8)
+    int wave_slots = 2048;             // resident waves of the patch kernel on this device (CUs x 4 SIMDs x its waves per SIMD)
     void* d_vsorted = nullptr;         // C value vectors in sorted order (MFMA-patch spreading)
     int64_t lds_spread = 0, lds_interp = 0;
 

@@ -996,6 +996,24 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     return NUFFT_OK;
 }
 
+int nufft_spread_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    if (!engine_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
+    *engine_out = NUFFT_SPREAD_LDS_TILES;
+    if (p->spread_method != NUFFT_SPREAD_MFMA_PATCHES) return NUFFT_OK;
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    uint32_t flag = 0;
+    NUFFT_HIP(hipMemcpyAsync(&flag, p->d_patch_choice + 2, sizeof(flag), hipMemcpyDeviceToHost, stream));
+    NUFFT_HIP(hipStreamSynchronize(stream));
+    *engine_out = flag ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
+    return NUFFT_OK;
+}
+
+int64_t nufft_sizeof_params(void) { return (int64_t)sizeof(nufft_params); }
+int64_t nufft_sizeof_info(void) { return (int64_t)sizeof(nufft_info); }
+
 int nufft_fill_zeros(nufft_plan* p, void* stream_) {
     int rc = require_device(p);
     if (rc) return rc;

@@ -252,6 +252,38 @@ static void fill_shape(TileShapeHost& t, int D, int M, int ncomp, int real_bytes
     t.max_items = (int)tile_items_bound(!padded, D, M, b, t.n, nbv);
 }
 
+// Exact maximum, over all tile positions, of the runs of the sorted array a tile looks up — the arithmetic of the kernels
+// themselves (bin_segments / the bin box of an interpolation tile, tile_kernels.h) replayed on the host for every tile
+// coordinate of every axis (the count is a product over the axes, so the maximum is the product of the per-axis maxima).
+// A plan whose table (tile_items_bound + kItemTarget) could not hold it is refused at creation; the kernels never see one.
+static int host_bin_rows(int lo, int hi, int N, int blog, int nb, int* pieces) {
+    *pieces = 1;
+    if (hi - lo >= N) return nb;
+    if (lo >= 0 && hi <= N) return ((hi - 1) >> blog) - (lo >> blog) + 1;
+    const int lo2 = lo < 0 ? lo + N : lo, hi2 = lo < 0 ? hi : hi - N;
+    const int a_first = lo2 >> blog, b_last = (hi2 - 1) >> blog;
+    if (b_last + 1 >= a_first) return nb;
+    *pieces = 2;
+    return (nb - a_first) + (b_last + 1);
+}
+long exact_tile_runs(bool spreading, int D, int M, const int64_t* Nover, int bin_log2, const TileShapeHost& t) {
+    long runs = 1;
+    for (int d = 0; d < D; ++d) {
+        const int N = (int)Nover[d], nb = (N + (1 << bin_log2) - 1) >> bin_log2;
+        int worst = 0;
+        for (int k = 0; k < t.nt[d]; ++k) {
+            const int org = k * t.n[d], neff = std::min(t.n[d], N - org);
+            int pieces = 1, rows;
+            if (spreading) rows = host_bin_rows(org - M, org + neff + M - 1, N, bin_log2, nb, &pieces);
+            else rows = ((org + neff - 1) >> bin_log2) - (org >> bin_log2) + 1;
+            // dimension 1 contributes its pieces (one run per piece), the others their bin rows
+            worst = std::max(worst, d == 0 ? (spreading ? pieces : 1) : rows);
+        }
+        runs *= worst;
+    }
+    return runs;
+}
+
 // exact LDS bytes of a candidate tile (tile + work-item table + window strips); -1: too many work items
 static int64_t candidate_lds(bool spreading, int D, int M, int ncomp, int real_bytes, int nwaves, int64_t elems,
                              const int n[3], const int64_t* Nover, int bin_log2) {
@@ -314,6 +346,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
             if (bn[0] == 0) return false;
         }
         fill_shape(g.sp, D, M, ncomp, real_bytes, Nover, bn, false, bin_log2);
+        if (exact_tile_runs(true, D, M, Nover, bin_log2, g.sp) > g.sp.max_items) return false;
     }
     // --- interpolation tile: padded, grid precision; cost = halo amplification of the tile load ---
     {
@@ -358,6 +391,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
             if (bn[0] == 0) return false;
         }
         fill_shape(g.ip, D, M, ncomp, real_bytes, Nover, bn, true, bin_log2);
+        if (exact_tile_runs(false, D, M, Nover, bin_log2, g.ip) > g.ip.max_items) return false;
     }
     return true;
 }

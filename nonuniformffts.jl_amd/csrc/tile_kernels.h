@@ -596,7 +596,11 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
     }
     const int R2 = seg[1].total(), R3 = seg[2].total();
     const int nruns = R2 * R3 * seg[0].n;
-    if (nruns > ts.max_items) __builtin_trap();     // the host sizes the table from the same arithmetic (tile_items_bound)
+    // (cannot exceed the table: plan creation replays this arithmetic for every tile position, exact_tile_runs in
+    // plan_math.cpp, and refuses the plan otherwise — a device trap would take the caller's whole HIP context down)
+#if defined(NUFFT_DEBUG_TRAPS)
+    if (nruns > ts.max_items) __builtin_trap();
+#endif
     for (int item = tid; item < nruns; item += nthreads) {
         const int sg = item % seg[0].n;
         const int r2 = (item / seg[0].n) % R2;
@@ -869,7 +873,9 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
         bcnt[d] = d < D ? ((org[d] + neff[d] - 1) >> g.blog[d]) - blo[d] + 1 : 1;
     }
     const int nruns = bcnt[1] * bcnt[2];
-    if (nruns > ts.max_items) __builtin_trap();     // sized by the host from the same arithmetic (tile_items_bound)
+#if defined(NUFFT_DEBUG_TRAPS)
+    if (nruns > ts.max_items) __builtin_trap();     // checked at plan creation (exact_tile_runs, plan_math.cpp)
+#endif
 
     const LdsLayout lay = lds_layout(ts.elems, (int)sizeof(T), (int)sizeof(T), D, M, NC, nwaves, ts.max_items);
     T* tile = reinterpret_cast<T*>(smem);

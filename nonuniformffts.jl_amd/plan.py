@@ -313,6 +313,13 @@ class PlanNUFFT:
         _check(lib.nufft_plan_info(self._handle, C.byref(self._info)))
         return self._info
 
+    def spread_engine_used(self) -> str:
+        """Engine that serves the point set of the last set_points: "lds_tiles" or "mfma_patches" (plans of the
+        patch engine decide per point set on the device; this reads the decision back and synchronises)."""
+        out = C.c_int(0)
+        _check(lib.nufft_spread_engine_used(self._handle, C.byref(out), self._stream()))
+        return {1: "lds_tiles", 2: "mfma_patches"}[out.value]
+
     @property
     def size(self) -> Tuple[int, ...]:
         """size(p): dims of the uniform arrays in Julia order (N1÷2+1, N2, ...) for real Z."""

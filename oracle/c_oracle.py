@@ -79,6 +79,8 @@ def _ptrs(arrs):
 def _common(plan: O.OraclePlan):
     assert np.dtype(plan.dtype) == np.float64, "the C oracle is Float64 only"
     num_threads()                                   # applies the CPU quota once
+    # Float32 points of a plan with coord_dtype = float32 are located with Float32 arithmetic (see nufft_oracle.c)
+    lib().oracle_set_coord_f32(1 if (plan.coord_dtype is not None and np.dtype(plan.coord_dtype) == np.float32) else 0)
     D = plan.ndim
     N = (C.c_int64 * 3)(*(list(plan.Nover) + [1] * (3 - D)))
     coefs = np.ascontiguousarray(np.stack([plan.coefs[d] for d in range(D)]))   # [D][npoly][2M]

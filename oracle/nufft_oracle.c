@@ -42,8 +42,22 @@ typedef struct {
     double beta[3];
 } oracle_geom;
 
+/* Coordinate arithmetic of a Float32 plan (oracle_set_coord_f32(1); OraclePlan.coord_dtype in nufft_oracle.py): the
+ * points (exactly representable Float32 numbers) are folded and located with Float32 operations, as the reference does
+ * for T = Float32 (src/blocking/blocking.jl:12-21, src/Kernels/Kernels.jl:121-126 evaluated in T); windows and sums stay
+ * Float64. */
+static int g_coord_f32 = 0;
+void oracle_set_coord_f32(int on) { g_coord_f32 = on; }
+
 /* to_unit_cell_cpu, src/blocking/blocking.jl:12-21 */
 static inline double fold(double x) {
+    if (g_coord_f32) {
+        volatile float xf = (float)x;
+        const float L = (float)TWO_PI;
+        while (xf < 0) xf += L;
+        while (xf >= L) xf -= L;
+        return (double)xf;
+    }
     while (x < 0) x += TWO_PI;
     while (x >= TWO_PI) x -= TWO_PI;
     return x;
@@ -51,6 +65,15 @@ static inline double fold(double x) {
 
 /* point_to_cell (0-based), src/Kernels/Kernels.jl:121-126 */
 static inline int64_t cell_of(double xf, int64_t N, double* r) {
+    if (g_coord_f32) {
+        volatile float q = (float)xf / (float)TWO_PI;
+        volatile float rf = q * (float)N;
+        int64_t i = (int64_t)rf;
+        if (i >= N) i = N - 1;
+        volatile float X = rf - (float)i;          /* the cell fraction is formed in Float32 too */
+        *r = (double)i + (double)X;
+        return i;
+    }
     *r = (xf / TWO_PI) * (double)N;
     int64_t i = (int64_t)(*r);
     if (i >= N) i = N - 1;

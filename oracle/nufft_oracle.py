@@ -127,22 +127,33 @@ def bkb_function(y, beta):
     return ratio * (beta / math.pi)
 
 
-def piecewise_poly_coefficients(f, M: int, npoly: int) -> np.ndarray:
+def piecewise_poly_coefficients(f, M: int, npoly: int, solve_dtype=np.float64) -> np.ndarray:
     """Chebyshev-node fit of ``f`` on each of the 2M sub-intervals of [-1, 1], ordered from
     right (+1) to left (-1) (src/Kernels/piecewise_polynomial.jl:23-74).
 
     Returns ``cs`` of shape (npoly, 2M): ``cs[k, j]`` multiplies x^k on sub-interval j
     (the "transposed" tuple-of-tuples layout of :43-47,73).
+
+    ``solve_dtype``: the reference builds and LU-solves the Vandermonde system in T = real(Z) (`Matrix{T}`, :52-57).  The
+    library and the default here solve in Float64 and round the coefficients to T afterwards — identical for Float64
+    plans; for Float32 plans the Float32 solve (solve_dtype = float32: LAPACK sgesv, the routine family `lu!` / `ldiv!`
+    call) loses 3-4 digits to the conditioning of the system, the Float64 solve does not.  DESIGN.md section 2 states the
+    deviation; tests/test_oracle_kernels.py pins its size.
     """
     L = 2 * M
+    st = np.dtype(solve_dtype).type
     i = np.arange(1, npoly + 1, dtype=np.float64)
-    xs = np.cos(np.pi * (i - 0.5) / npoly)            # :61  cospi((i - 1/2) / N)
-    A = np.vander(xs, npoly, increasing=True)         # :33-38  A[i, j] = xs[i]^(j-1)
+    xs = np.cos(np.pi * (i - 0.5).astype(solve_dtype).astype(np.float64) / npoly).astype(solve_dtype)   # :61  cospi(T(i - 1/2) / N)
+    A = np.empty((npoly, npoly), dtype=solve_dtype)   # :33-38  A[i, j] = xs[i]^(j-1), powers by repeated products in T
+    pw = np.ones(npoly, dtype=solve_dtype)
+    for jj in range(npoly):
+        A[:, jj] = pw
+        pw = (pw * xs).astype(solve_dtype)
     cs = np.empty((npoly, L), dtype=np.float64)
     delta = 1.0 / L                                   # :66
     for j in range(1, L + 1):
         h = 1.0 - 2.0 * (j - 0.5) / L                 # :65
-        ys = f(h + xs * delta)                        # :67-70
+        ys = np.asarray(f(h + xs.astype(np.float64) * delta)).astype(solve_dtype)   # :67-70 (h, δ are Float64 there too)
         cs[:, j - 1] = np.linalg.solve(A, ys)         # :39-40
     return cs
 
@@ -316,6 +327,11 @@ class OraclePlan:
     kernel: int = KERNEL_BKB
     kernel_param: Optional[float] = None
     point_transform: int = POINT_TRANSFORM_IDENTITY
+    # Precision of the coordinate arithmetic (fold, cell index, cell fraction) when it differs from `dtype`: a Float64
+    # plan with coord_dtype = float32 takes Float32 points, locates them exactly as a Float32 plan of the reference does
+    # (src/blocking/blocking.jl:26-33, src/Kernels/Kernels.jl:121-126 evaluated in T) and evaluates windows, sums and
+    # FFTs in Float64 — the expectation for Float32 plans whose un-normalised window overflows Float32 (3-D, M >= 7).
+    coord_dtype: Optional[type] = None
     # derived
     Nover: Tuple[int, ...] = field(init=False)
     ks: list = field(init=False)
@@ -329,7 +345,7 @@ class OraclePlan:
     def __post_init__(self):
         self.Ns = tuple(int(n) for n in self.Ns)
         D = len(self.Ns)
-        rdt = np.dtype(self.dtype)
+        rdt = np.dtype(self.coord_dtype or self.dtype)     # the plan parameters are numbers of type real(Z)
         # sigma is converted to real(Z) first (src/plan.jl:573-576)
         sigma_wanted = float(rdt.type(self.sigma))
         self.Nover = tuple(
@@ -439,6 +455,10 @@ def evaluate_window(plan: OraclePlan, d: int, x: np.ndarray):
     # out of bounds there.  Keep the point in the last cell with X = 1 (same window by continuity).
     i = np.minimum(i, plan.Nover[d] - 1)
     X = (r - i.astype(x.dtype)).astype(x.dtype)          # in [0, 1]
+    if np.dtype(plan.dtype) != x.dtype:                  # coord_dtype: located in Float32, evaluated in Float64
+        x = x.astype(plan.dtype)
+        X = X.astype(plan.dtype)
+        T = x.dtype.type
     if plan.kernel == KERNEL_BSPLINE:
         # src/Kernels/bspline.jl:99-119: x' = i - r (1-based i) = 1 - X; same recursion in both modes
         return i, bspline_evaluate_all((T(1) - X).astype(x.dtype), 2 * M).astype(x.dtype)
@@ -501,7 +521,7 @@ def set_points(plan: OraclePlan, xp: Sequence[np.ndarray]):
         raise ValueError(f"expected {plan.ndim}-dimensional points")
     n0 = len(xp[0])
     for x in xp:
-        if np.asarray(x).dtype != np.dtype(plan.dtype):
+        if np.asarray(x).dtype != np.dtype(plan.coord_dtype or plan.dtype):
             raise ValueError("input points must have the same accuracy as the created plan")
         if len(x) != n0:
             raise ValueError("input points must have the same length along all dimensions")
@@ -599,7 +619,45 @@ def _gather_index(plan: OraclePlan):
     return np.ix_(*[plan.index_map[d] for d in reversed(range(plan.ndim))])
 
 
-def exec_type1(plan: OraclePlan, vp, return_grid: bool = False):
+class NUFFTCallbacks:
+    """NUFFTCallbacks (src/plan.jl:146-164): `nonuniform(vs, n)` receives the tuple of the C values of point n
+    (0-based here) and returns the tuple that is spread (type 1, src/spreading/cpu_nonblocked.jl:57-62) or stored
+    (type 2, src/interpolation/cpu_nonblocked.jl:16-22); `uniform(ws, idx)` receives the tuple of the C deconvolved
+    (type 1: and normalised) coefficients of output index idx (0-based, dimension 1 first) and returns the tuple that is
+    written to the output (type 1, src/NonuniformFFTs.jl:372-379,394-401) or to the oversampled spectrum (type 2,
+    :437-445,460-467).  Defaults return their first argument (`default_callback`, src/plan.jl:164)."""
+
+    def __init__(self, nonuniform=None, uniform=None):
+        self.nonuniform = nonuniform
+        self.uniform = uniform
+
+
+def _apply_nonuniform(cb, vps, dtype):
+    """vs_new = callback(vs, i) for every point; results keep the element type (`oftype`, src/plan.jl:99-103)."""
+    if cb is None or cb.nonuniform is None:
+        return [np.asarray(v) for v in vps]
+    Np = len(vps[0])
+    out = [np.empty(Np, dtype=dtype) for _ in vps]
+    for i in range(Np):
+        new = cb.nonuniform(tuple(v[i] for v in vps), i)
+        for c in range(len(vps)):
+            out[c][i] = new[c]
+    return out
+
+
+def _apply_uniform(cb, ws, dtype):
+    """w_new = callback(ws, idx) for every output index; arrays have reversed axes (dimension 1 last)."""
+    if cb is None or cb.uniform is None:
+        return ws
+    out = [np.empty(w.shape, dtype=dtype) for w in ws]
+    for I in np.ndindex(ws[0].shape):
+        new = cb.uniform(tuple(w[I] for w in ws), tuple(reversed(I)))
+        for c in range(len(ws)):
+            out[c][I] = new[c]
+    return out
+
+
+def exec_type1(plan: OraclePlan, vp, return_grid: bool = False, callbacks=None):
     """exec_type1!: zero -> spread -> unnormalised forward FFT -> truncate + deconvolve + normalise
     (src/NonuniformFFTs.jl:148-189,197-211,350-385)."""
     single = not isinstance(vp, (list, tuple))
@@ -610,6 +668,7 @@ def exec_type1(plan: OraclePlan, vp, return_grid: bool = False):
     for v in vps:
         if len(v) != Np:
             raise ValueError("wrong length of data vector")
+    vps = _apply_nonuniform(callbacks, [np.asarray(v).astype(plan.vdtype) for v in vps], plan.vdtype)
     us = spread(plan, vps)
     norm = float(np.prod([TWO_PI / n for n in plan.Nover]))
     fac = norm / _deconv_factor(plan)
@@ -621,12 +680,13 @@ def exec_type1(plan: OraclePlan, vp, return_grid: bool = False):
             uh = np.fft.fftn(u.astype(np.complex128))
         w = uh[_gather_index(plan)] * fac
         outs.append(w.astype(plan.cdtype))
+    outs = _apply_uniform(callbacks, outs, plan.cdtype)
     if return_grid:
         return (outs[0] if single else outs), us
     return outs[0] if single else outs
 
 
-def exec_type2(plan: OraclePlan, uhat, return_grid: bool = False):
+def exec_type2(plan: OraclePlan, uhat, return_grid: bool = False, callbacks=None):
     """exec_type2!: zero-pad + deconvolve -> unnormalised backward FFT -> interpolate
     (src/NonuniformFFTs.jl:237-314,416-451)."""
     single = not isinstance(uhat, (list, tuple))
@@ -637,15 +697,19 @@ def exec_type2(plan: OraclePlan, uhat, return_grid: bool = False):
     fac = 1.0 / _deconv_factor(plan)
     grids = []
     for w in uhs:
-        w = np.asarray(w)
-        if w.shape != expected:
+        if np.asarray(w).shape != expected:
             raise ValueError(f"wrong dimensions of array (expected {plan.size})")
+    # deconvolve, then the uniform callback, then the scatter into the zero-padded spectrum (src/NonuniformFFTs.jl:437-447)
+    ws = [np.asarray(w).astype(np.complex128) * fac for w in uhs]
+    if callbacks is not None and callbacks.uniform is not None:
+        ws = _apply_uniform(callbacks, [w.astype(plan.cdtype) for w in ws], plan.cdtype)   # the callback sees values of type Z
+    for w in ws:
         if plan.is_real:
             shape = tuple(reversed((plan.Nover[0] // 2 + 1,) + plan.Nover[1:]))
         else:
             shape = tuple(reversed(plan.Nover))
         uh = np.zeros(shape, dtype=np.complex128)
-        uh[_gather_index(plan)] = w.astype(np.complex128) * fac
+        uh[_gather_index(plan)] = w.astype(np.complex128)
         ntot = int(np.prod(plan.Nover))
         if plan.is_real:
             # brfft: unnormalised c2r of length Nover[0] along dim 1
@@ -655,6 +719,7 @@ def exec_type2(plan: OraclePlan, uhat, return_grid: bool = False):
             u = (np.fft.ifftn(uh) * ntot).astype(plan.cdtype)
         grids.append(u)
     vs = interpolate(plan, grids)
+    vs = _apply_nonuniform(callbacks, vs, plan.vdtype)
     if return_grid:
         return (vs[0] if single else vs), grids
     return vs[0] if single else vs

@@ -265,3 +265,46 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
         num += float((out[j].to(torch.complex128) - exact).abs() ** 2)
         den += float(exact.abs() ** 2)
     assert np.sqrt(num / den) < 2e-4
+
+
+@pytest.mark.parametrize("Z,M,engine", [
+    (np.complex128, 4, "mfma_patches"), (np.float64, 6, "mfma_patches"), (np.complex64, 8, "mfma_patches"),
+    (np.float64, 4, "mfma_patches"), (np.complex64, 8, "lds_tiles"), (np.float32, 4, "mfma_patches"),
+])
+def test_dense_point_sets_match_c_oracle(Z, M, engine):
+    """Dense sets (oversampled 128^3 = 32^3 bins, Np = 2e6: 61 points per bin, every K-batch of the patch engine full and
+    every chunk of a run at capacity) against the C oracle — full rel-L2 over all output modes (type 1) and all points
+    (type 2), at the reference's bounds (test/pseudo_gpu.jl:159-171: 1e-7 Float64, 1e-5 Float32).  Float32 plans are
+    compared with the Float64 C oracle that locates the points in Float32 (coord_dtype), since the reference's
+    un-normalised Float32 window overflows at (3-D, M = 8)."""
+    from nufft_pkg import nufft
+    from oracle import nufft_oracle as O, c_oracle as CO
+    if not CO.available():
+        pytest.skip("C oracle not built")
+    Zt = np.dtype(Z)
+    is_real = Zt.kind == "f"
+    T = np.float32 if Zt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    n, Np = 64, 2_000_000
+    rng = np.random.default_rng(1000 + M)
+    xs = [(rng.random(Np) * O.TWO_PI).astype(T) for _ in range(3)]
+    v = (rng.standard_normal(Np) if is_real else rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Zt)
+    plan = nufft.PlanNUFFT(Zt, (n, n, n), m=M, sigma=2.0, kernel_evalmode=nufft.FastApproximation(), spread_method=engine,
+                           backend=nufft.ROCBackend(0))
+    oplan = O.OraclePlan((n, n, n), is_real=is_real, dtype=np.float64, coord_dtype=(np.float32 if T == np.float32 else None),
+                         M=M, sigma=2.0, evalmode=O.FAST_APPROXIMATION)
+    nufft.set_points(plan, tuple(torch.from_numpy(x).cuda() for x in xs))
+    assert plan.spread_engine_used() == engine
+    O.set_points(oplan, xs)
+    wide = np.float64 if is_real else np.complex128
+    u = torch.empty(plan.shape, dtype=plan.eltype, device="cuda")
+    nufft.exec_type1(u, plan, torch.from_numpy(v).cuda())
+    ref = CO.exec_type1(oplan, v.astype(wide))
+    tol = 1e-5 if T == np.float32 else 1e-7
+    e1 = float(np.linalg.norm(u.cpu().numpy().astype(np.complex128) - ref) / np.linalg.norm(ref))
+    assert e1 < tol, e1
+    w = (rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)).astype(np.complex64 if T == np.float32 else np.complex128)
+    out = torch.empty(Np, dtype=plan.Z, device="cuda")
+    nufft.exec_type2(out, plan, torch.from_numpy(w).cuda())
+    ref2 = CO.exec_type2(oplan, w.astype(np.complex128))
+    e2 = float(np.linalg.norm(out.cpu().numpy().astype(wide) - ref2) / np.linalg.norm(ref2))
+    assert e2 < tol, e2

@@ -121,3 +121,32 @@ def test_kernel_fourier_transforms_against_quadrature():
     xs = np.linspace(-12 * math.sqrt(tau), 12 * math.sqrt(tau), 400001)
     quad = np.array([np.trapezoid(np.exp(-xs * xs / tau) * np.cos(k * xs), xs) for k in ks])
     assert np.allclose(quad, O.gaussian_fourier(ks, tau), rtol=1e-9)
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 6, 8, 10])
+def test_float32_coefficients_float64_solve_vs_reference_float32_solve(M):
+    """Stated deviation: the reference solves the Chebyshev-node Vandermonde system of the piecewise
+    polynomial in T = real(Z) (`Matrix{T}`, src/Kernels/piecewise_polynomial.jl:50-60); the library (and the oracle's
+    default) solve in Float64 and round the coefficients to Float32.  Pin the size of the difference: window values from
+    the two coefficient sets agree to 3e-7 of the window maximum (the Float32 solve is the *less* accurate of the two
+    against the exactly solved polynomial), i.e. far inside the reference's Float32 GPU-vs-CPU bound of 1e-5
+    (test/pseudo_gpu.jl:159-171)."""
+    beta = float(np.float32(O.bkb_beta(M, 2.0)))
+    f = lambda y: O.bkb_function(y, beta)                       # noqa: E731
+    c64 = O.piecewise_poly_coefficients(f, M, M + 4)
+    c32 = O.piecewise_poly_coefficients(f, M, M + 4, solve_dtype=np.float32)
+    X = np.linspace(0.0, 1.0, 257)
+    xx = 2 * X - 1
+
+    def horner(cs):
+        v = np.broadcast_to(cs[-1][None, :], (len(X), 2 * M)).copy()
+        for k in range(cs.shape[0] - 2, -1, -1):
+            v = xx[:, None] * v + cs[k][None, :]
+        return v
+
+    exact = horner(c64)
+    lib = horner(c64.astype(np.float32).astype(np.float64))     # what the library loads into Float32 plans
+    ref = horner(c32.astype(np.float32).astype(np.float64))     # what the reference computes
+    peak = np.abs(exact).max()
+    assert np.abs(lib - ref).max() / peak < 3e-7
+    assert np.abs(lib - exact).max() <= np.abs(ref - exact).max() * 1.5 + 1e-8 * peak
