@@ -111,7 +111,9 @@ typedef struct nufft_params {
 /* What show(::PlanNUFFT) prints (src/plan.jl:362-392) plus sizes a caller needs. */
 /* Spreading engines (nufft_info.spread_method; nufft_params.spread_method selects, 0 = automatic):
  *   LDS tiles    — output-driven LDS tile with native ds_add_f64 (every D, M, kernel, grid size)
- *   MFMA patches — register-resident patches accumulated by v_mfma_f64_4x4x4_4b (3-D grids of 4-cell bins) */
+ *   MFMA patches — register-resident patches accumulated by the matrix pipe (3-D grids of 4-cell bins):
+ *                  v_mfma_f64_4x4x4_4b with Float64 accumulators, or — ComplexF32 plans whose dimension 3 is a
+ *                  multiple of 8 cells — v_mfma_f32_16x16x4 with Float32 accumulators (nufft_info.patch_f32acc) */
 enum { NUFFT_SPREAD_AUTO = 0, NUFFT_SPREAD_LDS_TILES = 1, NUFFT_SPREAD_MFMA_PATCHES = 2 };
 
 typedef struct nufft_info {
@@ -136,6 +138,9 @@ typedef struct nufft_info {
     int32_t kernel;          /* NUFFT_KERNEL_*                                                     */
     int32_t spread_max_items, interp_max_items; /* capacity of the per-tile work-item tables (runs of sorted points) */
     int32_t spread_method;   /* NUFFT_SPREAD_LDS_TILES or NUFFT_SPREAD_MFMA_PATCHES (what nufft_spread launches)      */
+    int32_t patch_dims[2];   /* MFMA patches: cube columns (of 4 x 4 cells) a wave owns along dimensions 1, 2; 0 otherwise */
+    int32_t patch_f32acc;    /* MFMA patches: 1 = ComplexF32 on v_mfma_f32_16x16x4 with Float32 accumulators (the reference's
+                                accumulation type, src/spreading/gpu.jl:271-283), 0 = v_mfma_f64_4x4x4 with Float64 ones  */
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */

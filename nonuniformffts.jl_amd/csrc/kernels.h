@@ -98,8 +98,10 @@ struct PatchPlan {
     int lds_bytes;                      // dynamic LDS per workgroup
     int pby;                            // rows of cube columns per patch
     int occ;                            // waves per SIMD the kernel is compiled for
+    int f32acc;                         // ComplexF32 on the FP32 matrix pipe with Float32 accumulators (patch32_kernels.h)
 };
-PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other);
+// allow_f32acc: ComplexF32 plans may take the FP32-matrix-pipe kernel where the grid allows it (octets along dimension 3)
+PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc = true);
 // set_points: decides on the device which engine serves this point set (balance.hip); choice = uint32[4], zeroed once
 hipError_t launch_patch_choice(const Geom& g, const PatchPlan& pp, int pby, const uint32_t* offsets, int64_t np, int wave_slots,
                                uint32_t* choice, uint32_t* slots_in_use, hipStream_t stream);

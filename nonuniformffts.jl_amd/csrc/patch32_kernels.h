@@ -1,0 +1,454 @@
+// Type-1 spreading of ComplexF32 plans on register-resident patches accumulated by the FP32 matrix pipe (gfx950, wave64).
+//
+// The Float32 sibling of patch_kernels.h (same decomposition: a wave owns a patch of cube columns and marches along
+// dimension 3 through a segment, output-driven, no atomics, no zero fill, every cell written once) with the sums
+// accumulated in Float32 — the reference accumulates in T = real(Z) (src/spreading/gpu.jl:271-283: the LDS tile has
+// element type Z; :381-403 adds it to the Float32 grid), so this is the reference's arithmetic, not a precision trade.
+//
+//     G[(x, y), (z, c)] += sum_p  A[(x, y), p] * B[p, (z, c)],    A = w1_p[x] * w2_p[y],   B = v_p[c] * w3_p[z]
+//
+// on v_mfma_f32_16x16x4_f32: i = (x, y) of a 4 x 4 cube face, j = (z, component) of an OCTET of 8 planes, k = 4 points.
+// One instruction forms 16 x 16 x 4 = 1024 products in 36 cycles (measured, scripts/microbench8.hip) — 2x the rate of
+// v_mfma_f64_4x4x4_4b (256 in 18) — and its 256 results cost 4 accumulator registers instead of 8, so the same register
+// file holds a patch of twice the area: PBX x PBY = 4 x 7 cube columns x 3 octets at M = 8 (4 x 3 x 5 cubes in Float64),
+// i.e. 3.1 instead of 4.7 visits per point, each of which re-evaluates the 3 x 2M window values and sets the operands up.
+//
+// Layouts (measured by scripts/microbench8.hip): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, D[4 (l / 16) + r][l % 16]
+// in register r of lane l.  With i = x + 4 y: lane l holds the cells x = 0..3 (registers), y = l / 16, z = (l % 16) / 2,
+// component l % 2 of its cube column and octet — two neighbouring lanes exchange two registers and store 32 contiguous
+// bytes (four complex cells); the four cube columns of a patch row complete 128-byte lines in L2.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "device_common.h"
+#include "nufft_mi355x.h"
+#include "patch_kernels.h"
+#include "tile_kernels.h"
+
+namespace nufft {
+
+// Accumulator registers of a patch, of the 256 + 256 a wave has at one wave per SIMD: in the accumulation registers
+// (AGPRs) — not all 256: the register allocator needs slack there, or it parks accumulators in vector registers and moves
+// them around the inline-assembly matrix instructions, which is a read-after-issue hazard (scripts/lint_patch32_isa.py
+// fails the build on it) — and in vector registers next to the working set.
+#ifndef NUFFT_PATCH32_AGPRS
+#define NUFFT_PATCH32_AGPRS 224
+#endif
+#ifndef NUFFT_PATCH32_VGPRS
+#define NUFFT_PATCH32_VGPRS 96
+#endif
+
+template <int M>
+struct Patch32Cfg {
+    static constexpr int L = 2 * M;
+    static constexpr int CLO = floor_div4(1 - M);      // cubes a stencil reaches relative to the bin of its point
+    static constexpr int CHI = floor_div4(3 + M);
+    static constexpr int NCB = CHI - CLO + 1;
+    static constexpr int NOB = NCB / 2 + 1;            // octets that cover NCB consecutive cube layers, whatever their parity
+    static constexpr int PBX = 4;
+    static constexpr int NCA_MAX = NUFFT_PATCH32_AGPRS / (4 * NOB), NCV_MAX = NUFFT_PATCH32_VGPRS / (4 * NOB);
+    static constexpr int rows() {
+        int r = (NCA_MAX + NCV_MAX) / PBX;
+        return r < 1 ? 1 : (r > 8 ? 8 : r);
+    }
+    static constexpr int PBY = rows();
+    static constexpr int NRB = PBY + NCB - 1;           // rows of bins visited per bin layer
+    // zeros in front of / behind the 2M window values of a staged row: dimensions 1 and 2 are read per cube ...
+    static constexpr int PADB = 4 - M - 4 * CLO;
+    static constexpr int PADA = 4 * CHI + 3 - M;
+    static constexpr int LW = PADB + L + PADA;
+    // ... dimension 3 per octet, whose first cube may be the one below the stencil's first cube
+    static constexpr int PADBZ = PADB + 4;
+    static constexpr int TMAXZ = 4 * CLO + M - 1 + 8 * NOB - 1;        // largest window index an octet read can reach
+    static constexpr int PADAZ = TMAXZ - (L - 1) > 0 ? TMAXZ - (L - 1) : 0;
+    static constexpr int LWZ = PADBZ + L + PADAZ;
+    static constexpr int G = next_pow2(L);              // lanes per point during window evaluation
+    static constexpr int PPW = kWave / G;
+    static constexpr int WX = 0, WY = LW * 4, WZ = 2 * LW * 4;          // byte offsets of the three rows of a staged point
+    static constexpr int MT = round_up((2 * LW + LWZ) * 4, 16);         // meta data {-4 sx, offy, offz, rbx} + value (re, im)
+    // stride between staged points: an odd multiple of 8 banks, so that the rows the four points of a K-batch read at the
+    // same offsets fall on disjoint banks
+    static constexpr int pstride() {
+        int s = round_up(MT + 32, 32);
+        while ((s / 4) % 32 != 8 && (s / 4) % 32 != 24) s += 32;
+        return s;
+    }
+    static constexpr int PSTRIDE = pstride();
+    static constexpr int NPOLY = M + 4;
+    static constexpr int table_bytes() { return round_up(3 * NPOLY * L * 4, 16); }
+    static constexpr int STAGE_PT = 16;                 // staged cell fractions (3 floats + pad)
+    // points per chunk: one wave per SIMD = one workgroup of four waves per CU with 160 KiB
+    static constexpr int chunk_points() {
+        const int budget = (160 * 1024 - 512 - table_bytes()) / kPatchWaves;
+        for (int ch = 64; ch > 16; ch -= 8)
+            if ((ch + 1) * PSTRIDE + ch * STAGE_PT + 32 <= budget) return ch;
+        return 16;
+    }
+    static constexpr int CH = chunk_points();
+    static constexpr int WBYTES = round_up((CH + 1) * PSTRIDE, 16);     // + the all-zero point
+    static constexpr int WAVE_BYTES = WBYTES + round_up(CH * STAGE_PT, 16);
+    static constexpr int lds_bytes() { return table_bytes() + kPatchWaves * WAVE_BYTES; }
+    // Accumulator placement, explicit (the matrix instructions are issued from inline assembly, see mfma_acc): the first
+    // NCA cube columns live in the 256 accumulation registers (AGPRs), the remaining NCV in vector registers next to the
+    // working set.  Left to the register allocator, the builtin form shuttled a fifth of the accumulators between the two
+    // files around every instruction (v_accvgpr_write x4, MFMA, s_nop 8, v_accvgpr_read x4) and spilled to scratch.
+    static constexpr int NCOL = PBX * PBY;
+    static constexpr int NCA = NCA_MAX < NCOL ? NCA_MAX : NCOL;
+    static constexpr int NCV = NCOL - NCA;
+    static_assert(PADB >= 1 && PADA >= 1 && PADBZ >= 1, "padding");
+    static_assert(NCV <= NCV_MAX, "vector-register accumulators leave room for the working set");
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// c += A B on v_mfma_f32_16x16x4_f32 with the accumulator pinned to one register file (AG: accumulation registers).
+// Inline assembly: the compiler's hazard recogniser does not see these as matrix instructions, so every other consumer of
+// an accumulator is ordered behind acc_fence() + acc_touch() (retire), the operand hazard is padded by hand (below), and
+// nothing but these statements touches the accumulators inside the K-batch loops (checked on the ISA by scripts/lint_patch32_isa.py at build time).  Two matrix
+// instructions on the same accumulator are a whole K-batch iteration (> 150 cycles) apart.
+template <bool AG>
+__device__ __forceinline__ void mfma_acc(v4f& c, float a, float b) {
+#if defined(NUFFT_PATCH32_BUILTIN)      // debugging: the compiler's own matrix instruction (and hazard handling)
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    return;
+#endif
+    // s_nop 1: a matrix instruction must not read a vector register in the two wait states after a VALU instruction
+    // wrote it (the compiler pads its own v_mfma the same way; found as stale A operands: w1 instead of w1 w2).  Behind
+    // another matrix instruction the no-op is hidden by the wait for the pipe.
+    if constexpr (AG) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// every matrix instruction issued so far has written its result (8 passes of 4 cycles + write-back)
+__device__ __forceinline__ void acc_fence() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+// orders the compiler's own reads / copies of c behind the preceding acc_fence()
+template <bool AG>
+__device__ __forceinline__ void acc_touch(v4f& c) {
+    if constexpr (AG) asm volatile("" : "+a"(c));
+    else asm volatile("" : "+v"(c));
+}
+
+// w[cx] = row[clamp(t + 4 cx, -1, L)] for Float32 rows (see lds_read_clamped in patch_kernels.h): t4 = 4 (lane x - sx)
+template <int L, int N, int... CX>
+__device__ __forceinline__ void lds_read_clamped32(float (&w)[N], uint32_t base, int t4, std::integer_sequence<int, CX...>) {
+    ((lds_read_imm<float, 16 * CX>(w[CX], base + (uint32_t)max(-4 - 16 * CX, min(t4, 4 * L - 16 * CX)))), ...);
+}
+
+template <int M, bool OTHERK>
+__global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(PatchArgs<float> a) {
+    using T = float;
+    using P = Patch32Cfg<M>;
+    constexpr int L = P::L, CLO = P::CLO, CHI = P::CHI, NCB = P::NCB, NOB = P::NOB, PBX = P::PBX, PBY = P::PBY, NRB = P::NRB;
+    constexpr int PADB = P::PADB, PADBZ = P::PADBZ, LW = P::LW, CH = P::CH, PSTRIDE = P::PSTRIDE;
+    constexpr int WX = P::WX, WY = P::WY, WZ = P::WZ, MT = P::MT;
+    using WE = WindowEval<T, 1, 3, M, P::G, OTHERK>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const Geom& g = a.t.g;
+    const PatchGeom& pg = a.pg;
+
+    if (a.enabled && *a.enabled == 0u) return;      // this point set goes to the LDS-tile kernel (patch_choice_kernel)
+    T* ctab = reinterpret_cast<T*>(smem);
+    for (int i = threadIdx.x; i < 3 * P::NPOLY * L; i += kPatchWaves * kWave) ctab[i] = a.t.coefs[i];
+    __syncthreads();
+
+    // ---- task: (patch column px, py; segment) ----
+    const int nwg = (int)gridDim.x;
+    const int wg = xcd_remap_chunked((int)blockIdx.x, nwg, a.t.xcd_chunk);
+    const int task = wg * kPatchWaves + wave;
+    if (task >= pg.ntasks) return;
+    const int comp_id = blockIdx.y;
+    const int px = task % pg.npx, py = (task / pg.npx) % pg.npy, seg = task / (pg.npx * pg.npy);
+    const int ncx = min(PBX, g.nb[0] - px * PBX), ncy = min(PBY, g.nb[1] - py * PBY);   // cube columns that exist
+    const int z0 = seg * pg.segl, z1 = min(z0 + pg.segl, g.nb[2]);                      // owned cube layers (both even)
+    const int X0 = px * PBX * 4;
+    const int bx0 = px * PBX, by0 = py * PBY;
+
+    unsigned char* wmem = smem + P::table_bytes() + wave * P::WAVE_BYTES;                // staged points
+    unsigned char* stage = wmem + P::WBYTES;
+    const uint32_t wbase = (uint32_t)(uintptr_t)wmem;
+    for (int o = lane * 16; o < P::WBYTES; o += kWave * 16) *reinterpret_cast<uint4*>(wmem + o) = make_uint4(0, 0, 0, 0);
+
+    // ---- accumulators: [ring slot = octet][cube row][cube column], 256 cells x 4 registers each ----
+    // (column = y * PBX + x; columns < NCA in accumulation registers, the others in vector registers)
+    constexpr int NCA = P::NCA, NCV = P::NCV;
+    v4f accA[NOB][NCA], accV[NOB][NCV > 0 ? NCV : 1];
+#pragma unroll
+    for (int s = 0; s < NOB; ++s) {
+#pragma unroll
+        for (int c = 0; c < NCA; ++c) accA[s][c] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < (NCV > 0 ? NCV : 1); ++c) accV[s][c] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int grp = lane / P::G, q = lane % P::G;                      // window evaluation roles (group mapping)
+    const int mk = lane >> 4, mb = (lane >> 2) & 3, mi = lane & 3;     // matrix roles of the A operand: point, y, x
+    const int bzl = (lane & 15) >> 1, bcl = lane & 1;                  // ... of the B operand: plane of the octet, component
+
+    const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.t.sorted);
+    const T* vs = a.vsorted[comp_id];
+    T* grid = a.t.grid[comp_id];
+
+    // ---- runs of the sorted array (as in spread_patch_kernel): lane t < 4 NRB holds bound (row t >> 2, piece, end) ----
+    const int gx0 = bx0 - CHI, gx1 = bx0 + ncx - 1 - CLO;
+    auto load_bounds = [&](int bz) __attribute__((always_inline)) -> uint32_t {
+        const int r = lane >> 2, piece = (lane >> 1) & 1, isend = lane & 1;
+        const int rb = r - CHI;
+        uint32_t val = 0;
+        if (lane < 4 * NRB && rb <= ncy - 1 - CLO) {
+            int lo, hi;
+            if (gx0 < 0) { lo = piece ? 0 : gx0 + g.nb[0]; hi = piece ? gx1 : g.nb[0] - 1; }
+            else if (gx1 >= g.nb[0]) { lo = piece ? 0 : gx0; hi = piece ? gx1 - g.nb[0] : g.nb[0] - 1; }
+            else { lo = gx0; hi = piece ? -1 : gx1; }
+            if (hi >= lo) {
+                int by = by0 + rb;
+                if (by < 0) by += g.nb[1];
+                if (by >= g.nb[1]) by -= g.nb[1];
+                int bzw = bz % g.nb[2];
+                if (bzw < 0) bzw += g.nb[2];
+                const int64_t row = ((int64_t)bzw * g.nb[1] + by) * g.nb[0];
+                val = a.t.offsets[row + (isend ? hi + 1 : lo)];
+            }
+        }
+        return val;
+    };
+    const int bz_first = z0 - CHI, bz_last = z1 - 1 - CLO;
+    struct Cursor { int bz, u; uint32_t p, pe; };
+    uint32_t bnd = load_bounds(bz_first);
+    uint32_t bnd_next = load_bounds(bz_first + 1);
+    auto advance = [&](Cursor& c) __attribute__((always_inline)) -> bool {
+        c.p += CH;
+        if (c.p < c.pe) return true;
+        for (;;) {
+            ++c.u;
+            if (c.u == 2 * NRB) {
+                c.u = 0;
+                ++c.bz;
+                if (c.bz > bz_last) return false;
+                bnd = bnd_next;
+                bnd_next = load_bounds(c.bz + 1);
+            }
+            c.p = (uint32_t)__builtin_amdgcn_readlane((int)bnd, 2 * c.u);
+            c.pe = (uint32_t)__builtin_amdgcn_readlane((int)bnd, 2 * c.u + 1);
+            if (c.p < c.pe) return true;
+        }
+    };
+
+    // ---- prefetch of a chunk: lane l < n holds record and value of point c.p + l ----
+    PointRec<T, 3> pf_rec;
+    float2 pf_v;
+    auto issue_prefetch = [&](const Cursor& c) __attribute__((always_inline)) {
+        const uint32_t n = min((uint32_t)CH, c.pe - c.p);
+        const uint32_t pp = c.p + min((uint32_t)lane, n - 1);
+        pf_rec = sorted[pp];
+        pf_v = reinterpret_cast<const float2*>(vs)[pp];
+    };
+    // lane l < CH = point l of the chunk: cell fraction staged for the window evaluation, meta data {-4 sx, byte offsets of
+    // the first reads of dimensions 2 and 3, bin along dimension 1} + value next to the point's window rows
+    auto commit_prefetch = [&](int bz) __attribute__((always_inline)) {
+        if (lane < CH) {
+            int cell[3];
+            float4 fr;
+            cell[0] = cell_of(pf_rec.r[0], g.Nover[0]); fr.x = pf_rec.r[0] - T(cell[0]);
+            cell[1] = cell_of(pf_rec.r[1], g.Nover[1]); fr.y = pf_rec.r[1] - T(cell[1]);
+            cell[2] = cell_of(pf_rec.r[2], g.Nover[2]); fr.z = pf_rec.r[2] - T(cell[2]);
+            fr.w = 0.f;
+            *reinterpret_cast<float4*>(stage + lane * P::STAGE_PT) = fr;
+            int sx = cell[0] - (M - 1) - X0;                           // stencil start relative to the patch, unwrapped
+            if (sx > g.Nover[0] / 2) sx -= g.Nover[0];
+            if (sx < -(g.Nover[0] / 2)) sx += g.Nover[0];
+            const int par = (bz + CLO) & 1;                            // first cube of the ring is the odd one of slot 0's octet
+            int4 m;
+            m.x = -4 * sx;
+            m.y = (PADB + M - 1 - (cell[1] & 3) + 4 * CLO) * 4;        // cube offset CLO, lane row 0
+            m.z = (PADBZ + M - 1 - (cell[2] & 3) + 4 * CLO - 4 * par) * 4;   // octet slot 0, plane 0
+            m.w = (sx + (M - 1)) >> 2;                                 // bin of the point relative to the patch
+            unsigned char* pw = wmem + lane * PSTRIDE + MT;
+            *reinterpret_cast<int4*>(pw) = m;
+            *reinterpret_cast<float2*>(pw + 16) = pf_v;
+        }
+    };
+
+    // ---- bin layer bz is finished: cube layer bz + CLO is complete; when it is the odd layer of its octet the octet
+    //      leaves (slot 0 of the ring) and the ring shifts ----
+    auto retire = [&](int bz) __attribute__((always_inline)) {
+        const int cz = bz + CLO;
+        if ((cz & 1) == 0) return;
+        acc_fence();
+#pragma unroll
+        for (int s = 0; s < NOB; ++s) {
+#pragma unroll
+            for (int c = 0; c < NCA; ++c) acc_touch<true>(accA[s][c]);
+#pragma unroll
+            for (int c = 0; c < NCV; ++c) acc_touch<false>(accV[s][c]);
+        }
+        if (cz >= z0 && cz < z1) {
+            const int64_t gz = (int64_t)(cz - 1) * 4 + bzl;           // plane of this lane
+            const int yl = lane >> 4;
+#pragma unroll
+            for (int y = 0; y < PBY; ++y) {
+                if (y < ncy) {
+                    const int64_t rowbase = ((gz * g.Nover[1] + (int64_t)(by0 + y) * 4 + yl) * g.Nover[0] + X0) * 2;
+#pragma unroll
+                    for (int x = 0; x < PBX; ++x) {
+                        if (x < ncx) {
+                            const int col = y * PBX + x;
+                            const v4f v = col < NCA ? accA[0][col < NCA ? col : 0] : accV[0][col >= NCA ? col - NCA : 0];
+                            // lane pair (component 0, 1): exchange two registers, then each stores two complex cells
+                            const float s0 = bcl ? v[0] : v[2], s1 = bcl ? v[1] : v[3];
+                            const float t0 = dpp_move<0xB1>(s0), t1 = dpp_move<0xB1>(s1);
+                            const float4 out = bcl ? make_float4(t0, v[2], t1, v[3]) : make_float4(v[0], t0, v[1], t1);
+                            *reinterpret_cast<float4*>(grid + rowbase + (4 * x + 2 * bcl) * 2) = out;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // one accumulator at a time through the vector registers
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCA; ++c) {
+#pragma unroll
+            for (int s = 0; s + 1 < NOB; ++s) accA[s][c] = accA[s + 1][c];
+            accA[NOB - 1][c] = v4f{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);                  // (the scheduler would otherwise gather all copies' temporaries)
+        }
+#pragma unroll
+        for (int c = 0; c < NCV; ++c) {
+#pragma unroll
+            for (int s = 0; s + 1 < NOB; ++s) accV[s][c] = accV[s + 1][c];
+            accV[NOB - 1][c] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- window evaluation of the n <= CH staged points of a chunk (group mapping) ----
+    auto eval_chunk = [&](int n) __attribute__((always_inline)) {
+        WE we;
+        we.init(a.t, q, ctab);
+        wave_lds_fence();
+#pragma unroll 1
+        for (int t0 = 0; t0 < n; t0 += P::PPW) {
+            const int pt = t0 + grp;
+            const float4 fr = *reinterpret_cast<const float4*>(stage + min(pt, n - 1) * P::STAGE_PT);
+            const T X[3] = {fr.x, fr.y, fr.z};
+            T v[WE::NSLOT];
+            we.eval_regs(a.t, X, v);
+            unsigned char* pw = wmem + pt * PSTRIDE;
+            if (pt < n) {
+#pragma unroll
+                for (int sl = 0; sl < WE::NSLOT; ++sl)
+                    if (we.has[sl]) {
+                        const int off = we.dsel[sl] == 2 ? WZ + (PADBZ + we.jsel[sl]) * 4 : we.dsel[sl] * (LW * 4) + (PADB + we.jsel[sl]) * 4;
+                        *reinterpret_cast<float*>(pw + off) = v[sl];
+                    }
+            }
+        }
+        wave_lds_fence();
+    };
+
+    // ---- K-batches of four points (k = lane >> 4; the all-zero point pads the last one), software-pipelined as in
+    //      spread_patch_kernel: the LDS reads of batch i + 1 (operands) and i + 2 (meta data) fly while batch i's MFMAs issue
+    auto batches = [&](auto RBc, int n) __attribute__((always_inline)) {
+        constexpr int RB = decltype(RBc)::value - CHI;                 // relative bin row: cube rows RB + CLO .. RB + CHI
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i m;
+        float vsel;                                                    // component bcl of the point's value
+        float w3[NOB], w2[NCB], w1[PBX];
+        uint32_t cxmask = 0u;
+        const uint32_t vsel_off = (uint32_t)bcl * 4u;
+        auto issue_meta = [&](int b0) __attribute__((always_inline)) {
+            const int pidx = b0 + mk < n ? b0 + mk : CH;
+            const uint32_t ad = wbase + (uint32_t)(pidx * PSTRIDE + MT);
+            const uint32_t adv = ad + vsel_off;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(m) : "v"(ad));
+            asm volatile("ds_read_b32 %0, %1 offset:16" : "=v"(vsel) : "v"(adv));
+        };
+        float vcur = 0.f;
+        auto issue_ops = [&](int b0) __attribute__((always_inline)) {
+            const int pidx = b0 + mk < n ? b0 + mk : CH;
+            const uint32_t pb = wbase + (uint32_t)(pidx * PSTRIDE);
+            const int nvalid = max(1, min(4, n - b0));
+            {
+                const int lo = max(__builtin_amdgcn_readlane(m.w, 0) + CLO, 0);
+                const int hi = min(__builtin_amdgcn_readlane(m.w, 16 * (nvalid - 1)) + CHI, PBX - 1);
+                cxmask = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+            }
+            vcur = vsel;
+            lds_read_rows<float, NOB, 0, 32>(w3, pb + WZ + (uint32_t)m.z + (uint32_t)bzl * 4, std::make_integer_sequence<int, NOB>{});
+            lds_read_rows<float, NCB, 0, 16>(w2, pb + WY + (uint32_t)m.y + (uint32_t)mb * 4, std::make_integer_sequence<int, NCB>{});
+            const int t4 = mi * 4 + m.x;
+            lds_read_clamped32<L, PBX>(w1, pb + WX + PADB * 4, t4, std::make_integer_sequence<int, PBX>{});
+        };
+        auto wait_all = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(m), "+v"(vsel));
+#pragma unroll
+            for (int s = 0; s < NOB; ++s) asm volatile("" : "+v"(w3[s]));
+#pragma unroll
+            for (int o = 0; o < NCB; ++o) asm volatile("" : "+v"(w2[o]));
+#pragma unroll
+            for (int cx = 0; cx < PBX; ++cx) asm volatile("" : "+v"(w1[cx]));
+        };
+        issue_meta(0);
+        wait_all();
+        issue_ops(0);
+        issue_meta(4);
+        wait_all();
+#pragma unroll 1
+        for (int b0 = 0; b0 < n; b0 += 4) {
+            float A[NCB][PBX], B[NOB];
+#pragma unroll
+            for (int s = 0; s < NOB; ++s) B[s] = w3[s] * vcur;
+#pragma unroll
+            for (int o = 0; o < NCB; ++o)
+#pragma unroll
+                for (int cx = 0; cx < PBX; ++cx) A[o][cx] = (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? w1[cx] * w2[o] : 0.f;
+            const uint32_t mask = cxmask;
+            issue_ops(b0 + 4);
+            issue_meta(b0 + 8);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cx = 0; cx < PBX; ++cx) {
+                if (mask & (1u << cx)) {
+#pragma unroll
+                    for (int o = 0; o < NCB; ++o) {
+                        const int cy = RB + CLO + o;
+                        if (cy >= 0 && cy < PBY) {
+#pragma unroll
+                            for (int s = 0; s < NOB; ++s) {
+                                const int col = cy * PBX + cx;
+                                if (col < NCA) mfma_acc<true>(accA[s][col < NCA ? col : 0], A[o][cx], B[s]);
+                                else mfma_acc<false>(accV[s][col >= NCA ? col - NCA : 0], A[o][cx], B[s]);
+                            }
+                        }
+                    }
+                }
+            }
+            wait_all();
+        }
+    };
+
+    // ---- main loop over the chunks of the segment ----
+    Cursor nxt{bz_first, -1, 0u, 0u};
+    bool has = advance(nxt);
+    if (has) issue_prefetch(nxt);
+    int bz_done = bz_first;
+    while (has) {
+        const Cursor cur = nxt;
+        while (bz_done < cur.bz) { retire(bz_done); ++bz_done; }
+        wave_lds_fence();
+        commit_prefetch(cur.bz);
+        has = advance(nxt);
+        if (has) issue_prefetch(nxt);
+        const int n = (int)min((uint32_t)CH, cur.pe - cur.p);
+        eval_chunk(n);
+        dispatch_row<0, NRB>(cur.u >> 1, [&](auto Rc) __attribute__((always_inline)) { batches(Rc, n); });
+    }
+    while (bz_done <= bz_last) { retire(bz_done); ++bz_done; }
+}
+
+}  // namespace nufft

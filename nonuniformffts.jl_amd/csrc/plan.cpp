@@ -333,10 +333,12 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         int req = in->spread_method != NUFFT_SPREAD_AUTO ? in->spread_method : env_int("NUFFT_SPREAD_METHOD", NUFFT_SPREAD_AUTO);
         if (req < NUFFT_SPREAD_AUTO || req > NUFFT_SPREAD_MFMA_PATCHES) return fail(NUFFT_ERR_INVALID_ARG, "unknown spread_method");
         p->spread_method_req = req;
-        const PatchPlan pp = patch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
+        // NUFFT_PATCH_F32ACC=0: ComplexF32 plans keep the Float64-accumulating patch kernel (A/B runs)
+        const PatchPlan pp = patch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode),
+                                        env_int("NUFFT_PATCH_F32ACC", 1) != 0);
         p->patch.eligible = pp.eligible;
         p->patch.npx = pp.npx; p->patch.npy = pp.npy; p->patch.nseg = pp.nseg; p->patch.segl = pp.segl;
-        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes; p->patch.pby = pp.pby; p->patch.occ = pp.occ;
+        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes; p->patch.pby = pp.pby; p->patch.occ = pp.occ; p->patch.f32acc = pp.f32acc;
         if (req == NUFFT_SPREAD_MFMA_PATCHES && !pp.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = MFMA patches needs a 3-D grid of 4-cell bins with every oversampled "
                                                "axis a multiple of 4 and at least 2 (patch + stencil) bins long, and the default window evaluation");
@@ -889,6 +891,10 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->spread_max_items = p->tile.sp.max_items;
     o->interp_max_items = p->tile.ip.max_items;
     o->spread_method = p->spread_method;
+    const bool patches = p->spread_method == NUFFT_SPREAD_MFMA_PATCHES;
+    o->patch_dims[0] = patches ? 4 : 0;
+    o->patch_dims[1] = patches ? p->patch.pby : 0;
+    o->patch_f32acc = patches ? p->patch.f32acc : 0;
     return NUFFT_OK;
 }
 
@@ -987,7 +993,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         PatchPlan pp{};
         pp.eligible = true;
         pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
-        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby;
+        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc;
         const int slots = p->spread_method_req == NUFFT_SPREAD_MFMA_PATCHES ? 1 : p->wave_slots;    // explicit request: always the patches
         NUFFT_HIP(launch_patch_choice(s.g, pp, p->patch.pby, p->d_offsets, np, slots, p->d_patch_choice, p->bal.d_slots, stream));
     }
@@ -1051,7 +1057,7 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
         PatchPlan pp{};
         pp.eligible = true;
         pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
-        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby;
+        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc;
         NUFFT_HIP(launch_spread_patch(a, pp, p->d_vsorted, vstride, enabled, stream));
     }
     return NUFFT_OK;

@@ -165,6 +165,8 @@ const void* patch_kernel_f32c(int M, bool other, int* lds_bytes, int* pby);
 const void* patch_kernel_f64r(int M, bool other, int* lds_bytes, int* pby);
 const void* patch_kernel_f64c(int M, bool other, int* lds_bytes, int* pby);
 
+const void* patch32_kernel_f32c(int M, bool other, int* lds_bytes, int* pby);
+
 static const void* patch_kernel(int dtype, int is_complex, int M, bool other, int* lds_bytes, int* pby) {
     if (dtype == NUFFT_F32) return is_complex ? patch_kernel_f32c(M, other, lds_bytes, pby) : patch_kernel_f32r(M, other, lds_bytes, pby);
     return is_complex ? patch_kernel_f64c(M, other, lds_bytes, pby) : patch_kernel_f64r(M, other, lds_bytes, pby);
@@ -173,11 +175,18 @@ static const void* patch_kernel(int dtype, int is_complex, int M, bool other, in
 // Patch decomposition of a plan, or eligible = false: 3-D grids of 4-cell bins whose axes are multiples of the bin
 // edge and long enough that the bins a patch visits are distinct and a stencil cannot reach a patch from both
 // sides; default window evaluation without per-point weights (those use the LDS-tile kernel).
-PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other) {
+PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc) {
     PatchPlan pp{};
     int lds = 0, pby = 0;
     if (D != 3 || !patch_kernel(dtype, is_complex, M, other, &lds, &pby)) return pp;
     const int clo = floor_div4(1 - M), chi = floor_div4(3 + M), ncb = chi - clo + 1;
+    // ComplexF32: the FP32 matrix pipe with Float32 accumulators (octets of 8 planes: dimension 3 a multiple of 8), if its
+    // larger patch still fits the grid; the Float64-accumulating kernel otherwise
+    bool f32acc = false;
+    if (allow_f32acc && dtype == NUFFT_F32 && is_complex && g.Nover[2] % 8 == 0) {
+        int lds32 = 0, pby32 = 0;
+        if (patch32_kernel_f32c(M, other, &lds32, &pby32) && g.nb[1] >= 2 * (pby32 + ncb)) { f32acc = true; lds = lds32; pby = pby32; }
+    }
     const int pb[3] = {4, pby, 1};
     for (int d = 0; d < 3; ++d) {
         if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return pp;
@@ -194,11 +203,13 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
     if (nseg > max_seg) nseg = max_seg;
     if (nseg < 1) nseg = 1;
     pp.segl = (g.nb[2] + nseg - 1) / nseg;
+    if (f32acc) pp.segl += pp.segl & 1;               // whole octets per segment
     pp.nseg = (g.nb[2] + pp.segl - 1) / pp.segl;
     pp.ntasks = cols * pp.nseg;
     pp.lds_bytes = lds;
     pp.pby = pby;
-    pp.occ = patch_occupancy(is_complex ? 2 : 1, M);
+    pp.occ = f32acc ? 1 : patch_occupancy(is_complex ? 2 : 1, M);
+    pp.f32acc = f32acc ? 1 : 0;
     pp.eligible = true;
     return pp;
 }
@@ -207,14 +218,18 @@ hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other) {
     int lds = 0, pby = 0;
     const void* fn = patch_kernel(dtype, is_complex, M, other, &lds, &pby);
     if (!fn) return hipErrorInvalidValue;
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    if (dtype == NUFFT_F32 && is_complex && (fn = patch32_kernel_f32c(M, other, &lds, &pby)))
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e;
 }
 
 template <typename T>
 static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
                                  const uint32_t* enabled, hipStream_t stream) {
     int lds = 0, pby = 0;
-    const void* fn = patch_kernel(a.dtype, a.is_complex, a.M, false, &lds, &pby);
+    const void* fn = pp.f32acc ? patch32_kernel_f32c(a.M, false, &lds, &pby) : patch_kernel(a.dtype, a.is_complex, a.M, false, &lds, &pby);
     if (!fn) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;

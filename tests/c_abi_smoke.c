@@ -123,8 +123,9 @@ int main(int argc, char** argv) {
         den += re * re + im * im;
     }
     const double e1 = sqrt(num / den), ceil_m4 = 6.0 * pow(10.0, -1.9 * M);
-    /* type 2 of the computed spectrum at every 50th point: v_j = Σ_k h(k1) Re(û(k) exp(i k·x_j)), h = 1 at k1 = 0 (and
-     * at the Nyquist mode of an even N1), 2 otherwise (Hermitian symmetry, test/accuracy.jl:184-186) */
+    /* type 2 of the computed spectrum at every 50th point: v_j = Σ_k h(k1) Re(û(k) exp(i k·x_j)), h = 1 at k1 = 0 and 2
+     * otherwise — also at k1 = N1/2, an ordinary mode of the oversampled c2r transform (test/accuracy.jl:184-186:
+     * factor = ifelse(iszero(k), 1, 2)) */
     num = den = 0;
     for (int64_t j = 0; j < Np; j += 50) {
         double s = 0;
@@ -132,7 +133,7 @@ int main(int argc, char** argv) {
             const int64_t i1 = idx % K1, i2 = (idx / K1) % K2, i3 = idx / (K1 * K2);
             const double k1 = (double)i1, k2 = (double)(i2 < (K2 + 1) / 2 ? i2 : i2 - K2), k3 = (double)(i3 < (K3 + 1) / 2 ? i3 : i3 - K3);
             const double ph = k1 * x[0][j] + k2 * x[1][j] + k3 * x[2][j];
-            const double h = (i1 == 0 || (N[0] % 2 == 0 && i1 == N[0] / 2)) ? 1.0 : 2.0;
+            const double h = i1 == 0 ? 1.0 : 2.0;
             s += h * (u[2 * idx] * cos(ph) - u[2 * idx + 1] * sin(ph));
         }
         num += (w[j] - s) * (w[j] - s);

@@ -380,13 +380,28 @@ def test_both_spreading_engines_match_oracle(engine, Z, dims, M, sigma, evalmode
 
 
 @pytest.mark.parametrize("M", range(2, 11))
-@pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
-def test_patch_engine_every_instantiation(Z, M):
-    """Every (element type, M) instantiation of the patch kernel against the oracle (type 1; ADVICE round 2: only 15 of
-    the 36 were exercised).  96^3 oversampled grid = 24 bins per axis: partial last patch rows for PBY = 3, 4."""
+@pytest.mark.parametrize("Z", [np.float32, np.complex64, "complex64/f64acc", np.float64, np.complex128])
+def test_patch_engine_every_instantiation(Z, M, monkeypatch):
+    """Every (element type, M) instantiation of the patch kernels against the oracle (type 1; ADVICE round 2: only 15 of
+    the 36 were exercised).  96^3 oversampled grid = 24 bins per axis: partial last patch rows.  ComplexF32 has two
+    kernels: Float32 accumulators on v_mfma_f32_16x16x4 (the default where dimension 3 is a multiple of 8 cells) and
+    Float64 accumulators on v_mfma_f64_4x4x4 (NUFFT_PATCH_F32ACC=0 here; other grids in ENGINE_CASES)."""
+    f32acc = None
+    if isinstance(Z, str):
+        Z, f32acc = np.complex64, 0
+        monkeypatch.setenv("NUFFT_PATCH_F32ACC", "0")
+    elif np.dtype(Z) == np.complex64:
+        f32acc = 1
+    if np.dtype(Z) == np.complex128 and M == 10:
+        # the LDS-tile engines of this plan need 2-cell bins (tile + work-item table in 160 KiB); the patches serve 4-cell bins
+        with pytest.raises(ValueError):
+            _make_case(Z, (48, 48, 48), M, 2.0, O.FAST_APPROXIMATION, 1, 1500, seed=11 + M, spread_method="mfma_patches")
+        return
     nufft, plan, oplan, xs, vs = _make_case(Z, (48, 48, 48), M, 2.0, O.FAST_APPROXIMATION, 1, 1500, seed=11 + M,
                                             spread_method="mfma_patches")
     assert plan.info().spread_method == 2
+    if f32acc is not None:
+        assert plan.info().patch_f32acc == f32acc
     dev = plan.device
     nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
     O.set_points(oplan, xs)
