@@ -325,18 +325,16 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
         }
     };
 
-    // ---- window evaluation of the n <= CH staged points of a chunk (group mapping) ----
+    // ---- window evaluation of the n <= CH staged points of a chunk (group mapping), two passes of PPW points at a time:
+    //      at one wave per SIMD nothing else hides the latency of a pass (LDS read -> Horner chain -> LDS writes), and the
+    //      polynomial runs both passes' chains as the two halves of v_pk_fma_f32 ----
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const bool poly_eval = a.t.evalmode != NUFFT_EVAL_DIRECT;
     auto eval_chunk = [&](int n) __attribute__((always_inline)) {
         WE we;
         we.init(a.t, q, ctab);
         wave_lds_fence();
-#pragma unroll 1
-        for (int t0 = 0; t0 < n; t0 += P::PPW) {
-            const int pt = t0 + grp;
-            const float4 fr = *reinterpret_cast<const float4*>(stage + min(pt, n - 1) * P::STAGE_PT);
-            const T X[3] = {fr.x, fr.y, fr.z};
-            T v[WE::NSLOT];
-            we.eval_regs(a.t, X, v);
+        auto store = [&](int pt, const T (&v)[WE::NSLOT]) __attribute__((always_inline)) {
             unsigned char* pw = wmem + pt * PSTRIDE;
             if (pt < n) {
 #pragma unroll
@@ -346,6 +344,37 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
                         *reinterpret_cast<float*>(pw + off) = v[sl];
                     }
             }
+        };
+#pragma unroll 1
+        for (int t0 = 0; t0 < n; t0 += 2 * P::PPW) {
+            const int ptA = t0 + grp, ptB = ptA + P::PPW;
+            const float4 frA = *reinterpret_cast<const float4*>(stage + min(ptA, n - 1) * P::STAGE_PT);
+            const float4 frB = *reinterpret_cast<const float4*>(stage + min(ptB, n - 1) * P::STAGE_PT);
+            T vA[WE::NSLOT], vB[WE::NSLOT];
+            if (!OTHERK && poly_eval) {
+                // Horner (src/Kernels/piecewise_polynomial.jl:84-92) for both points at once: same operations, same order
+                const v2f x0 = {2.f * frA.x - 1.f, 2.f * frB.x - 1.f}, x1 = {2.f * frA.y - 1.f, 2.f * frB.y - 1.f},
+                          x2 = {2.f * frA.z - 1.f, 2.f * frB.z - 1.f};
+                // (the NSLOT independent chains advance together: a dependent v_pk_fma_f32 costs an extra wait state)
+                v2f xx[WE::NSLOT], val[WE::NSLOT];
+#pragma unroll
+                for (int sl = 0; sl < WE::NSLOT; ++sl) {
+                    xx[sl] = we.dsel[sl] == 0 ? x0 : (we.dsel[sl] == 1 ? x1 : x2);
+                    val[sl] = v2f{we.cs[sl][WE::NP - 1], we.cs[sl][WE::NP - 1]};
+                }
+#pragma unroll
+                for (int c = WE::NP - 2; c >= 0; --c)
+#pragma unroll
+                    for (int sl = 0; sl < WE::NSLOT; ++sl) val[sl] = __builtin_elementwise_fma(xx[sl], val[sl], v2f{we.cs[sl][c], we.cs[sl][c]});
+#pragma unroll
+                for (int sl = 0; sl < WE::NSLOT; ++sl) { vA[sl] = val[sl][0]; vB[sl] = val[sl][1]; }
+            } else {
+                const T XA[3] = {frA.x, frA.y, frA.z}, XB[3] = {frB.x, frB.y, frB.z};
+                we.eval_regs(a.t, XA, vA);
+                we.eval_regs(a.t, XB, vB);
+            }
+            store(ptA, vA);
+            store(ptB, vB);
         }
         wave_lds_fence();
     };
@@ -408,11 +437,14 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
 #pragma unroll
                 for (int cx = 0; cx < PBX; ++cx) A[o][cx] = (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? w1[cx] * w2[o] : 0.f;
             const uint32_t mask = cxmask;
-            issue_ops(b0 + 4);
-            issue_meta(b0 + 8);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cx = 0; cx < PBX; ++cx) {
+            // The operand reads of the next batch (and the meta data of the one after) are issued behind the matrix
+            // instructions of cube column 1 — four fifths of the matrix work belongs to batches that touch it — so that
+            // their address arithmetic, the LDS issue and the scalar mask set-up run while the matrix pipe works: with one
+            // wave per SIMD nothing else fills it, and everything in front of the first matrix instruction is serial time.
+            // ONE issue site: registers an inline-assembly read has been issued into must not meet at a control-flow join,
+            // where the compiler would copy them before the data has arrived.
+            auto column = [&](auto CXc) __attribute__((always_inline)) {
+                constexpr int cx = decltype(CXc)::value;
                 if (mask & (1u << cx)) {
 #pragma unroll
                     for (int o = 0; o < NCB; ++o) {
@@ -420,18 +452,31 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
                         if (cy >= 0 && cy < PBY) {
 #pragma unroll
                             for (int s = 0; s < NOB; ++s) {
+                                constexpr int dummy = 0;
                                 const int col = cy * PBX + cx;
-                                if (col < NCA) mfma_acc<true>(accA[s][col < NCA ? col : 0], A[o][cx], B[s]);
-                                else mfma_acc<false>(accV[s][col >= NCA ? col - NCA : 0], A[o][cx], B[s]);
+                                if (col < NCA) mfma_acc<true>(accA[s][col < NCA ? col : dummy], A[o][cx], B[s]);
+                                else mfma_acc<false>(accV[s][col >= NCA ? col - NCA : dummy], A[o][cx], B[s]);
                             }
                         }
                     }
                 }
-            }
+            };
+            column(std::integral_constant<int, 1>{});
+            issue_ops(b0 + 4);
+            issue_meta(b0 + 8);
+            column(std::integral_constant<int, 2>{});
+            column(std::integral_constant<int, 0>{});
+            column(std::integral_constant<int, 3>{});
             wait_all();
         }
     };
 
+#if defined(NUFFT_PATCH_PROFILE)
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define NUFFT_PH32(i) do { const unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; } while (0)
+#else
+#define NUFFT_PH32(i) do { } while (0)
+#endif
     // ---- main loop over the chunks of the segment ----
     Cursor nxt{bz_first, -1, 0u, 0u};
     bool has = advance(nxt);
@@ -439,16 +484,27 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
     int bz_done = bz_first;
     while (has) {
         const Cursor cur = nxt;
+        NUFFT_PH32(0);
         while (bz_done < cur.bz) { retire(bz_done); ++bz_done; }
+        NUFFT_PH32(1);
         wave_lds_fence();
         commit_prefetch(cur.bz);
+        NUFFT_PH32(2);
         has = advance(nxt);
         if (has) issue_prefetch(nxt);
+        NUFFT_PH32(0);
         const int n = (int)min((uint32_t)CH, cur.pe - cur.p);
         eval_chunk(n);
+        NUFFT_PH32(3);
         dispatch_row<0, NRB>(cur.u >> 1, [&](auto Rc) __attribute__((always_inline)) { batches(Rc, n); });
+        NUFFT_PH32(4);
     }
     while (bz_done <= bz_last) { retire(bz_done); ++bz_done; }
+    NUFFT_PH32(1);
+#if defined(NUFFT_PATCH_PROFILE)
+    if (lane == 0 && a.prof)
+        for (int i = 0; i < 5; ++i) atomicAdd(a.prof + i, tph[i]);
+#endif
 }
 
 }  // namespace nufft
