@@ -75,6 +75,7 @@ struct TileKernelArgs {
     const void* desc;          // uint2[ntiles]: slot -> (tile, slice << 16 | slices), see balance.hip
     const uint32_t* desc_total;    // number of slots in use
     int xcd_chunk;
+    int march;                 // interpolation: also launch the z-marching kernel (march_kernels.h); decided per point set on the device
     int fixed_tile;            // the tile (g.ip / g.sp) equals the compile-time one (kernel variant with constant strides)
     int cubes;                 // spreading with the compile-time tile: accumulate cube by cube with the FP64 matrix instruction
 };
@@ -84,6 +85,9 @@ void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n);
 // the same for the spreading tile (fixed_spread_tile())
 void spread_fixed_dims(int dtype, int is_complex, int D, int M, int* n);
 bool spread_cubes_available(int dtype, int is_complex, int D, int M);
+// z-marching interpolation (march_kernels.h): available for this plan?  (3-D, 4-cell bins, default window evaluation)
+bool interp_march_available(int dtype, int is_complex, int D, int M, const Geom& g, bool other);
+hipError_t prepare_interp_march(int dtype, int is_complex, int M);
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
 hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);
 // Sets the dynamic-LDS attribute of every instantiation that may be launched for this configuration.

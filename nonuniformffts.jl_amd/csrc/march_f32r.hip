@@ -1,0 +1,5 @@
+// interp_march_kernel instantiations for (float, complex = false): one per half-support M.
+#define NUFFT_T float
+#define NUFFT_CPLX false
+#define NUFFT_MARCH_GETTER march_kernel_f32r
+#include "march_inst.h"

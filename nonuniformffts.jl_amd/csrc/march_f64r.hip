@@ -1,0 +1,5 @@
+// interp_march_kernel instantiations for (double, complex = false): one per half-support M.
+#define NUFFT_T double
+#define NUFFT_CPLX false
+#define NUFFT_MARCH_GETTER march_kernel_f64r
+#include "march_inst.h"

@@ -1,0 +1,317 @@
+// Type-2 interpolation on a z-marching LDS ring (gfx950, wave64): the second interpolation engine.
+//
+// Replaces interpolate_to_points_shmem_kernel! (reference src/interpolation/gpu.jl:211-328, tile load :331-355) for 3-D
+// plans, with the same arithmetic per point (every point gathers its (2M)^3 stencil once).  interp_tile_kernel loads a
+// padded box (n + 2M - 1)^3 per tile, so every grid cell is fetched 2.6x (C2: 20 x 20 x 16 interior) to 12.5x (C3:
+// 16 x 12 x 8, ComplexF32, M = 8) through L2.  Here a workgroup owns a COLUMN of the grid — (n1 + 2M - 1) x (n2 + 2M - 1)
+// cells in x, y — and marches along z through a segment of bin layers: LDS holds a ring of RZ = 2M - 1 + 4 planes, the
+// window of the stencils of one bin layer (4 planes of cells); per layer 4 new planes replace the 4 oldest.  The halo is
+// paid in x and y only (C2: 32 x 32 interior, 1.49x; C3: 16 x 16, 3.75x), and the planes of the next layer are fetched
+// into registers while the points of the current layer are gathered, so the load latency is off the critical path.
+//
+// Points: the bins of a layer inside the column are runs of the bin-sorted array (one per row of bins); waves pull
+// passes of PPW points from an LDS counter.  The gather itself is the one of interp_tile_kernel (group mapping, DPP
+// broadcasts of the window values for real data, DPP / permlane reduction) with the plane index taken modulo RZ.
+//
+// Heavy columns are not shared between workgroups: set_points' balance pass (balance.hip) gives heavy tiles of the
+// regular tiling extra slices, and this kernel runs only when it gave none (uniform-like point sets; otherwise
+// interp_tile_kernel runs, which has the slices) — decided on the device, no host read-back.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "device_common.h"
+#include "nufft_mi355x.h"
+#include "tile_kernels.h"
+
+namespace nufft {
+
+struct MarchGeom {
+    int ntx, nty, nseg, segl;       // columns along x, y; segments along z; bin layers per segment
+    int ntasks;
+    uint32_t expect_slots;          // run only if *desc_total equals this (no tile of the regular tiling was sliced)
+};
+
+constexpr int kMarchThreads = 1024;
+constexpr int kMarchMaxRows = 16;   // rows of bins of a column (n2 <= 64)
+
+template <typename T, bool CPLX, int M>
+struct MarchCfg {
+    static constexpr int NC = CPLX ? 2 : 1;
+    static constexpr int L = 2 * M, HALO = L - 1;
+#ifndef NUFFT_MARCH_KL
+#define NUFFT_MARCH_KL 1
+#endif
+    static constexpr int KL = NUFFT_MARCH_KL;           // bin layers per phase (one barrier pair and one plane fetch per phase)
+    static constexpr int BZ = 4 * KL;                   // planes per phase
+    static constexpr int RZ = HALO + BZ;                // ring depth
+    static constexpr int NW = kMarchThreads / kWave;
+    using GP = Grp<NC, M>;
+    static constexpr bool REGW = !CPLX && (GP::G == 8 || GP::G == 16);      // window values stay in registers (DPP broadcasts)
+    static constexpr int strip_bytes() { return REGW ? 0 : round_up(GP::PPW * 3 * L * (int)sizeof(T), 16); }
+    // [runs of the segment: layer x row][passes of the longest run per layer][pass counter, flag]
+    static constexpr int table_bytes(int segl) { return round_up(kMarchMaxRows * segl * 8 + segl * 4 + 64, 16); }
+    static constexpr int kSegMax = 64;
+    static constexpr int fixed_bytes() { return table_bytes(kSegMax) + NW * strip_bytes() + 64; }
+    // column interior (n1, n2): multiples of the bin edge, minimal halo amplification within the LDS budget
+    struct Dims { int n1, n2; };
+    static constexpr Dims search() {
+        Dims best{0, 0};
+        double best_cost = 1e300;
+        for (int n2 = 4; n2 <= 4 * kMarchMaxRows; n2 += 4)
+            for (int n1 = 4; n1 <= 64; n1 += 4) {
+                const long bytes = (long)NC * (n1 + HALO) * (n2 + HALO) * RZ * (long)sizeof(T) + fixed_bytes();
+                if (bytes > 163840 - 256) continue;
+                double cost = (double)(n1 + HALO) / n1 * (double)(n2 + HALO) / n2;
+                // columns whose edge divides the common power-of-two grid sizes leave no partial column
+                if (512 % n1) cost *= 1.03;
+                if (512 % n2) cost *= 1.03;
+                cost -= 1e-6 * n1;
+                if (cost < best_cost) { best_cost = cost; best = Dims{n1, n2}; }
+            }
+        return best;
+    }
+    static constexpr Dims DIMS = search();
+    static constexpr int N1 = DIMS.n1, N2 = DIMS.n2;
+    static constexpr int P1 = N1 + HALO, P2 = N2 + HALO;
+    static constexpr int RS = NC * P1;                  // row stride in reals
+    static constexpr int PS = RS * P2;                  // plane stride in reals
+    static constexpr int RING_BYTES = round_up(RZ * PS * (int)sizeof(T), 16);
+    static constexpr int lds_bytes() { return RING_BYTES + fixed_bytes(); }
+    static constexpr int NPF = (BZ * PS + kMarchThreads - 1) / kMarchThreads;    // prefetched reals per thread and layer
+    static constexpr bool FITS = N1 > 0;                // (ComplexF64 at M >= 9: not even a 4 x 4 column fits 160 KiB)
+};
+
+template <typename T, bool CPLX, int M>
+__global__ __launch_bounds__(kMarchThreads) void interp_march_kernel(TileArgs<T> a, MarchGeom mg) {
+    using C = MarchCfg<T, CPLX, M>;
+    using GP = typename C::GP;
+    constexpr int NC = C::NC, L = C::L, RZ = C::RZ, BZ = C::BZ, RS = C::RS, PS = C::PS, P1 = C::P1, P2 = C::P2;
+    constexpr int N1 = C::N1, N2 = C::N2, NPF = C::NPF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    if (*a.desc_total != mg.expect_slots) return;      // sliced tiles: interp_tile_kernel serves this point set
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const Geom& g = a.g;
+    const int task = xcd_remap_chunked((int)blockIdx.x, (int)gridDim.x, a.xcd_chunk);
+    if (task >= mg.ntasks) return;
+    const int comp_id = blockIdx.y;
+    const int tx = task % mg.ntx, ty = (task / mg.ntx) % mg.nty, seg = task / (mg.ntx * mg.nty);
+    const int org1 = tx * N1, org2 = ty * N2;
+    const int neff1 = min(N1, g.Nover[0] - org1), neff2 = min(N2, g.Nover[1] - org2);
+    const int zb0 = seg * mg.segl, zb1 = min(zb0 + mg.segl, g.nb[2]);
+    const int nlay = zb1 - zb0;
+    const int nrows = (neff2 + 3) >> 2;                 // rows of bins of the column
+    const int bx0 = org1 >> 2, nbx = (neff1 + 3) >> 2, by0 = org2 >> 2;
+
+    T* ring = reinterpret_cast<T*>(smem);
+    uint2* runs = reinterpret_cast<uint2*>(smem + C::RING_BYTES);                 // [layer][row] -> [p0, p1) of the sorted array
+    int* maxp = reinterpret_cast<int*>(runs + kMarchMaxRows * C::kSegMax);        // [layer] -> passes of its longest run
+    int* counter = reinterpret_cast<int*>(smem + C::RING_BYTES + C::table_bytes(C::kSegMax) - 64);   // [0] pass counter, [1] any point
+    T* strip_wave = reinterpret_cast<T*>(smem + C::RING_BYTES + C::table_bytes(C::kSegMax) + wave * C::strip_bytes());
+
+    // ---- runs of the segment, and whether it holds any point at all ----
+    if (tid < 2) counter[tid] = 0;
+    for (int i = tid; i < nlay; i += kMarchThreads) maxp[i] = 0;
+    __syncthreads();
+    {
+        int any = 0;
+        for (int i = tid; i < nlay * nrows; i += kMarchThreads) {
+            const int lay = i / nrows, row = i % nrows;
+            const int64_t bin0 = ((int64_t)(zb0 + lay) * g.nb[1] + by0 + row) * g.nb[0] + bx0;
+            const uint2 pr = make_uint2(a.offsets[bin0], a.offsets[bin0 + nbx]);
+            runs[lay * kMarchMaxRows + row] = pr;
+            any |= pr.x != pr.y;
+            atomicMax(&maxp[lay], (int)((pr.y - pr.x + GP::PPW - 1) / GP::PPW));
+        }
+        if (any) counter[1] = 1;
+    }
+    __syncthreads();
+    if (counter[1] == 0) return;
+
+    const T* grid = a.grid[comp_id];
+    const int zbase = 4 * zb0 - (M - 1);                // first plane of the segment's first window (may be negative)
+    const int o1 = org1 - (M - 1), o2 = org2 - (M - 1);
+
+    // global address of real e of plane `gz` (unwrapped) of the padded column
+    auto src_of = [&](int gz, int e) __attribute__((always_inline)) -> const T* {
+        const int r = e / RS, xx = e % RS;
+        const int64_t row = (int64_t)wrap_index(gz, g.Nover[2]) * g.Nover[1] + wrap_index(o2 + r, g.Nover[1]);
+        return grid + (row * g.Nover[0] + wrap_index(o1 + xx / NC, g.Nover[0])) * NC + xx % NC;
+    };
+    // ---- first window: RZ planes straight into the ring (plane zbase + k in slot k) ----
+    for (int e = tid; e < RZ * PS; e += kMarchThreads) {
+        const int k = e / PS;
+        int gz = zbase + k;
+        if (gz < 0) gz += g.Nover[2];
+        ring[e] = *src_of(gz, e % PS);
+    }
+
+    const int grp = lane / GP::G, q = lane % GP::G;
+    const bool lane_active = q < GP::W1;
+    const int comp = q % NC, j1 = (q / NC) % L;
+    T* strip = strip_wave + grp * (3 * L);
+    WindowEval<T, NC, 3, M, GP::G, false> we;
+    we.init(a, q);
+    const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.sorted);
+    T* vout = a.vout[comp_id];
+    __syncthreads();
+
+    constexpr int KL = C::KL;
+    int pm = 0;                                         // (BZ * phase) mod RZ: slot of the first plane of the window
+    const int nphase = (nlay + KL - 1) / KL;
+    for (int ph = 0; ph < nphase; ++ph) {
+        // ---- planes of the next phase into registers (they replace the BZ oldest once this phase is done) ----
+        T pf[NPF];
+        const bool more = ph + 1 < nphase;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int e = tid + u * kMarchThreads;
+                pf[u] = T(0);
+                if (e < BZ * PS) {
+                    int gz = zbase + RZ + BZ * ph + e / PS;
+                    if (gz >= g.Nover[2]) gz -= g.Nover[2];
+                    pf[u] = *src_of(gz, e % PS);
+                }
+            }
+        }
+        // ---- points of this phase's bin layers: passes of PPW points, pulled from a counter; item -> (layer, row, pass of
+        //      that row), up to the pass count of the phase's longest run (shorter rows yield empty items) ----
+        const int lay0 = ph * KL, nl = min(KL, nlay - lay0);
+        int mp = 0;
+#pragma unroll
+        for (int kl = 0; kl < KL; ++kl) mp = max(mp, kl < nl ? maxp[lay0 + kl] : 0);
+        const int nrl = nrows * nl;
+        const int nitems = mp * nrl;
+        for (;;) {
+            int item = 0;
+            if (lane == 0) item = atomicAdd(counter, 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item >= nitems) break;
+            const int rl = item % nrl, kl = rl / nrows;
+            const uint2 pr = runs[(lay0 + kl) * kMarchMaxRows + rl % nrows];
+            const uint32_t p0 = pr.x + (uint32_t)(item / nrl) * GP::PPW, p1 = pr.y;
+            if (p0 >= p1) continue;
+            const uint32_t p = p0 + grp;
+            const bool have = p < p1;
+            const PointRec<T, 3> rec = sorted[min(p, p1 - 1)];
+            int s[3];
+            T X[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int c = cell_of(rec.r[d], g.Nover[d]);
+                X[d] = rec.r[d] - T(c);
+                s[d] = c;
+            }
+            s[0] -= org1; s[1] -= org2;                   // first stencil node in padded-column coordinates
+            int s3 = pm + 4 * kl + (s[2] & 3);           // ring slot of the first stencil plane
+            if (s3 >= RZ) s3 -= RZ;
+            T wv[WindowEval<T, NC, 3, M, GP::G, false>::NSLOT];
+            T w1;
+            if constexpr (C::REGW) {
+                we.eval_regs(a, X, wv);
+                w1 = wv[0];
+            } else {
+                wave_lds_fence();
+                we.eval_to_strip(a, X, strip, q);
+                wave_lds_fence();
+                w1 = strip[j1];
+            }
+            auto wfetch = [&](int d, int j) __attribute__((always_inline)) -> T {
+                const int kk = d * L + j;
+                const T x = wv[kk / GP::G];
+                if constexpr (GP::G == 16) return row_bcast(x, kk % GP::G);
+                const T lo = row_bcast(x, kk % GP::G), hi = row_bcast(x, kk % GP::G + 8);
+                return (lane & 8) ? hi : lo;
+            };
+            const T* base = ring + (s[0] + j1) * NC + comp + s[1] * RS;
+            int poff = s3 * PS;                          // plane offset of stencil plane j3 (wraps at RZ * PS)
+            T acc = T(0);
+            if constexpr (C::REGW) {
+                T w2[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
+#if NUFFT_INTERP_ASM_READS
+                // hand-scheduled LDS reads (as in interp_tile_kernel): groups of R rows with immediate offsets from the
+                // plane's own address (the ring wraps between planes), the next group in flight while this one is consumed
+                constexpr int R = 2, GPP = L / R, NG = L * GPP, RB = RS * (int)sizeof(T);      // (larger groups spill: 128 registers at 16 waves per CU)
+                const uint32_t a0 = (uint32_t)(uintptr_t)base;
+                T buf[2][R];
+                lds_read_rows<T, R, 0, RB>(buf[0], a0 + (uint32_t)poff * (uint32_t)sizeof(T), std::make_integer_sequence<int, R>{});
+                T t2 = T(0);
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    if (gi + 1 < NG) {
+                        if ((gi + 1) % GPP == 0) {                 // next group starts the next plane
+                            poff += PS;
+                            if (poff >= RZ * PS) poff -= RZ * PS;
+                        }
+                        const uint32_t ad = a0 + (uint32_t)poff * (uint32_t)sizeof(T) + (uint32_t)(((gi + 1) % GPP) * R * RB);
+                        lds_read_rows<T, R, 0, RB>(buf[(gi + 1) & 1], ad, std::make_integer_sequence<int, R>{});
+                        lds_wait_rows<R>(buf[gi & 1]);
+                    } else {
+                        lds_wait_rows<0>(buf[gi & 1]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) t2 = fma(buf[gi & 1][r], w2[(gi % GPP) * R + r], t2);
+                    if (gi % GPP == GPP - 1) {
+                        acc = fma(t2, wfetch(2, gi / GPP), acc);
+                        t2 = T(0);
+                    }
+                }
+#else
+#pragma unroll
+                for (int j3 = 0; j3 < L; ++j3) {
+                    const T* plane = base + poff;
+                    T t2 = T(0);
+#pragma unroll
+                    for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * RS], w2[j2], t2);
+                    acc = fma(t2, wfetch(2, j3), acc);
+                    poff += PS;
+                    if (poff >= RZ * PS) poff -= RZ * PS;
+                }
+#endif
+                acc = (have && lane_active) ? acc * w1 : T(0);
+            } else if (have && lane_active) {
+                T w2[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) w2[j] = strip[L + j];
+#pragma unroll
+                for (int j3 = 0; j3 < L; ++j3) {
+                    const T* plane = base + poff;
+                    T t2 = T(0);
+#pragma unroll
+                    for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * RS], w2[j2], t2);
+                    acc = fma(t2, strip[2 * L + j3], acc);
+                    poff += PS;
+                    if (poff >= RZ * PS) poff -= RZ * PS;
+                }
+                acc *= w1;
+            }
+            acc = group_sum<T, GP::G, CPLX>(acc);
+            if (have && q < NC) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
+        }
+        __syncthreads();                                 // every wave has finished with this phase's window
+        if (more) {
+            if (tid == 0) counter[0] = 0;
+            // the BZ new planes take the slots of the BZ oldest: slots pm .. pm + BZ - 1 (mod RZ)
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int e = tid + u * kMarchThreads;
+                if (e < BZ * PS) {
+                    int slot = pm + e / PS;
+                    if (slot >= RZ) slot -= RZ;
+                    ring[slot * PS + e % PS] = pf[u];
+                }
+            }
+            pm += BZ;
+            if (pm >= RZ) pm -= RZ;
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace nufft

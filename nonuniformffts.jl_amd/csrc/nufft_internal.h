@@ -107,6 +107,7 @@ struct nufft_plan {
     std::vector<double> phihat[3];
     std::vector<int64_t> index_map[3];
     nufft::TileGeom tile;
+    bool interp_march = false;         // the z-marching interpolation kernel serves un-sliced point sets (march_kernels.h)
     bool interp_fixed = false;         // tile.ip is the compile-time tile of the kernel instantiation
     bool spread_fixed = false;         // tile.sp likewise
     bool spread_cubes = false;         // LDS-tile spreading accumulates cube by cube (v_mfma_f64_4x4x4 + one ds_add_f64 per cube)

@@ -379,6 +379,9 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
         wave_lds_fence();
     };
 
+#if defined(NUFFT_PATCH_PROFILE)
+    unsigned long long nmfma = 0, nbatchcol = 0, nbatch = 0;
+#endif
     // ---- K-batches of four points (k = lane >> 4; the all-zero point pads the last one), software-pipelined as in
     //      spread_patch_kernel: the LDS reads of batch i + 1 (operands) and i + 2 (meta data) fly while batch i's MFMAs issue
     auto batches = [&](auto RBc, int n) __attribute__((always_inline)) {
@@ -429,6 +432,9 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
         wait_all();
 #pragma unroll 1
         for (int b0 = 0; b0 < n; b0 += 4) {
+#if defined(NUFFT_PATCH_PROFILE)
+            nbatch += 1;
+#endif
             float A[NCB][PBX], B[NOB];
 #pragma unroll
             for (int s = 0; s < NOB; ++s) B[s] = w3[s] * vcur;
@@ -446,6 +452,15 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
             auto column = [&](auto CXc) __attribute__((always_inline)) {
                 constexpr int cx = decltype(CXc)::value;
                 if (mask & (1u << cx)) {
+#if defined(NUFFT_PATCH_PROFILE)
+                    {
+                        int rows = 0;
+#pragma unroll
+                        for (int o = 0; o < NCB; ++o) rows += (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? 1 : 0;
+                        nmfma += (unsigned long long)(rows * NOB);
+                        nbatchcol += 1;
+                    }
+#endif
 #pragma unroll
                     for (int o = 0; o < NCB; ++o) {
                         const int cy = RB + CLO + o;
@@ -473,6 +488,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
 
 #if defined(NUFFT_PATCH_PROFILE)
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    tph[5] = 0;
 #define NUFFT_PH32(i) do { const unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; } while (0)
 #else
 #define NUFFT_PH32(i) do { } while (0)
@@ -502,8 +518,12 @@ __global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(
     while (bz_done <= bz_last) { retire(bz_done); ++bz_done; }
     NUFFT_PH32(1);
 #if defined(NUFFT_PATCH_PROFILE)
-    if (lane == 0 && a.prof)
+    if (lane == 0 && a.prof) {
         for (int i = 0; i < 5; ++i) atomicAdd(a.prof + i, tph[i]);
+        atomicAdd(a.prof + 5, nmfma);
+        atomicAdd(a.prof + 6, nbatch);
+        atomicAdd(a.prof + 7, nbatchcol);
+    }
 #endif
 }
 

@@ -520,6 +520,12 @@ static int build_device(nufft_plan* p) {
         NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp, other != 0));
     }
 
+    // second interpolation engine (z-marching ring, march_kernels.h): 3-D plans with the default window evaluation, when
+    // the balance pass exists (its slot count is the per-point-set switch); NUFFT_INTERP_MARCH=0: off (A/B runs)
+    p->interp_march = env_int("NUFFT_INTERP_MARCH", 1) != 0 && p->balance_enabled &&
+                      interp_march_available(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
+    if (p->interp_march) NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M));
+
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false));
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 4 * sizeof(uint32_t)))) return rc;
@@ -605,6 +611,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.weights = p->cb_point_weights;
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
+    a.march = interp && p->interp_march && !p->cb_point_weights;
     a.cubes = !interp && p->spread_cubes && !needs_other_eval(p->kernel, p->evalmode) && !p->cb_point_weights;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
     const nufft_plan::Balance& b = p->bal;

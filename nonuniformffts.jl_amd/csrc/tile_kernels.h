@@ -66,6 +66,8 @@ struct TileArgs {
     const uint2* desc;                    // slot -> (tile, slice << 16 | slices of the tile), balance.hip
     const uint32_t* desc_total;           // slots in use (the launch grid may be larger)
     int xcd_chunk;                        // slots per XCD chunk (0: one contiguous range per XCD)
+    uint32_t march_slots;                 // interpolation: nonzero = the z-marching kernel (march_kernels.h) serves point sets
+                                          // whose slot count equals this (no sliced tile); interp_tile_kernel then returns
     int evalmode;
     int kernel;                           // NUFFT_KERNEL_*; beta / bop per kernel: see WindowEval
 };
@@ -849,6 +851,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
 
     const uint32_t nslots = *a.desc_total;
     if (blockIdx.x >= nslots) return;
+    if (a.march_slots != 0u && nslots == a.march_slots) return;     // this point set goes to interp_march_kernel
     const uint2 de = a.desc[xcd_remap_chunked(blockIdx.x, (int)nslots, a.xcd_chunk)];
     const int tile_id = (int)de.x, slice = (int)(de.y >> 16), nslices = (int)(de.y & 0xffffu);
     const int comp_id = blockIdx.y;

@@ -6,8 +6,32 @@
 #include "kernels.h"
 #include "tile_kernels.h"
 #include "patch_kernels.h"
+#include "march_kernels.h"
 
 namespace nufft {
+
+const void* march_kernel_f32r(int M, int* lds_bytes, int* n);
+const void* march_kernel_f32c(int M, int* lds_bytes, int* n);
+const void* march_kernel_f64r(int M, int* lds_bytes, int* n);
+const void* march_kernel_f64c(int M, int* lds_bytes, int* n);
+static const void* march_kernel(int dtype, int is_complex, int M, int* lds_bytes, int* n) {
+    if (dtype == NUFFT_F32) return is_complex ? march_kernel_f32c(M, lds_bytes, n) : march_kernel_f32r(M, lds_bytes, n);
+    return is_complex ? march_kernel_f64c(M, lds_bytes, n) : march_kernel_f64r(M, lds_bytes, n);
+}
+bool interp_march_available(int dtype, int is_complex, int D, int M, const Geom& g, bool other) {
+    int lds = 0, n[3];
+    if (D != 3 || other || !march_kernel(dtype, is_complex, M, &lds, n)) return false;
+    for (int d = 0; d < 3; ++d)
+        if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return false;
+    // columns shorter than the axis (a point's stencil then never reaches a column from both sides)
+    return n[0] + 2 * M - 1 <= g.Nover[0] && n[1] + 2 * M - 1 <= g.Nover[1] && 4 + 2 * M - 1 <= g.Nover[2];
+}
+hipError_t prepare_interp_march(int dtype, int is_complex, int M) {
+    int lds = 0, n[3];
+    const void* fn = march_kernel(dtype, is_complex, M, &lds, n);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
 
 const void* spread_kernel_f32r(int D, int M, bool flag, bool other);
 const void* spread_kernel_f32c(int D, int M, bool flag, bool other);
@@ -127,6 +151,7 @@ static TileArgs<T> fill_tile_args(const TileKernelArgs& a, int c0, int nc) {
     k.desc = static_cast<const uint2*>(a.desc);
     k.desc_total = a.desc_total;
     k.xcd_chunk = a.xcd_chunk;
+    k.march_slots = 0u;
     k.evalmode = a.evalmode;
     k.kernel = a.kernel;
     return k;
@@ -148,13 +173,39 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         }
     }
     if (!fn) return hipErrorInvalidValue;
+    // z-marching interpolation: launched next to the tile kernel; the slot count set_points left on the device decides
+    // which of the two finds work (no sliced tile: the marching kernel)
+    const bool march = interp && a.march != 0 && !other;
+    const uint32_t march_slots = march ? (uint32_t)a.g.ip.ntiles : 0u;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
+        k.march_slots = march_slots;
         void* params[] = {&k};
         hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
                                        params, (size_t)a.lds_bytes, stream);
         if (e != hipSuccess) return e;
+        if (march) {
+            int lds = 0, n[3];
+            const void* mfn = march_kernel(a.dtype, a.is_complex, a.M, &lds, n);
+            MarchGeom mg{};
+            mg.ntx = (a.g.Nover[0] + n[0] - 1) / n[0];
+            mg.nty = (a.g.Nover[1] + n[1] - 1) / n[1];
+            // segments along z: about four workgroups per CU in flight over the run, whole bin layers, at most n[2] each
+            const int cols = mg.ntx * mg.nty;
+            int nseg = (1024 + cols - 1) / cols;
+            const int min_seg = (a.g.nb[2] + n[2] - 1) / n[2];
+            if (nseg < min_seg) nseg = min_seg;
+            if (nseg > a.g.nb[2] / 8 && a.g.nb[2] / 8 >= min_seg) nseg = a.g.nb[2] / 8;
+            if (nseg < 1) nseg = 1;
+            mg.segl = (a.g.nb[2] + nseg - 1) / nseg;
+            mg.nseg = (a.g.nb[2] + mg.segl - 1) / mg.segl;
+            mg.ntasks = cols * mg.nseg;
+            mg.expect_slots = march_slots;
+            void* mparams[] = {&k, &mg};
+            e = hipLaunchKernel(mfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3(kMarchThreads, 1, 1), mparams, (size_t)lds, stream);
+            if (e != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
@@ -256,6 +307,8 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
         fprintf(stderr, "patch phases (%% of wave cycles): advance+prefetch %.1f  retire %.1f  commit %.1f  eval %.1f  batches %.1f  (total %.3g cycles)\n",
                 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, tot);
+        if (h[5]) fprintf(stderr, "patch32 counts: %.4g matrix instructions, %.4g K-batches (%.2f matrix instructions each), %.4g batch-columns\n",
+                          (double)h[5], (double)h[6], (double)h[5] / (double)h[6], (double)h[7]);
 #endif
     }
     return hipSuccess;
