@@ -10,15 +10,15 @@ static void march_entry(const void** fn, int* lds_bytes, int* n) {
     if constexpr (C::FITS) {
         *fn = reinterpret_cast<const void*>(&interp_march_kernel<NUFFT_T, NUFFT_CPLX, M>);
         *lds_bytes = C::lds_bytes();
-        n[0] = C::N1; n[1] = C::N2; n[2] = C::kSegMax;
+        n[0] = C::N1; n[1] = C::N2; n[2] = C::kSegMax; n[3] = C::THREADS;
     }
 }
 
-// kernel for half-support M (null: none), its dynamic LDS bytes, the column interior n[0] x n[1] and the longest segment n[2]
+// kernel for half-support M (null: none), its dynamic LDS bytes, the column interior n[0] x n[1], the longest segment n[2] and the workgroup size n[3]
 const void* NUFFT_MARCH_GETTER(int M, int* lds_bytes, int* n) {
     const void* fn = nullptr;
     *lds_bytes = 0;
-    n[0] = n[1] = n[2] = 0;
+    n[0] = n[1] = n[2] = n[3] = 0;
     switch (M) {
         case 2: march_entry<2>(&fn, lds_bytes, n); break;
         case 3: march_entry<3>(&fn, lds_bytes, n); break;

@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "device_common.h"
@@ -34,7 +35,6 @@ struct MarchGeom {
     uint32_t expect_slots;          // run only if *desc_total equals this (no tile of the regular tiling was sliced)
 };
 
-constexpr int kMarchThreads = 1024;
 constexpr int kMarchMaxRows = 16;   // rows of bins of a column (n2 <= 64)
 
 template <typename T, bool CPLX, int M>
@@ -47,9 +47,21 @@ struct MarchCfg {
     static constexpr int KL = NUFFT_MARCH_KL;           // bin layers per phase (one barrier pair and one plane fetch per phase)
     static constexpr int BZ = 4 * KL;                   // planes per phase
     static constexpr int RZ = HALO + BZ;                // ring depth
-    static constexpr int NW = kMarchThreads / kWave;
-    using GP = Grp<NC, M>;
-    static constexpr bool REGW = !CPLX && (GP::G == 8 || GP::G == 16);      // window values stay in registers (DPP broadcasts)
+    // 16 waves per CU leave 128 registers per lane: enough for M <= 5; wider stencils (more window values, coefficients
+    // and rows in flight per lane) spill there, so they run 8 waves with 256 registers each
+#ifndef NUFFT_MARCH_WIDE_M
+#define NUFFT_MARCH_WIDE_M 6
+#endif
+    static constexpr int THREADS = M >= NUFFT_MARCH_WIDE_M ? 512 : 1024;
+    static constexpr int NW = THREADS / kWave;
+    // Complex data with at most 16 lanes per stencil row: ONE lane per j1 gathers both components (64- / 128-bit LDS reads,
+    // v_pk_fma_f32 for ComplexF32) — half the wave instructions per point of the (j1, component) lane mapping, and the
+    // window values can stay in registers as for real data.
+    // (ComplexF32 only: 128-bit reads of ComplexF64 pairs run the LDS at a quarter of its rate, scripts/microbench7.hip —
+    // measured here: ComplexF64 m = 4 interpolation 5.5 ms paired against 4.4 ms with the tile kernel)
+    static constexpr bool PAIR = CPLX && sizeof(T) == 4 && next_pow2(L) <= 16;
+    using GP = Grp<PAIR ? 1 : NC, M>;
+    static constexpr bool REGW = (!CPLX || PAIR) && (GP::G == 8 || GP::G == 16);   // window values stay in registers (DPP broadcasts)
     static constexpr int strip_bytes() { return REGW ? 0 : round_up(GP::PPW * 3 * L * (int)sizeof(T), 16); }
     // [runs of the segment: layer x row][passes of the longest run per layer][pass counter, flag]
     static constexpr int table_bytes(int segl) { return round_up(kMarchMaxRows * segl * 8 + segl * 4 + 64, 16); }
@@ -80,13 +92,14 @@ struct MarchCfg {
     static constexpr int PS = RS * P2;                  // plane stride in reals
     static constexpr int RING_BYTES = round_up(RZ * PS * (int)sizeof(T), 16);
     static constexpr int lds_bytes() { return RING_BYTES + fixed_bytes(); }
-    static constexpr int NPF = (BZ * PS + kMarchThreads - 1) / kMarchThreads;    // prefetched reals per thread and layer
+    static constexpr int NPF = (BZ * PS + THREADS - 1) / THREADS;    // prefetched reals per thread and layer
     static constexpr bool FITS = N1 > 0;                // (ComplexF64 at M >= 9: not even a 4 x 4 column fits 160 KiB)
 };
 
 template <typename T, bool CPLX, int M>
-__global__ __launch_bounds__(kMarchThreads) void interp_march_kernel(TileArgs<T> a, MarchGeom mg) {
+__global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_kernel(TileArgs<T> a, MarchGeom mg) {
     using C = MarchCfg<T, CPLX, M>;
+    constexpr int kMarchThreads = C::THREADS;
     using GP = typename C::GP;
     constexpr int NC = C::NC, L = C::L, RZ = C::RZ, BZ = C::BZ, RS = C::RS, PS = C::PS, P1 = C::P1, P2 = C::P2;
     constexpr int N1 = C::N1, N2 = C::N2, NPF = C::NPF;
@@ -149,11 +162,21 @@ __global__ __launch_bounds__(kMarchThreads) void interp_march_kernel(TileArgs<T>
         ring[e] = *src_of(gz, e % PS);
     }
 
+    // lane roles: G lanes per point, lane q = (j1, component) — or j1 alone with both components per lane (PAIR)
+    constexpr bool PAIR = C::PAIR;
+    constexpr int NCL = PAIR ? 1 : NC;                  // components that have lanes of their own
+    typedef T VT2 __attribute__((ext_vector_type(2)));
+    using VT = typename std::conditional<PAIR, VT2, T>::type;      // what one lane gathers per stencil node
+    auto vfma = [](VT x, T w, VT acc) __attribute__((always_inline)) -> VT {
+        if constexpr (PAIR) return __builtin_elementwise_fma(x, VT{w, w}, acc);
+        else return fma(x, w, acc);
+    };
     const int grp = lane / GP::G, q = lane % GP::G;
     const bool lane_active = q < GP::W1;
-    const int comp = q % NC, j1 = (q / NC) % L;
+    const int comp = q % NCL, j1 = (q / NCL) % L;
     T* strip = strip_wave + grp * (3 * L);
-    WindowEval<T, NC, 3, M, GP::G, false> we;
+    using WEv = WindowEval<T, NCL, 3, M, GP::G, false>;
+    WEv we;
     we.init(a, q);
     const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.sorted);
     T* vout = a.vout[comp_id];
@@ -209,7 +232,7 @@ __global__ __launch_bounds__(kMarchThreads) void interp_march_kernel(TileArgs<T>
             s[0] -= org1; s[1] -= org2;                   // first stencil node in padded-column coordinates
             int s3 = pm + 4 * kl + (s[2] & 3);           // ring slot of the first stencil plane
             if (s3 >= RZ) s3 -= RZ;
-            T wv[WindowEval<T, NC, 3, M, GP::G, false>::NSLOT];
+            T wv[WEv::NSLOT];
             T w1;
             if constexpr (C::REGW) {
                 we.eval_regs(a, X, wv);
@@ -230,18 +253,19 @@ __global__ __launch_bounds__(kMarchThreads) void interp_march_kernel(TileArgs<T>
             const T* base = ring + (s[0] + j1) * NC + comp + s[1] * RS;
             int poff = s3 * PS;                          // plane offset of stencil plane j3 (wraps at RZ * PS)
             T acc = T(0);
+            VT accv = VT(0);
             if constexpr (C::REGW) {
                 T w2[L];
 #pragma unroll
                 for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
-#if NUFFT_INTERP_ASM_READS
+                if constexpr (L <= 8) {
                 // hand-scheduled LDS reads (as in interp_tile_kernel): groups of R rows with immediate offsets from the
                 // plane's own address (the ring wraps between planes), the next group in flight while this one is consumed
                 constexpr int R = 2, GPP = L / R, NG = L * GPP, RB = RS * (int)sizeof(T);      // (larger groups spill: 128 registers at 16 waves per CU)
                 const uint32_t a0 = (uint32_t)(uintptr_t)base;
-                T buf[2][R];
-                lds_read_rows<T, R, 0, RB>(buf[0], a0 + (uint32_t)poff * (uint32_t)sizeof(T), std::make_integer_sequence<int, R>{});
-                T t2 = T(0);
+                VT buf[2][R];
+                lds_read_rows<VT, R, 0, RB>(buf[0], a0 + (uint32_t)poff * (uint32_t)sizeof(T), std::make_integer_sequence<int, R>{});
+                VT t2 = VT(0);
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     if (gi + 1 < NG) {
@@ -250,30 +274,40 @@ __global__ __launch_bounds__(kMarchThreads) void interp_march_kernel(TileArgs<T>
                             if (poff >= RZ * PS) poff -= RZ * PS;
                         }
                         const uint32_t ad = a0 + (uint32_t)poff * (uint32_t)sizeof(T) + (uint32_t)(((gi + 1) % GPP) * R * RB);
-                        lds_read_rows<T, R, 0, RB>(buf[(gi + 1) & 1], ad, std::make_integer_sequence<int, R>{});
+                        lds_read_rows<VT, R, 0, RB>(buf[(gi + 1) & 1], ad, std::make_integer_sequence<int, R>{});
                         lds_wait_rows<R>(buf[gi & 1]);
                     } else {
                         lds_wait_rows<0>(buf[gi & 1]);
                     }
 #pragma unroll
-                    for (int r = 0; r < R; ++r) t2 = fma(buf[gi & 1][r], w2[(gi % GPP) * R + r], t2);
+                    for (int r = 0; r < R; ++r) t2 = vfma(buf[gi & 1][r], w2[(gi % GPP) * R + r], t2);
                     if (gi % GPP == GPP - 1) {
-                        acc = fma(t2, wfetch(2, gi / GPP), acc);
-                        t2 = T(0);
+                        accv = vfma(t2, wfetch(2, gi / GPP), accv);
+                        t2 = VT(0);
                     }
                 }
-#else
+                } else {
+                    // wide stencils: the unrolled hand-scheduled form (2M x M groups) spills; the compiler schedules the reads
 #pragma unroll
-                for (int j3 = 0; j3 < L; ++j3) {
-                    const T* plane = base + poff;
-                    T t2 = T(0);
+                    for (int j3 = 0; j3 < L; ++j3) {
+                        const VT* plane = reinterpret_cast<const VT*>(base + poff);
+                        VT t2 = VT(0);
 #pragma unroll
-                    for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * RS], w2[j2], t2);
-                    acc = fma(t2, wfetch(2, j3), acc);
-                    poff += PS;
-                    if (poff >= RZ * PS) poff -= RZ * PS;
+                        for (int j2 = 0; j2 < L; ++j2) t2 = vfma(*reinterpret_cast<const VT*>(reinterpret_cast<const T*>(plane) + j2 * RS), w2[j2], t2);
+                        accv = vfma(t2, wfetch(2, j3), accv);
+                        poff += PS;
+                        if (poff >= RZ * PS) poff -= RZ * PS;
+                    }
                 }
-#endif
+                if constexpr (PAIR) {
+                    const bool okl = have && lane_active;
+                    const T re = group_sum<T, GP::G, false>(okl ? accv[0] * w1 : T(0));
+                    const T im = group_sum<T, GP::G, false>(okl ? accv[1] * w1 : T(0));
+                    if (have && q == 0) *reinterpret_cast<VT*>(vout + (int64_t)rec.idx * 2) = VT{re * a.prefactor, im * a.prefactor};
+                    continue;
+                } else {
+                    acc = accv;
+                }
                 acc = (have && lane_active) ? acc * w1 : T(0);
             } else if (have && lane_active) {
                 T w2[L];

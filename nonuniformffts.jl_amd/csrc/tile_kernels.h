@@ -297,7 +297,8 @@ __device__ __forceinline__ void lds_add_planes(double* p, T w, const T (&w3)[L],
 template <typename T, int OFF>
 __device__ __forceinline__ void lds_read_imm(T& dst, uint32_t addr) {
     static_assert(OFF >= 0 && OFF < 65536, "LDS immediate offset out of range");
-    if constexpr (sizeof(T) == 8) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+    if constexpr (sizeof(T) == 16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+    else if constexpr (sizeof(T) == 8) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
     else asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 template <typename T, int R, int FIRST_OFF, int ROW_BYTES, int... J>

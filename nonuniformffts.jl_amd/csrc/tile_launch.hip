@@ -19,7 +19,7 @@ static const void* march_kernel(int dtype, int is_complex, int M, int* lds_bytes
     return is_complex ? march_kernel_f64c(M, lds_bytes, n) : march_kernel_f64r(M, lds_bytes, n);
 }
 bool interp_march_available(int dtype, int is_complex, int D, int M, const Geom& g, bool other) {
-    int lds = 0, n[3];
+    int lds = 0, n[4];
     if (D != 3 || other || !march_kernel(dtype, is_complex, M, &lds, n)) return false;
     for (int d = 0; d < 3; ++d)
         if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return false;
@@ -27,7 +27,7 @@ bool interp_march_available(int dtype, int is_complex, int D, int M, const Geom&
     return n[0] + 2 * M - 1 <= g.Nover[0] && n[1] + 2 * M - 1 <= g.Nover[1] && 4 + 2 * M - 1 <= g.Nover[2];
 }
 hipError_t prepare_interp_march(int dtype, int is_complex, int M) {
-    int lds = 0, n[3];
+    int lds = 0, n[4];
     const void* fn = march_kernel(dtype, is_complex, M, &lds, n);
     if (!fn) return hipErrorInvalidValue;
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -186,7 +186,7 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
                                        params, (size_t)a.lds_bytes, stream);
         if (e != hipSuccess) return e;
         if (march) {
-            int lds = 0, n[3];
+            int lds = 0, n[4];
             const void* mfn = march_kernel(a.dtype, a.is_complex, a.M, &lds, n);
             MarchGeom mg{};
             mg.ntx = (a.g.Nover[0] + n[0] - 1) / n[0];
@@ -203,7 +203,7 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
             mg.ntasks = cols * mg.nseg;
             mg.expect_slots = march_slots;
             void* mparams[] = {&k, &mg};
-            e = hipLaunchKernel(mfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3(kMarchThreads, 1, 1), mparams, (size_t)lds, stream);
+            e = hipLaunchKernel(mfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)n[3], 1, 1), mparams, (size_t)lds, stream);
             if (e != hipSuccess) return e;
         }
     }
