@@ -134,6 +134,50 @@ def launch_ranks(a):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def sync_barrier(dev, distributed):
+    """Device sync + (N > 1) barrier + device sync: both ends of the timed region (driver contract)."""
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
+def timed_steps(step_fn, K, W, dev, distributed, after=None):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by sync_barrier; returns (seconds = MAX over ranks,
+    events).  `step_fn(k, events)` runs one step (events is None during warm-up); `after()` runs inside the timed region
+    behind the last step (e.g. waiting for the side-stream gather)."""
+    for k in range(W):
+        step_fn(k, None)
+    events = []
+    sync_barrier(dev, distributed)
+    t0 = time.perf_counter()
+    for k in range(K):
+        step_fn(k, events)
+    if after is not None:
+        after()
+    sync_barrier(dev, distributed)
+    dt = time.perf_counter() - t0
+    if distributed:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, events
+
+
+def gather_components(outs, recv, rank, dst=0):
+    """The single collective of the path: every component's output spectrum of every rank to rank `dst`.
+    outs: C tensors of this rank; recv: on rank dst, C lists of world-size receive buffers (None elsewhere).  Complex
+    spectra travel as their (re, im) real views (same bytes; every backend supports reals)."""
+    import torch.distributed as dist
+    for c, o in enumerate(outs):
+        src = torch.view_as_real(o) if o.is_complex() else o
+        dist.gather(src, recv[c] if rank == dst else None, dst=dst)
+
+
 def hbm_probe(dev):
     """Measured HBM roofline of this box (device-to-device copy / triad over buffers far larger than the
     256 MB infinity cache).  GB/s of algorithmic bytes: copy moves 2 x, triad 3 x the buffer.  (The stand-alone
@@ -248,8 +292,8 @@ def main():
                 done.record()
                 gather_stream.wait_event(done)
                 with torch.cuda.stream(gather_stream):
-                    for c in range(Cn):     # every component's spectrum (stream-ordered, the host does not block)
-                        dist.gather(torch.view_as_real(out[c]), gather_list[k % 2][c] if rank == 0 else None, dst=0)
+                    # every component's spectrum (stream-ordered, the host does not block)
+                    gather_components(out, gather_list[k % 2] if rank == 0 else None, rank)
                     e = torch.cuda.Event()
                     e.record()
                     gather_done[k % 2] = e
@@ -269,31 +313,11 @@ def main():
             if events is not None:
                 events.append(ev)
 
-        def barrier():
-            torch.cuda.synchronize(dev)
-            if distributed:
-                import torch.distributed as dist
-                dist.barrier()
-            torch.cuda.synchronize(dev)
-
         def timed(step_fn, K, W):
-            for k in range(W):
-                step_fn(k)
-            events = []
-            barrier()
-            t0 = time.perf_counter()
-            for k in range(K):
+            def step(k, events):
                 step_fn(k, events)
-            if use_gather[0]:
-                gather_stream.synchronize()
-            barrier()
-            dt = time.perf_counter() - t0
-            if distributed:
-                import torch.distributed as dist
-                t = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
-            return dt, events
+            return timed_steps(step, K, W, dev, distributed,
+                               after=(gather_stream.synchronize if use_gather[0] else None))
 
         def stage_ms(events, names):
             return {name: float(np.mean([ev[i].elapsed_time(ev[i + 1]) for ev in events])) for i, name in enumerate(names)}
@@ -312,7 +336,7 @@ def main():
             "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt1},
             "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt2,
                       "ms_per_step": dt2 / steps * 1e3},
-            "spread_engine": engine_used,
+            "spread_engine": engine_used, "patch_f32acc": int(info.patch_f32acc), "patch_dims": [int(info.patch_dims[0]), int(info.patch_dims[1])],
             "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
             "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
         }
@@ -331,7 +355,11 @@ def main():
     exec2_ms = st2["deconv_pad"] + st2["fft"] + st2["interp"]
     # the dominant kernel of the step: spreading (one launch per component)
     tname = {"float64": "double", "float32": "float", "complex64": "float", "complex128": "double"}[cfg["Z"]]
-    if head["spread_engine"] == "mfma_patches":
+    if head["spread_engine"] == "mfma_patches" and head["patch_f32acc"]:
+        kname = f"spread_patch32_kernel<{cfg['m']}"
+        binding = ("the FP32 matrix pipe (v_mfma_f32_16x16x4, about half of the kernel) plus the vector work that shares its ALUs "
+                   "(window evaluation, operand products) at one wave per SIMD, not HBM: see DESIGN.md section 4.5")
+    elif head["spread_engine"] == "mfma_patches":
         kname = f"spread_patch_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}"
         binding = ("issue and latency of the per-visit point set-up at 8 waves per CU (VALU 36 %, LDS 44 %, FP64 matrix pipe 16 % "
                    "busy), not HBM: see DESIGN.md section 4.4")
@@ -359,6 +387,10 @@ def main():
         "achieved_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9,
         "frac_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9 / HBM_PEAK_GBS,
         "kernel_ms": st1["spread"],
+        "interp": {"kernel_ms": st2["interp"], "algorithmic_bytes_per_stage": ab["interp_kernel"],
+                   "achieved": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9, "frac": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "traffic": (lambda t: t[0] / 1e9 if t[0] is not None else None)(pmc_traffic("interp_march_kernel", a.config)),
+                   "note": "type-2 gather stage (R(G) + R(points) + W(values)); z-marching LDS ring where the point set is not sliced"},
         "type1_exec_frac": ab["type1_exec"] / (exec1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "type2_exec_frac": ab["type2_exec"] / (exec2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "type1_exec_frac_of_measured_peak": (ab["type1_exec"] / (exec1_ms * 1e-3) / 1e9 / peak_m) if peak_m else None,
@@ -377,7 +409,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"float64": "f64", "float32": "f32", "complex64": "c64 (f32 arithmetic, f64 accumulation)", "complex128": "c128"}[cfg["Z"]],
+        "dtype": {"float64": "f64", "float32": "f32", "complex64": "c64 (f32 arithmetic and accumulation, as the reference)", "complex128": "c128"}[cfg["Z"]],
         "data": "synthetic",
         "config": {
             "workload": f"{cfg['label']}, m={cfg['m']}, sigma={cfg['sigma']} (oversampled {tuple(head['oversampled'])}), "

@@ -47,12 +47,13 @@ struct MarchCfg {
     static constexpr int KL = NUFFT_MARCH_KL;           // bin layers per phase (one barrier pair and one plane fetch per phase)
     static constexpr int BZ = 4 * KL;                   // planes per phase
     static constexpr int RZ = HALO + BZ;                // ring depth
-    // 16 waves per CU leave 128 registers per lane: enough for M <= 5; wider stencils (more window values, coefficients
-    // and rows in flight per lane) spill there, so they run 8 waves with 256 registers each
+    // 16 waves per CU leave 128 registers per lane.  Only Float32 real data at M <= 5 fit them; everything else spilled
+    // its prefetched planes to scratch (measured at C2, Float64: 5.3 GB of memory-side fetches per launch instead of 1.9,
+    // 1.83 ms instead of 1.67), so those run 8 waves with 256 registers each.
 #ifndef NUFFT_MARCH_WIDE_M
 #define NUFFT_MARCH_WIDE_M 6
 #endif
-    static constexpr int THREADS = M >= NUFFT_MARCH_WIDE_M ? 512 : 1024;
+    static constexpr int THREADS = (sizeof(T) == 8 || CPLX || M >= NUFFT_MARCH_WIDE_M) ? 512 : 1024;
     static constexpr int NW = THREADS / kWave;
     // Complex data with at most 16 lanes per stencil row: ONE lane per j1 gathers both components (64- / 128-bit LDS reads,
     // v_pk_fma_f32 for ComplexF32) — half the wave instructions per point of the (j1, component) lane mapping, and the
