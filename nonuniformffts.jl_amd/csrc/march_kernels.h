@@ -77,6 +77,8 @@ struct MarchCfg {
             for (int n1 = 4; n1 <= 64; n1 += 4) {
                 const long bytes = (long)NC * (n1 + HALO) * (n2 + HALO) * RZ * (long)sizeof(T) + fixed_bytes();
                 if (bytes > 163840 - 256) continue;
+                // registers of the per-thread plane prefetch (the planes of the next layer are in flight during the gather)
+                if (((long)BZ * NC * (n1 + HALO) * (n2 + HALO) + THREADS - 1) / THREADS * (long)(sizeof(T) / 4) > 32) continue;
                 double cost = (double)(n1 + HALO) / n1 * (double)(n2 + HALO) / n2;
                 // columns whose edge divides the common power-of-two grid sizes leave no partial column
                 if (512 % n1) cost *= 1.03;
@@ -259,10 +261,13 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
                 T w2[L];
 #pragma unroll
                 for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
-                if constexpr (L <= 8) {
+                // rows per group of the hand-scheduled form (0: compiler-scheduled reads): what compiles without spills
+                constexpr int R = L <= 8 ? ((CPLX || C::THREADS != 512) ? 2 : 4) : (L % 8 == 0 ? 8 : (L % 4 == 0 ? 4 : 0));
+                if constexpr (R > 0) {
                 // hand-scheduled LDS reads (as in interp_tile_kernel): groups of R rows with immediate offsets from the
                 // plane's own address (the ring wraps between planes), the next group in flight while this one is consumed
-                constexpr int R = 2, GPP = L / R, NG = L * GPP, RB = RS * (int)sizeof(T);      // (larger groups spill: 128 registers at 16 waves per CU)
+                constexpr int GPP = L / R, NG = L * GPP, RB = RS * (int)sizeof(T);
+
                 const uint32_t a0 = (uint32_t)(uintptr_t)base;
                 VT buf[2][R];
                 lds_read_rows<VT, R, 0, RB>(buf[0], a0 + (uint32_t)poff * (uint32_t)sizeof(T), std::make_integer_sequence<int, R>{});
