@@ -35,6 +35,9 @@ namespace nufft {
 // (AGPRs) — not all 256: the register allocator needs slack there, or it parks accumulators in vector registers and moves
 // them around the inline-assembly matrix instructions, which is a read-after-issue hazard (scripts/lint_patch32_isa.py
 // fails the build on it) — and in vector registers next to the working set.
+#ifndef NUFFT_PATCH32_OCC
+#define NUFFT_PATCH32_OCC 1             // waves per SIMD the kernel is compiled for (2: A/B builds, half the registers and LDS each)
+#endif
 #ifndef NUFFT_PATCH32_AGPRS
 #define NUFFT_PATCH32_AGPRS 224
 #endif
@@ -83,7 +86,7 @@ struct Patch32Cfg {
     static constexpr int STAGE_PT = 16;                 // staged cell fractions (3 floats + pad)
     // points per chunk: one wave per SIMD = one workgroup of four waves per CU with 160 KiB
     static constexpr int chunk_points() {
-        const int budget = (160 * 1024 - 512 - table_bytes()) / kPatchWaves;
+        const int budget = (160 * 1024 / NUFFT_PATCH32_OCC - 512 - table_bytes()) / kPatchWaves;
         for (int ch = 64; ch > 16; ch -= 8)
             if ((ch + 1) * PSTRIDE + ch * STAGE_PT + 32 <= budget) return ch;
         return 16;
@@ -138,7 +141,7 @@ __device__ __forceinline__ void lds_read_clamped32(float (&w)[N], uint32_t base,
 }
 
 template <int M, bool OTHERK>
-__global__ __launch_bounds__(kPatchWaves * kWave, 1) void spread_patch32_kernel(PatchArgs<float> a) {
+__global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread_patch32_kernel(PatchArgs<float> a) {
     using T = float;
     using P = Patch32Cfg<M>;
     constexpr int L = P::L, CLO = P::CLO, CHI = P::CHI, NCB = P::NCB, NOB = P::NOB, PBX = P::PBX, PBY = P::PBY, NRB = P::NRB;

@@ -7,6 +7,7 @@
 #include "tile_kernels.h"
 #include "patch_kernels.h"
 #include "march_kernels.h"
+#include "patch32_kernels.h"
 
 namespace nufft {
 
@@ -259,7 +260,7 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
     pp.ntasks = cols * pp.nseg;
     pp.lds_bytes = lds;
     pp.pby = pby;
-    pp.occ = f32acc ? 1 : patch_occupancy(is_complex ? 2 : 1, M);
+    pp.occ = f32acc ? NUFFT_PATCH32_OCC : patch_occupancy(is_complex ? 2 : 1, M);
     pp.f32acc = f32acc ? 1 : 0;
     pp.eligible = true;
     return pp;
