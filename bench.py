@@ -336,7 +336,7 @@ def main():
             "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt1},
             "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt2,
                       "ms_per_step": dt2 / steps * 1e3},
-            "spread_engine": engine_used, "patch_f32acc": int(info.patch_f32acc), "patch_dims": [int(info.patch_dims[0]), int(info.patch_dims[1])],
+            "spread_engine": engine_used, "patch_f32acc": int(info.patch_f32acc), "patch_dims": [int(info.patch_dims[0]), int(info.patch_dims[1])], "patch_planar": int(info.patch_planar),
             "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
             "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
         }
@@ -360,7 +360,7 @@ def main():
         binding = ("the FP32 matrix pipe (v_mfma_f32_16x16x4, about half of the kernel) plus the vector work that shares its ALUs "
                    "(window evaluation, operand products) at one wave per SIMD, not HBM: see DESIGN.md section 4.5")
     elif head["spread_engine"] == "mfma_patches":
-        kname = f"spread_patch_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}"
+        kname = f"spread_patch_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, false, {head['patch_planar']}>"
         binding = ("issue and latency of the per-visit point set-up at 8 waves per CU (VALU 36 %, LDS 44 %, FP64 matrix pipe 16 % "
                    "busy), not HBM: see DESIGN.md section 4.4")
     else:
@@ -374,7 +374,7 @@ def main():
     achieved = ab["spread_kernel"] / spread_s / 1e9
     roofline = {
         "bound": "hbm",
-        "kernel": kname + ", ...> (the zero + spread stage: one launch, gridDim.y = C = %d components)" % Cn,
+        "kernel": kname + ("" if kname.endswith(">") else ", ...>") + " (the zero + spread stage of the C = %d component(s))" % Cn,
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "peak_measured": peak_m, "frac_of_measured_peak": (achieved / peak_m) if peak_m else None,
         "traffic": (traffic_b / 1e9) if traffic_b is not None else None,

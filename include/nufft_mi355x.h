@@ -141,6 +141,8 @@ typedef struct nufft_info {
     int32_t patch_dims[2];   /* MFMA patches: cube columns (of 4 x 4 cells) a wave owns along dimensions 1, 2; 0 otherwise */
     int32_t patch_f32acc;    /* MFMA patches: 1 = ComplexF32 on v_mfma_f32_16x16x4 with Float32 accumulators (the reference's
                                 accumulation type, src/spreading/gpu.jl:271-283), 0 = v_mfma_f64_4x4x4 with Float64 ones  */
+    int32_t patch_planar;    /* MFMA patches: real plans with ntransforms = 2 / 3 spread that many components together (shared window
+                                evaluation and operands — the reference's TODO at src/spreading/gpu.jl:293); 0 = one at a time    */
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */

@@ -103,13 +103,18 @@ struct PatchPlan {
     int pby;                            // rows of cube columns per patch
     int occ;                            // waves per SIMD the kernel is compiled for
     int f32acc;                         // ComplexF32 on the FP32 matrix pipe with Float32 accumulators (patch32_kernels.h)
+    int planar;                         // real plans with ntransforms = 2 / 3: that many components spread together (0: one at a time)
 };
 // allow_f32acc: ComplexF32 plans may take the FP32-matrix-pipe kernel where the grid allows it (octets along dimension 3)
-PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc = true);
+// planar_nc: ntransforms of a real plan whose components may be spread together (2 or 3; 0 = one component per launch)
+PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc = true, int planar_nc = 0);
 // set_points: decides on the device which engine serves this point set (balance.hip); choice = uint32[4], zeroed once
 hipError_t launch_patch_choice(const Geom& g, const PatchPlan& pp, int pby, const uint32_t* offsets, int64_t np, int wave_slots,
                                uint32_t* choice, uint32_t* slots_in_use, hipStream_t stream);
-hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other);
+hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other, int planar_nc = 0);
+// all C value vectors of a real plan gathered into one interleaved buffer vout[p * C + c] (planar patch kernel)
+hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np, const void* const* vin, int C,
+                                const void* weights, void* vout, const uint32_t* enabled, hipStream_t stream);
 // vsorted: C value vectors in sorted order (launch_gather_values), vstride_reals reals apart
 // enabled: device flag (null: always run); both kernels return at once when *enabled == 0
 hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,

@@ -115,7 +115,7 @@ struct nufft_plan {
     int spread_method_req = NUFFT_SPREAD_AUTO;    // what the caller asked for
     struct Patch {                                // decomposition of the MFMA-patch spreading (patch_kernels.h)
         bool eligible = false;
-        int npx = 0, npy = 0, nseg = 0, segl = 0, ntasks = 0, lds_bytes = 0, pby = 0, occ = 2, f32acc = 0;
+        int npx = 0, npy = 0, nseg = 0, segl = 0, ntasks = 0, lds_bytes = 0, pby = 0, occ = 2, f32acc = 0, planar = 0;
     } patch;
     uint32_t* d_patch_choice = nullptr;   // [4]: scratch of patch_choice_kernel; [2] = 1: this point set is spread by the patches
     int wave_slots = 2048;             // resident waves of the patch kernel on this device (CUs x 4 SIMDs x its waves per SIMD)

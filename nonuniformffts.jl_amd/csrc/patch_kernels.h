@@ -50,18 +50,20 @@ namespace nufft {
 // 5.8 ms, m = 5 11.5 vs 10.9, m = 6 19.3 vs 18.0, m = 7 20.5 vs 18.0 (with the larger chunks); Float64 m = 7 11.9 vs 12.8,
 // m = 8 11.4 vs 12.1, m = 9 18.5 vs 21.2, m = 10 39.3 vs 29.4; C3 (ComplexF32, m = 8) 168 vs 136 ms.
 // NUFFT_PATCH_ACC_CAP / NUFFT_PATCH_OCC override both for every instantiation (ablation builds).
+// (three components — real plans with ntransforms = 3, below — always take the large configuration: with 48 accumulators
+// their patch would be a single row of cube columns.)
 constexpr __host__ __device__ int patch_acc_cap(int ncomp, int M) {
 #if defined(NUFFT_PATCH_ACC_CAP)
     return NUFFT_PATCH_ACC_CAP;
 #else
-    return ((ncomp == 2 && M >= 5) || M >= 10) ? 120 : 48;
+    return ((ncomp == 2 && M >= 5) || M >= 10 || ncomp >= 3) ? 120 : 48;
 #endif
 }
 constexpr __host__ __device__ int patch_occupancy(int ncomp, int M) {
 #if defined(NUFFT_PATCH_OCC)
     return NUFFT_PATCH_OCC;
 #else
-    return ((ncomp == 2 && M >= 5) || M >= 10) ? 1 : 2;
+    return ((ncomp == 2 && M >= 5) || M >= 10 || ncomp >= 3) ? 1 : 2;
 #endif
 }
 
@@ -73,7 +75,11 @@ constexpr __host__ __device__ int patch_rows(int ncomp, int ncb, int cap) {
     return r < 1 ? 1 : (r > 4 ? 4 : r);
 }
 
-template <int NC, int M>
+// NC components per point: 1 (real), 2 (complex, interleaved in values and grid) — or, PL = planar, the NC = ntransforms
+// separate real value vectors / grids of a real plan spread TOGETHER: the window evaluation, the operand set-up and the
+// A = w1 w2 operand are shared, only B = v_c w3 and the accumulators are per component (the reference re-evaluates the
+// windows per component, TODO at src/spreading/gpu.jl:293 / src/interpolation/gpu.jl:273).
+template <int NC, int M, bool PL = false>
 struct PatchCfg {
     static constexpr int L = 2 * M;
     static constexpr int CLO = floor_div4(1 - M);      // cubes a stencil reaches relative to the bin of its point
@@ -95,16 +101,16 @@ struct PatchCfg {
         const int occ = patch_occupancy(NC, M);
         const int budget = (occ == 1 ? 160 : 80) * 1024 - 512;
         for (int ch = (occ == 1 ? 64 : 32); ch > 16; ch -= 8)
-            if (4 * ((ch + 1) * (3 * LW * 8 + 32) + ch * 48 + 32) + 3 * (M + 4) * L * 8 + 64 <= budget) return ch;
+            if (4 * ((ch + 1) * (3 * LW * 8 + META) + ch * 48 + 32) + 3 * (M + 4) * L * 8 + 64 <= budget) return ch;
         return 16;
     }
+    static constexpr int META = round_up(16 + 8 * NC, 16) < 32 ? 32 : round_up(16 + 8 * NC, 16);   // bytes: {sx, offy, offz, rbx} + NC values
     static constexpr int CH = chunk_points();
-    static constexpr int META = 32;                     // bytes: {sx, offy, offz, rbx} + value (re, im)
     static constexpr int PSTRIDE = 3 * LW * 8 + META;   // bytes per staged point
     static constexpr int WBYTES = (CH + 1) * PSTRIDE;   // + the all-zero point
-    static constexpr int ROWLEN = 16 * NC + 2;          // reals per row of the transposition buffer (+2: banks)
+    static constexpr int ROWLEN = (PL ? 16 : 16 * NC) + 2;   // reals per row of the transposition buffer (+2: banks); planar: one component at a time
     static constexpr int TBYTES = 4 * 4 * PBY * ROWLEN * 8;
-    static constexpr int STAGE_PT = 32 + 16;            // staged record (3 coordinates as double + pad) + value
+    static constexpr int STAGE_PT = 32 + 16;            // staged record (3 coordinates as double + pad)
     static constexpr int WAVE_BYTES = round_up((WBYTES > TBYTES ? WBYTES : TBYTES), 16) + round_up(CH * STAGE_PT, 16);
     static constexpr int NPOLY = M + 4;                 // coefficients per sub-interval (src/Kernels/kaiser_bessel_backwards.jl:98)
     static_assert(PADB >= 1 && PADA >= 1, "padding");
@@ -118,6 +124,9 @@ struct PatchGeom {
     int npx, npy, nseg, segl;       // patch columns, segments along dimension 3, cube layers per segment
     int ntasks;
 };
+
+template <typename T>
+struct PlanarPtrs { const T* p[4]; };
 
 template <typename T>
 struct PatchArgs {
@@ -149,6 +158,22 @@ __global__ __launch_bounds__(256) void gather_values_kernel(const unsigned char*
     }
 }
 
+// Planar components (ntransforms = NC real value vectors): vs[p * NC + c] = v_c[idx[p]] — one interleaved buffer, so that
+// the patch kernel prefetches the NC values of a point with one access pattern
+template <typename T, int NC, int REC_BYTES>
+__global__ __launch_bounds__(256) void gather_planar_kernel(const unsigned char* __restrict__ recs, int idx_off, int64_t np,
+                                                           PlanarPtrs<T> vin, const T* __restrict__ weights, T* __restrict__ vout,
+                                                           const uint32_t* __restrict__ enabled) {
+    if (enabled && *enabled == 0u) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += stride) {
+        const int32_t idx = *reinterpret_cast<const int32_t*>(recs + p * REC_BYTES + idx_off);
+        const T w = weights ? weights[idx] : T(1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) vout[p * NC + c] = vin.p[c][idx] * w;
+    }
+}
+
 // Window values of cube columns 0 .. N-1 of dimension 1: w[cx] = row[clamp(t8 / 8 + 4 cx, -1, L)] with `base` the LDS
 // byte address of row[0] and t8 = 8 (lane coordinate - stencil start); row[-1] and row[L] are padding zeros.
 // v_med3 clamps t8 against bounds shifted by the column, the column offset itself is the immediate of the read.
@@ -170,10 +195,12 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
-template <typename T, bool CPLX, int M, bool OTHERK>
-__global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, M)) void spread_patch_kernel(PatchArgs<T> a) {
-    constexpr int NC = CPLX ? 2 : 1;
-    using P = PatchCfg<NC, M>;
+template <typename T, bool CPLX, int M, bool OTHERK, int NP = 0>
+__global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : (CPLX ? 2 : 1), M)) void spread_patch_kernel(PatchArgs<T> a) {
+    constexpr bool PLANAR = NP > 0;                    // NP real components spread together (comp_id 0 carries all of them)
+    static_assert(!PLANAR || !CPLX, "planar components are real");
+    constexpr int NC = PLANAR ? NP : (CPLX ? 2 : 1);
+    using P = PatchCfg<NC, M, PLANAR>;
     constexpr int L = P::L, CLO = P::CLO, CHI = P::CHI, NCB = P::NCB, PBX = P::PBX, PBY = P::PBY, NRB = P::NRB;
     constexpr int PADB = P::PADB, LW = P::LW, CH = P::CH, PSTRIDE = P::PSTRIDE;
     constexpr int WX = 0, WY = LW * 8, WZ = 2 * LW * 8, MT = 3 * LW * 8;      // byte offsets inside a staged point
@@ -312,7 +339,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, 
             m.w = (sx + (M - 1)) >> 2;                                 // bin of the point relative to the patch
             unsigned char* pw = wmem + lane * PSTRIDE + MT;
             *reinterpret_cast<int4*>(pw) = m;
-            *reinterpret_cast<double2*>(pw + 16) = make_double2((double)pf_v[0], NC == 2 ? (double)pf_v[NC - 1] : 0.0);
+            *reinterpret_cast<double2*>(pw + 16) = make_double2((double)pf_v[0], NC >= 2 ? (double)pf_v[NC >= 2 ? 1 : 0] : 0.0);
+            if constexpr (NC >= 3) *reinterpret_cast<double*>(pw + 32) = (double)pf_v[NC >= 3 ? 2 : 0];
         }
     };
 
@@ -324,35 +352,43 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, 
             double* tb = reinterpret_cast<double*>(wmem);
             // D layout of v_mfma_f64_4x4x4_4b: lane 16 i + 4 b + j holds cell (x = i, y = b, z = j) of the cube
             const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
+            // interleaved components (complex) leave in one round; planar ones (separate grids) one component per round
+            constexpr int NR = PLANAR ? NC : 1;            // rounds
+            constexpr int NI = PLANAR ? 1 : NC;            // components interleaved within a round
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int rd = 0; rd < NR; ++rd) {
+                if (rd > 0) wave_lds_fence();
 #pragma unroll
-                for (int y = 0; y < PBY; ++y)
+                for (int c = 0; c < NI; ++c)
 #pragma unroll
-                    for (int x = 0; x < PBX; ++x)
-                        tb[(dj * (4 * PBY) + 4 * y + db) * P::ROWLEN + (4 * x + di) * NC + c] = acc[c][0][y][x];
-            wave_lds_fence();
-            // rows of 16 NC reals: 8 lanes per row (2 NC reals each), 8 rows per wave instruction
-            constexpr int NROWS = 4 * 4 * PBY;
-            const int sub = lane >> 3, e0 = (lane & 7) * 2 * NC;
-            const int nxr = ncx * 4 * NC, nyr = ncy * 4;
+                    for (int y = 0; y < PBY; ++y)
 #pragma unroll
-            for (int r0 = 0; r0 < NROWS; r0 += 8) {
-                const int row = r0 + sub;
-                const int pl = row / (4 * PBY), yy = row % (4 * PBY);
-                if (yy < nyr && e0 < nxr) {
-                    const double* src = tb + row * P::ROWLEN + e0;
-                    const int64_t gz = (int64_t)cz * 4 + pl, gy = (int64_t)by0 * 4 + yy;
-                    T* dst = grid + ((gz * g.Nover[1] + gy) * g.Nover[0] + X0) * NC + e0;
-                    if constexpr (NC == 1) {
-                        if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(src[0], src[1]);
-                        else *reinterpret_cast<float2*>(dst) = make_float2((float)src[0], (float)src[1]);
-                    } else {
-                        if constexpr (sizeof(T) == 8) {
-                            reinterpret_cast<double2*>(dst)[0] = make_double2(src[0], src[1]);
-                            reinterpret_cast<double2*>(dst)[1] = make_double2(src[2], src[3]);
+                        for (int x = 0; x < PBX; ++x)
+                            tb[(dj * (4 * PBY) + 4 * y + db) * P::ROWLEN + (4 * x + di) * NI + c] = acc[PLANAR ? rd : c][0][y][x];
+                wave_lds_fence();
+                // rows of 16 NI reals: 8 lanes per row (2 NI reals each), 8 rows per wave instruction
+                constexpr int NROWS = 4 * 4 * PBY;
+                const int sub = lane >> 3, e0 = (lane & 7) * 2 * NI;
+                const int nxr = ncx * 4 * NI, nyr = ncy * 4;
+                T* gr = PLANAR ? a.t.grid[rd] : grid;
+#pragma unroll
+                for (int r0 = 0; r0 < NROWS; r0 += 8) {
+                    const int row = r0 + sub;
+                    const int pl = row / (4 * PBY), yy = row % (4 * PBY);
+                    if (yy < nyr && e0 < nxr) {
+                        const double* src = tb + row * P::ROWLEN + e0;
+                        const int64_t gz = (int64_t)cz * 4 + pl, gy = (int64_t)by0 * 4 + yy;
+                        T* dst = gr + ((gz * g.Nover[1] + gy) * g.Nover[0] + X0) * NI + e0;
+                        if constexpr (NI == 1) {
+                            if constexpr (sizeof(T) == 8) *reinterpret_cast<double2*>(dst) = make_double2(src[0], src[1]);
+                            else *reinterpret_cast<float2*>(dst) = make_float2((float)src[0], (float)src[1]);
                         } else {
-                            *reinterpret_cast<float4*>(dst) = make_float4((float)src[0], (float)src[1], (float)src[2], (float)src[3]);
+                            if constexpr (sizeof(T) == 8) {
+                                reinterpret_cast<double2*>(dst)[0] = make_double2(src[0], src[1]);
+                                reinterpret_cast<double2*>(dst)[1] = make_double2(src[2], src[3]);
+                            } else {
+                                *reinterpret_cast<float4*>(dst) = make_float4((float)src[0], (float)src[1], (float)src[2], (float)src[3]);
+                            }
                         }
                     }
                 }
@@ -404,7 +440,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, 
         typedef int v4i __attribute__((ext_vector_type(4)));
         typedef double v2d __attribute__((ext_vector_type(2)));
         v4i m;                       // {sx, byte offset dim 2, byte offset dim 3, bin along dim 1 relative to the patch}
-        v2d vv;                      // value (re, im)
+        v2d vv;                      // value (re, im) / components 0, 1
+        double v3 = 0.0, v3n = 0.0;  // component 2 (planar, NC = 3)
         double w3[NCB], w2[NCB], w1[PBX];
         double vre = 0.0, vim = 0.0;
         uint32_t cxmask = 0u;                                          // cube columns the batch can touch
@@ -413,6 +450,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, 
             const uint32_t ad = wbase + (uint32_t)(pidx * PSTRIDE + MT);
             asm volatile("ds_read_b128 %0, %1" : "=v"(m) : "v"(ad));
             asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(vv) : "v"(ad));
+            if constexpr (NC >= 3) asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(v3n) : "v"(ad));
         };
         // operands of the batch whose meta data has arrived in (m, vv)
         auto issue_ops = [&](int b0) __attribute__((always_inline)) {
@@ -429,6 +467,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, 
 #endif
             }
             vre = vv.x; vim = vv.y;
+            if constexpr (NC >= 3) v3 = v3n;
             // dimension 3: ring slot s <-> cube offset CLO + s; dimension 2: cube offset CLO + o (static offsets from
             // one address each); dimension 1: the window index is clamped into the zero padding
             lds_read_rows<double, NCB, 0, 32>(w3, pb + WZ + (uint32_t)m.z + (uint32_t)mi * 8, std::make_integer_sequence<int, NCB>{});
@@ -440,6 +479,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, 
         auto wait_all = [&]() __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(m), "+v"(vv));
+            if constexpr (NC >= 3) asm volatile("" : "+v"(v3n));
 #pragma unroll
             for (int s = 0; s < NCB; ++s) asm volatile("" : "+v"(w3[s]), "+v"(w2[s]));
 #pragma unroll
@@ -459,7 +499,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(CPLX ? 2 : 1, 
 #pragma unroll
             for (int s = 0; s < NCB; ++s) {
                 bz_[0][s] = w3[s] * vre;
-                if constexpr (NC == 2) bz_[NC - 1][s] = w3[s] * vim;
+                if constexpr (NC >= 2) bz_[NC >= 2 ? 1 : 0][s] = w3[s] * vim;
+                if constexpr (NC >= 3) bz_[NC >= 3 ? 2 : 0][s] = w3[s] * v3;
             }
 #pragma unroll
             for (int o = 0; o < NCB; ++o)

@@ -334,17 +334,21 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         if (req < NUFFT_SPREAD_AUTO || req > NUFFT_SPREAD_MFMA_PATCHES) return fail(NUFFT_ERR_INVALID_ARG, "unknown spread_method");
         p->spread_method_req = req;
         // NUFFT_PATCH_F32ACC=0: ComplexF32 plans keep the Float64-accumulating patch kernel (A/B runs)
+        // NUFFT_PATCH_PLANAR=0: the components of a real plan with ntransforms = 2 / 3 are spread one after the other (A/B runs)
+        const int planar_nc = (!p->is_complex && (p->C == 2 || p->C == 3) && env_int("NUFFT_PATCH_PLANAR", 1) != 0) ? p->C : 0;
         const PatchPlan pp = patch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode),
-                                        env_int("NUFFT_PATCH_F32ACC", 1) != 0);
+                                        env_int("NUFFT_PATCH_F32ACC", 1) != 0, planar_nc);
         p->patch.eligible = pp.eligible;
         p->patch.npx = pp.npx; p->patch.npy = pp.npy; p->patch.nseg = pp.nseg; p->patch.segl = pp.segl;
-        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes; p->patch.pby = pp.pby; p->patch.occ = pp.occ; p->patch.f32acc = pp.f32acc;
+        p->patch.ntasks = pp.ntasks; p->patch.lds_bytes = pp.lds_bytes; p->patch.pby = pp.pby; p->patch.occ = pp.occ; p->patch.f32acc = pp.f32acc; p->patch.planar = pp.planar;
         if (req == NUFFT_SPREAD_MFMA_PATCHES && !pp.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = MFMA patches needs a 3-D grid of 4-cell bins with every oversampled "
                                                "axis a multiple of 4 and at least 2 (patch + stencil) bins long, and the default window evaluation");
         // automatic choice, from the measurements in DESIGN.md section 4.4: the patches win where the stencil carries
         // more matrix work per point visit (complex data, M >= 5: 1.15x ... 2x), the LDS tiles for real data at M <= 4
-        const bool prefer_patches = p->is_complex || p->M >= 5 || env_int("NUFFT_PREFER_PATCHES", 0) != 0;     // (the switch: test runs)
+        // — and for real plans with ntransforms = 2 / 3, whose components the patches spread together (shared windows and operands:
+        // C4 9.1 -> 7.5 ms, two components 6.1 -> 5.2 ms)
+        const bool prefer_patches = p->is_complex || p->M >= 5 || pp.planar != 0 || env_int("NUFFT_PREFER_PATCHES", 0) != 0;     // (the switch: test runs)
         p->spread_method = (pp.eligible && (req == NUFFT_SPREAD_MFMA_PATCHES || (req == NUFFT_SPREAD_AUTO && prefer_patches)))
                                ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
     }
@@ -527,7 +531,7 @@ static int build_device(nufft_plan* p) {
     if (p->interp_march) NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M));
 
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
-        NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false));
+        NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false, p->patch.planar));
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 4 * sizeof(uint32_t)))) return rc;
         NUFFT_HIP(hipMemset(p->d_patch_choice, 0, 4 * sizeof(uint32_t)));
         hipDeviceProp_t prop;
@@ -902,6 +906,7 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->patch_dims[0] = patches ? 4 : 0;
     o->patch_dims[1] = patches ? p->patch.pby : 0;
     o->patch_f32acc = patches ? p->patch.f32acc : 0;
+    o->patch_planar = patches ? p->patch.planar : 0;
     return NUFFT_OK;
 }
 
@@ -1000,7 +1005,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         PatchPlan pp{};
         pp.eligible = true;
         pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
-        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc;
+        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc; pp.planar = p->patch.planar;
         const int slots = p->spread_method_req == NUFFT_SPREAD_MFMA_PATCHES ? 1 : p->wave_slots;    // explicit request: always the patches
         NUFFT_HIP(launch_patch_choice(s.g, pp, p->patch.pby, p->d_offsets, np, slots, p->d_patch_choice, p->bal.d_slots, stream));
     }
@@ -1058,13 +1063,16 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
         // values gathered into sorted order (per-point weights of the callback menu folded in), then the patches
         const uint32_t* enabled = p->d_patch_choice + 2;
         const int64_t vstride = p->Np * (p->is_complex ? 2 : 1);
-        for (int c = 0; c < p->C; ++c)
-            NUFFT_HIP(launch_gather_values(p->dtype, p->is_complex, p->D, p->d_sorted, p->Np, values_in[c], p->cb_point_weights,
-                                           static_cast<char*>(p->d_vsorted) + (size_t)c * vstride * real_bytes(p), enabled, stream));
+        if (p->patch.planar)
+            NUFFT_HIP(launch_gather_planar(p->dtype, p->D, p->d_sorted, p->Np, values_in, p->C, p->cb_point_weights, p->d_vsorted, enabled, stream));
+        else
+            for (int c = 0; c < p->C; ++c)
+                NUFFT_HIP(launch_gather_values(p->dtype, p->is_complex, p->D, p->d_sorted, p->Np, values_in[c], p->cb_point_weights,
+                                               static_cast<char*>(p->d_vsorted) + (size_t)c * vstride * real_bytes(p), enabled, stream));
         PatchPlan pp{};
         pp.eligible = true;
         pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
-        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc;
+        pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc; pp.planar = p->patch.planar;
         NUFFT_HIP(launch_spread_patch(a, pp, p->d_vsorted, vstride, enabled, stream));
     }
     return NUFFT_OK;

@@ -218,6 +218,11 @@ const void* patch_kernel_f64r(int M, bool other, int* lds_bytes, int* pby);
 const void* patch_kernel_f64c(int M, bool other, int* lds_bytes, int* pby);
 
 const void* patch32_kernel_f32c(int M, bool other, int* lds_bytes, int* pby);
+const void* patch_planar_kernel_f32r(int NP, int M, int* lds_bytes, int* pby);
+const void* patch_planar_kernel_f64r(int NP, int M, int* lds_bytes, int* pby);
+static const void* patch_planar_kernel(int dtype, int NP, int M, int* lds_bytes, int* pby) {
+    return dtype == NUFFT_F32 ? patch_planar_kernel_f32r(NP, M, lds_bytes, pby) : patch_planar_kernel_f64r(NP, M, lds_bytes, pby);
+}
 
 static const void* patch_kernel(int dtype, int is_complex, int M, bool other, int* lds_bytes, int* pby) {
     if (dtype == NUFFT_F32) return is_complex ? patch_kernel_f32c(M, other, lds_bytes, pby) : patch_kernel_f32r(M, other, lds_bytes, pby);
@@ -227,10 +232,16 @@ static const void* patch_kernel(int dtype, int is_complex, int M, bool other, in
 // Patch decomposition of a plan, or eligible = false: 3-D grids of 4-cell bins whose axes are multiples of the bin
 // edge and long enough that the bins a patch visits are distinct and a stencil cannot reach a patch from both
 // sides; default window evaluation without per-point weights (those use the LDS-tile kernel).
-PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc) {
+PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc, int planar_nc) {
     PatchPlan pp{};
     int lds = 0, pby = 0;
     if (D != 3 || !patch_kernel(dtype, is_complex, M, other, &lds, &pby)) return pp;
+    // real plans with ntransforms = 2 / 3: the components together (shared windows and operands), where that kernel exists
+    int planar = 0;
+    if (!is_complex && !other && (planar_nc == 2 || planar_nc == 3)) {
+        int ldsp = 0, pbyp = 0;
+        if (patch_planar_kernel(dtype, planar_nc, M, &ldsp, &pbyp)) { planar = planar_nc; lds = ldsp; pby = pbyp; }
+    }
     const int clo = floor_div4(1 - M), chi = floor_div4(3 + M), ncb = chi - clo + 1;
     // ComplexF32: the FP32 matrix pipe with Float32 accumulators (octets of 8 planes: dimension 3 a multiple of 8), if its
     // larger patch still fits the grid; the Float64-accumulating kernel otherwise
@@ -260,14 +271,20 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
     pp.ntasks = cols * pp.nseg;
     pp.lds_bytes = lds;
     pp.pby = pby;
-    pp.occ = f32acc ? NUFFT_PATCH32_OCC : patch_occupancy(is_complex ? 2 : 1, M);
+    pp.occ = f32acc ? NUFFT_PATCH32_OCC : patch_occupancy(planar ? planar : (is_complex ? 2 : 1), M);
     pp.f32acc = f32acc ? 1 : 0;
+    pp.planar = planar;
     pp.eligible = true;
     return pp;
 }
 
-hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other) {
+hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other, int planar_nc) {
     int lds = 0, pby = 0;
+    if (planar_nc) {
+        const void* pf = patch_planar_kernel(dtype, planar_nc, M, &lds, &pby);
+        if (!pf) return hipErrorInvalidValue;
+        return hipFuncSetAttribute(pf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
     const void* fn = patch_kernel(dtype, is_complex, M, other, &lds, &pby);
     if (!fn) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -281,14 +298,19 @@ template <typename T>
 static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
                                  const uint32_t* enabled, hipStream_t stream) {
     int lds = 0, pby = 0;
-    const void* fn = pp.f32acc ? patch32_kernel_f32c(a.M, false, &lds, &pby) : patch_kernel(a.dtype, a.is_complex, a.M, false, &lds, &pby);
+    const void* fn = pp.planar ? patch_planar_kernel(a.dtype, pp.planar, a.M, &lds, &pby)
+                   : (pp.f32acc ? patch32_kernel_f32c(a.M, false, &lds, &pby) : patch_kernel(a.dtype, a.is_complex, a.M, false, &lds, &pby));
     if (!fn) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
-        const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
+        int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         PatchArgs<T> k{};
         k.t = fill_tile_args<T>(a, c0, nc);
         k.pg.npx = pp.npx; k.pg.npy = pp.npy; k.pg.nseg = pp.nseg; k.pg.segl = pp.segl; k.pg.ntasks = pp.ntasks;
         for (int c = 0; c < nc; ++c) k.vsorted[c] = static_cast<const T*>(vsorted) + (int64_t)(c0 + c) * vstride_reals;
+        if (pp.planar) {                 // all components in one launch: vsorted is one interleaved buffer, gridDim.y = 1
+            k.vsorted[0] = static_cast<const T*>(vsorted);
+            nc = 1;
+        }
         k.prof = nullptr;
         k.enabled = enabled;
 #if defined(NUFFT_PATCH_PROFILE)
@@ -348,6 +370,36 @@ hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* so
                                               : gather_t<float, 1>(D, sorted, np, vin, weights, vout, enabled, stream);
     return is_complex ? gather_t<double, 2>(D, sorted, np, vin, weights, vout, enabled, stream)
                       : gather_t<double, 1>(D, sorted, np, vin, weights, vout, enabled, stream);
+}
+
+template <typename T, int NC>
+static hipError_t gather_planar_t(int D, const void* sorted, int64_t np, const void* const* vin, const void* weights, void* vout,
+                                  const uint32_t* enabled, hipStream_t stream) {
+    if (np <= 0) return hipSuccess;
+    const int rec_bytes = (int)sizeof(T) * D + 4 > 16 ? 32 : ((int)sizeof(T) * D + 4 > 8 ? 16 : 8);
+    const int idx_off = D * (int)sizeof(T);
+    int64_t blocks = (np + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    PlanarPtrs<T> pv{};
+    for (int c = 0; c < NC; ++c) pv.p[c] = static_cast<const T*>(vin[c]);
+    const unsigned char* r = static_cast<const unsigned char*>(sorted);
+    const T* w = static_cast<const T*>(weights);
+    T* vo = static_cast<T*>(vout);
+    switch (rec_bytes) {
+        case 8: hipLaunchKernelGGL((gather_planar_kernel<T, NC, 8>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, pv, w, vo, enabled); break;
+        case 16: hipLaunchKernelGGL((gather_planar_kernel<T, NC, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, pv, w, vo, enabled); break;
+        default: hipLaunchKernelGGL((gather_planar_kernel<T, NC, 32>), dim3((unsigned)blocks), dim3(256), 0, stream, r, idx_off, np, pv, w, vo, enabled); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np, const void* const* vin, int C,
+                                const void* weights, void* vout, const uint32_t* enabled, hipStream_t stream) {
+    if (C == 2) return dtype == NUFFT_F32 ? gather_planar_t<float, 2>(D, sorted, np, vin, weights, vout, enabled, stream)
+                                          : gather_planar_t<double, 2>(D, sorted, np, vin, weights, vout, enabled, stream);
+    if (C == 3) return dtype == NUFFT_F32 ? gather_planar_t<float, 3>(D, sorted, np, vin, weights, vout, enabled, stream)
+                                          : gather_planar_t<double, 3>(D, sorted, np, vin, weights, vout, enabled, stream);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream) {

@@ -9,7 +9,9 @@ assembly, which the compiler's hazard recogniser does not see):
      s_waitcnt lgkmcnt(0) (linear scan over the code layout: the kernels wait at the end of the block that issued);
   4. reports scratch instructions per kernel (informative).
 
-usage: lint_patch32_isa.py file.s   (from hipcc --cuda-device-only -S).  Exit code 1 on a violation.
+usage: lint_patch32_isa.py file.s [--reads-only]   (from hipcc --cuda-device-only -S).  Exit code 1 on a violation.
+--reads-only: the kernels of the file issue their matrix instructions through the compiler's builtin (which pads and
+orders them itself): only check 3 applies (spread_patch_kernel of patch_kernels.h: its operand reads are inline assembly).
 """
 import re
 import sys
@@ -35,10 +37,11 @@ def operands(line):
     return parts[0], [re.sub(r"\s.*", "", o) for o in ops]
 
 
-def main(path):
+def main(path, reads_only=False):
     text = open(path).read().split("\n")
     bad = 0
-    kernels = [i for i, l in enumerate(text) if re.match(r"^_ZN5nufft21spread_patch32_kernel[^:]*:", l)]
+    pat = r"^_ZN5nufft19spread_patch_kernel[^:]*:" if reads_only else r"^_ZN5nufft21spread_patch32_kernel[^:]*:"
+    kernels = [i for i, l in enumerate(text) if re.match(pat, l)]
     for k in kernels:
         end = next(i for i in range(k, len(text)) if "s_endpgm" in text[i])
         body = text[k:end + 1]
@@ -65,7 +68,7 @@ def main(path):
         blocks.append(cur)
         nm = 0
         for b in blocks:
-            if not any("v_mfma" in l for l in b):
+            if reads_only or not any("v_mfma" in l for l in b):
                 continue
             for l in b:
                 op, ops = operands(l)
@@ -177,4 +180,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1]))
+    sys.exit(main(sys.argv[1], "--reads-only" in sys.argv[2:]))

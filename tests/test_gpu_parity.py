@@ -366,6 +366,11 @@ ENGINE_CASES = [
     (np.float64, (36, 50, 40), 4, 2.0, O.DIRECT, 1),
     (np.complex128, (36, 50, 40), 4, 2.0, O.FAST_APPROXIMATION, 1),
     (np.float32, (36, 50, 40), 5, 2.0, O.FAST_APPROXIMATION, 2),
+    # real plans with ntransforms = 2 / 3: the patch engine spreads the components together (planar components)
+    (np.float64, (32, 32, 32), 4, 2.0, O.DIRECT, 3),
+    (np.float32, (40, 48, 40), 6, 2.0, O.FAST_APPROXIMATION, 3),
+    (np.float64, (36, 50, 40), 4, 2.0, O.FAST_APPROXIMATION, 2),
+    (np.float64, (40, 40, 40), 2, 2.0, O.DIRECT, 3),
     # wide supports in Float64 (the Float32 cases above are bounded by Float32 round-off): the same code at 1e-7
     (np.complex128, (48, 48, 48), 8, 2.0, O.FAST_APPROXIMATION, 1),
     (np.float64, (48, 48, 48), 8, 2.0, O.FAST_APPROXIMATION, 1),
@@ -424,6 +429,11 @@ def test_spreading_engine_selection():
     assert nufft.PlanNUFFT(np.complex128, (64, 64, 64), backend=nufft.ROCBackend(0)).info().spread_method == 2
     assert nufft.PlanNUFFT(np.float64, (64, 64, 64), m=6, backend=nufft.ROCBackend(0)).info().spread_method == 2
     assert nufft.PlanNUFFT(np.complex128, (35, 64, 40), sigma=1.5, backend=nufft.ROCBackend(0)).info().spread_method == 1
+    # real plans with ntransforms = 2 / 3: the patches spread the components together
+    i3 = nufft.PlanNUFFT(np.float64, (64, 64, 64), ntransforms=3, backend=nufft.ROCBackend(0)).info()
+    assert i3.spread_method == 2 and i3.patch_planar == 3
+    i4 = nufft.PlanNUFFT(np.float64, (64, 64, 64), ntransforms=4, backend=nufft.ROCBackend(0)).info()
+    assert i4.spread_method == 1 and i4.patch_planar == 0
 
 
 @pytest.mark.parametrize("kw", [dict(gpu_method="global_memory"),
