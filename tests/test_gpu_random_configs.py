@@ -95,3 +95,81 @@ def test_random_configuration(seed):
         denom = np.linalg.norm(np.asarray(ref2[c]).ravel())
         err = np.linalg.norm((out[c].cpu().numpy() - ref2[c]).ravel())
         assert err <= tol * max(denom, 1e-30), (dims, M, sigma, kname, mode, Zt, dist)
+
+
+def _draw_large(rng):
+    M = int(rng.integers(2, 11))
+    sigma = float(rng.choice([1.25, 1.5, 2.0, 2.0]))
+    dims = tuple(int(rng.integers(28, 72)) for _ in range(3))
+    Z = [np.float64, np.complex128, np.float32, np.complex64][int(rng.integers(0, 4))]
+    mode = int(rng.integers(0, 2))
+    C = int(rng.choice([1, 1, 2, 3]))
+    dist = ["uniform", "uniform", "cluster"][int(rng.integers(0, 3))]
+    engine = ["auto", "auto", "lds_tiles", "mfma_patches"][int(rng.integers(0, 4))]
+    if np.dtype(Z) in (np.dtype(np.float32), np.dtype(np.complex64)):
+        # Float32 at small sigma is ill-conditioned whatever the implementation: the deconvolution spans 4-5 decades and amplifies
+        # Float32 round-off of windows and sums to 1e-3 (measured at sigma = 1.25, M = 6, clustered points: Float32 oracle vs
+        # Float64-accumulating oracle 2.6e-3, HIP path vs the latter 7.7e-4) — nothing to compare at 1e-5 there
+        sigma = 2.0
+    return M, sigma, dims, Z, mode, C, dist, engine
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_configuration_large_3d(seed):
+    """The same differential test on 3-D grids large enough for the engines that need room — register patches (Float64 and
+    Float32 accumulators, planar components), the z-marching interpolation ring — with the default window, both evaluation
+    modes, all element types, ntransforms 1..3, uniform and clustered points (clustered sets switch both stages back to the
+    LDS-tile kernels on the device), and the spreading engine automatic or forced (an engine the plan cannot serve must be
+    refused, nothing silent)."""
+    from nufft_pkg import nufft
+    rng = np.random.default_rng(5000 + seed)
+    M, sigma, dims, Z, mode, C, dist, engine = _draw_large(rng)
+    Zt = np.dtype(Z)
+    is_real = Zt.kind == "f"
+    T = np.float32 if Zt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
+    wide = T == np.float32 and 3 * M >= 21             # un-normalised Float32 windows overflow: Float64 oracle, Float32 cell arithmetic
+    oplan = O.OraclePlan(dims, is_real=is_real, dtype=np.float64 if wide else T, coord_dtype=T if wide else None, M=M, sigma=sigma,
+                         evalmode=mode, ntransforms=C)
+    Np = int(rng.integers(500, 6000))
+    if dist == "uniform":
+        xs = [(rng.random(Np) * 3 - 1) * O.TWO_PI for _ in dims]
+    else:
+        xs = [rng.standard_normal(Np) * 0.1 + rng.random() * O.TWO_PI for _ in dims]
+    xs = [x.astype(T) for x in xs]
+    vs = [(rng.standard_normal(Np) if is_real else rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Zt)
+          for _ in range(C)]
+    try:
+        plan = nufft.PlanNUFFT(Zt, dims, m=M, sigma=sigma, ntransforms=C, spread_method=engine,
+                               kernel_evalmode=nufft.Direct() if mode == O.DIRECT else nufft.FastApproximation(),
+                               backend=nufft.ROCBackend(0))
+    except ValueError as exc:
+        assert engine == "mfma_patches" and "MFMA patches" in str(exc)
+        return
+    assert plan.oversampled_dims == oplan.Nover
+    O.set_points(oplan, xs)
+    dev = plan.device
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    if engine != "auto":
+        assert plan.spread_engine_used() == engine
+    us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
+    nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+    wide_c = np.complex128 if (wide or T == np.float64) else np.complex64
+    vo = [v.astype(wide_c if not is_real else (np.float64 if wide else T)) for v in vs]
+    ref = O.exec_type1(oplan, vo if C > 1 else vo[0])
+    ref = ref if C > 1 else [ref]
+    tol = 1e-7 if T == np.float64 else 5e-5             # (Float32: sums of thousands of Float32 terms in different orders)
+    for c in range(C):
+        err = np.linalg.norm(us[c].cpu().numpy().astype(np.complex128) - ref[c]) / np.linalg.norm(ref[c])
+        assert err < tol, (seed, M, sigma, dims, Z, mode, C, dist, engine, err)
+    ws = [(rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)).astype(np.complex64 if T == np.float32 else np.complex128)
+          for _ in range(C)]
+    wd = tuple(torch.from_numpy(w).to(dev) for w in ws)
+    out = tuple(torch.empty(Np, dtype=plan.Z, device=dev) for _ in range(C))
+    nufft.exec_type2(out if C > 1 else out[0], plan, wd if C > 1 else wd[0])
+    wo = [w.astype(wide_c) for w in ws]
+    ref2 = O.exec_type2(oplan, wo if C > 1 else wo[0])
+    ref2 = ref2 if C > 1 else [ref2]
+    for c in range(C):
+        err = np.linalg.norm(out[c].cpu().numpy() - ref2[c]) / np.linalg.norm(ref2[c])
+        assert err < tol, (seed, M, sigma, dims, Z, mode, C, dist, engine, "type 2", err)
