@@ -37,10 +37,11 @@ def _rel(a, b):
 
 def _f32_overflows(Z, dims, M):
     """The reference's un-normalised BKB window peaks at e^β/2π; in Float32 the product of D window
-    values overflows for large M (D = 3: M >= 7).  There the Float32 oracle is not finite and the HIP
+    values overflows for large M (D = 3: M >= 7 at sigma = 2; D = 2: M = 10 — β = 46.9 — and, with the sums of a
+    cell, M = 9: D * M >= 18 is the conservative rule).  There the Float32 oracle is not finite and the HIP
     path (which normalises the window by an exact power of two) is checked against the Float64 oracle that locates
     the points in Float32 exactly as a Float32 plan does (`coord_dtype`), at the reference's Float32 bound 1e-5."""
-    return np.dtype(Z) in (np.dtype(np.float32), np.dtype(np.complex64)) and len(dims) * M >= 21
+    return np.dtype(Z) in (np.dtype(np.float32), np.dtype(np.complex64)) and len(dims) * M >= 18
 
 
 _KERNEL_OBJ = {O.KERNEL_BKB: "BackwardsKaiserBesselKernel", O.KERNEL_KB: "KaiserBesselKernel",

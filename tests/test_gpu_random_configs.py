@@ -41,9 +41,9 @@ def test_random_configuration(seed):
     T = np.float32 if Zt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
     # Float32 plans are checked against the Float32 oracle (same fold arithmetic: a point at a multiple of 2 pi may
     # land on either side of the periodic boundary in Float32, which matters at the window-truncation level,
-    # 1e-2 at M = 2) unless its un-normalised windows overflow (D * M >= 21): then against the Float64 oracle.
+    # 1e-2 at M = 2) unless its un-normalised windows overflow (D * M >= 18, conservatively): then against the Float64 oracle.
     big_window = kid in (O.KERNEL_BKB, O.KERNEL_KB)
-    To = np.float64 if (T == np.float64 or (big_window and D * M >= 21)) else np.float32
+    To = np.float64 if (T == np.float64 or (big_window and D * M >= 18)) else np.float32
     try:
         oplan64 = O.OraclePlan(dims, is_real=is_real, dtype=To, M=M, sigma=sigma, evalmode=mode, ntransforms=C,
                                kernel=kid, fftshift=fftshift)
@@ -127,7 +127,7 @@ def test_random_configuration_large_3d(seed):
     Zt = np.dtype(Z)
     is_real = Zt.kind == "f"
     T = np.float32 if Zt in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64
-    wide = T == np.float32 and 3 * M >= 21             # un-normalised Float32 windows overflow: Float64 oracle, Float32 cell arithmetic
+    wide = T == np.float32 and 3 * M >= 18             # un-normalised Float32 windows overflow: Float64 oracle, Float32 cell arithmetic
     oplan = O.OraclePlan(dims, is_real=is_real, dtype=np.float64 if wide else T, coord_dtype=T if wide else None, M=M, sigma=sigma,
                          evalmode=mode, ntransforms=C)
     Np = int(rng.integers(500, 6000))
