@@ -28,7 +28,8 @@
 //   * Values arrive gathered in sorted order (gather_values_kernel), records and values of the next chunk of
 //     points are prefetched into registers while the current chunk is processed.
 //
-// Float32 plans evaluate their windows in Float32 and accumulate in Float64 (as the LDS-tile kernel does).
+// Float32 plans evaluate their windows in Float32 and accumulate in Float64 here (as the LDS-tile kernel does); ComplexF32
+// plans normally run patch32_kernels.h instead (FP32 matrix pipe, Float32 accumulators, as the reference accumulates).
 #pragma once
 
 #include <hip/hip_runtime.h>
