@@ -64,6 +64,12 @@ struct Patch32Cfg {
     static constexpr int PADB = 4 - M - 4 * CLO;
     static constexpr int PADA = 4 * CHI + 3 - M;
     static constexpr int LW = PADB + L + PADA;
+    // dimension 1 is read at (cube column of the patch, lane) - (stencil start): every patch-relative position a visited
+    // point can produce lies inside the padding, so the PBX reads of a lane are plain offsets from one address
+    // (pairs of columns by ds_read2_b32) — no clamping arithmetic
+    static constexpr int PADXB = 4 * (PBX - CLO) - M;
+    static constexpr int PADXA = 4 * PBX + 4 * CHI - M - 1;
+    static constexpr int LWX = PADXB + L + PADXA;
     // ... dimension 3 per octet, whose first cube may be the one below the stencil's first cube
     static constexpr int PADBZ = PADB + 4;
     static constexpr int TMAXZ = 4 * CLO + M - 1 + 8 * NOB - 1;        // largest window index an octet read can reach
@@ -71,8 +77,8 @@ struct Patch32Cfg {
     static constexpr int LWZ = PADBZ + L + PADAZ;
     static constexpr int G = next_pow2(L);              // lanes per point during window evaluation
     static constexpr int PPW = kWave / G;
-    static constexpr int WX = 0, WY = LW * 4, WZ = 2 * LW * 4;          // byte offsets of the three rows of a staged point
-    static constexpr int MT = round_up((2 * LW + LWZ) * 4, 16);         // meta data {-4 sx, offy, offz, rbx} + value (re, im)
+    static constexpr int WX = 0, WY = LWX * 4, WZ = (LWX + LW) * 4;     // byte offsets of the three rows of a staged point
+    static constexpr int MT = round_up((LWX + LW + LWZ) * 4, 16);       // meta data {offx, offy, offz, rbx} + value (re, im)
     // stride between staged points: an odd multiple of 8 banks, so that the rows the four points of a K-batch read at the
     // same offsets fall on disjoint banks
     static constexpr int pstride() {
@@ -102,7 +108,7 @@ struct Patch32Cfg {
     static constexpr int NCOL = PBX * PBY;
     static constexpr int NCA = NCA_MAX < NCOL ? NCA_MAX : NCOL;
     static constexpr int NCV = NCOL - NCA;
-    static_assert(PADB >= 1 && PADA >= 1 && PADBZ >= 1, "padding");
+    static_assert(PADB >= 1 && PADA >= 1 && PADBZ >= 1 && PADXB >= 0 && PADXA >= 0, "padding");
     static_assert(NCV <= NCV_MAX, "vector-register accumulators leave room for the working set");
 };
 
@@ -134,6 +140,24 @@ __device__ __forceinline__ void acc_touch(v4f& c) {
     else asm volatile("" : "+v"(c));
 }
 
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+// two dwords at addr + 4 O0 and addr + 4 O1 into a register pair
+template <int O0, int O1>
+__device__ __forceinline__ void lds_read2_b32(v2f32& dst, uint32_t addr) {
+    static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2 offsets");
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(O0), "n"(O1));
+}
+// N values at a stride of S dwords: pairs by ds_read2_b32 into p[(N + 1) / 2]
+template <int N, int S, int I = 0>
+__device__ __forceinline__ void lds_read_strided(v2f32 (&p)[(N + 1) / 2], uint32_t addr) {
+    if constexpr (I + 1 < N) {
+        lds_read2_b32<I * S, (I + 1) * S>(p[I / 2], addr);
+        lds_read_strided<N, S, I + 2>(p, addr);
+    } else if constexpr (I < N) {
+        lds_read2_b32<I * S, I * S>(p[I / 2], addr);       // odd count: the last value twice (no copy out of a register in flight)
+    }
+}
+
 // w[cx] = row[clamp(t + 4 cx, -1, L)] for Float32 rows (see lds_read_clamped in patch_kernels.h): t4 = 4 (lane x - sx)
 template <int L, int N, int... CX>
 __device__ __forceinline__ void lds_read_clamped32(float (&w)[N], uint32_t base, int t4, std::integer_sequence<int, CX...>) {
@@ -145,7 +169,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
     using T = float;
     using P = Patch32Cfg<M>;
     constexpr int L = P::L, CLO = P::CLO, CHI = P::CHI, NCB = P::NCB, NOB = P::NOB, PBX = P::PBX, PBY = P::PBY, NRB = P::NRB;
-    constexpr int PADB = P::PADB, PADBZ = P::PADBZ, LW = P::LW, CH = P::CH, PSTRIDE = P::PSTRIDE;
+    constexpr int PADB = P::PADB, PADBZ = P::PADBZ, PADXB = P::PADXB, LW = P::LW, CH = P::CH, PSTRIDE = P::PSTRIDE;
     constexpr int WX = P::WX, WY = P::WY, WZ = P::WZ, MT = P::MT;
     using WE = WindowEval<T, 1, 3, M, P::G, OTHERK>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
             if (sx < -(g.Nover[0] / 2)) sx += g.Nover[0];
             const int par = (bz + CLO) & 1;                            // first cube of the ring is the odd one of slot 0's octet
             int4 m;
-            m.x = -4 * sx;
+            m.x = (PADXB - sx) * 4;                                    // first read of dimension 1: cube column 0, lane x = 0
             m.y = (PADB + M - 1 - (cell[1] & 3) + 4 * CLO) * 4;        // cube offset CLO, lane row 0
             m.z = (PADBZ + M - 1 - (cell[2] & 3) + 4 * CLO - 4 * par) * 4;   // octet slot 0, plane 0
             m.w = (sx + (M - 1)) >> 2;                                 // bin of the point relative to the patch
@@ -343,7 +367,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
 #pragma unroll
                 for (int sl = 0; sl < WE::NSLOT; ++sl)
                     if (we.has[sl]) {
-                        const int off = we.dsel[sl] == 2 ? WZ + (PADBZ + we.jsel[sl]) * 4 : we.dsel[sl] * (LW * 4) + (PADB + we.jsel[sl]) * 4;
+                        const int off = we.dsel[sl] == 2 ? WZ + (PADBZ + we.jsel[sl]) * 4
+                                      : (we.dsel[sl] == 1 ? WY + (PADB + we.jsel[sl]) * 4 : WX + (PADXB + we.jsel[sl]) * 4);
                         *reinterpret_cast<float*>(pw + off) = v[sl];
                     }
             }
@@ -392,7 +417,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
         typedef int v4i __attribute__((ext_vector_type(4)));
         v4i m;
         float vsel;                                                    // component bcl of the point's value
-        float w3[NOB], w2[NCB], w1[PBX];
+        v2f32 w3p[(NOB + 1) / 2], w2p[(NCB + 1) / 2], w1p[PBX / 2];      // operand values in register pairs (ds_read2_b32)
         uint32_t cxmask = 0u;
         const uint32_t vsel_off = (uint32_t)bcl * 4u;
         auto issue_meta = [&](int b0) __attribute__((always_inline)) {
@@ -413,20 +438,19 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
                 cxmask = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
             }
             vcur = vsel;
-            lds_read_rows<float, NOB, 0, 32>(w3, pb + WZ + (uint32_t)m.z + (uint32_t)bzl * 4, std::make_integer_sequence<int, NOB>{});
-            lds_read_rows<float, NCB, 0, 16>(w2, pb + WY + (uint32_t)m.y + (uint32_t)mb * 4, std::make_integer_sequence<int, NCB>{});
-            const int t4 = mi * 4 + m.x;
-            lds_read_clamped32<L, PBX>(w1, pb + WX + PADB * 4, t4, std::make_integer_sequence<int, PBX>{});
+            lds_read_strided<NOB, 8>(w3p, pb + WZ + (uint32_t)m.z + (uint32_t)bzl * 4);       // octets: 8 planes apart
+            lds_read_strided<NCB, 4>(w2p, pb + WY + (uint32_t)m.y + (uint32_t)mb * 4);        // cube rows: 4 cells apart
+            lds_read_strided<PBX, 4>(w1p, pb + WX + (uint32_t)m.x + (uint32_t)mi * 4);        // cube columns of the patch
         };
         auto wait_all = [&]() __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(m), "+v"(vsel));
 #pragma unroll
-            for (int s = 0; s < NOB; ++s) asm volatile("" : "+v"(w3[s]));
+            for (int s = 0; s < (NOB + 1) / 2; ++s) asm volatile("" : "+v"(w3p[s]));
 #pragma unroll
-            for (int o = 0; o < NCB; ++o) asm volatile("" : "+v"(w2[o]));
+            for (int o = 0; o < (NCB + 1) / 2; ++o) asm volatile("" : "+v"(w2p[o]));
 #pragma unroll
-            for (int cx = 0; cx < PBX; ++cx) asm volatile("" : "+v"(w1[cx]));
+            for (int cx = 0; cx < PBX / 2; ++cx) asm volatile("" : "+v"(w1p[cx]));
         };
         issue_meta(0);
         wait_all();
@@ -438,13 +462,15 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
 #if defined(NUFFT_PATCH_PROFILE)
             nbatch += 1;
 #endif
-            float A[NCB][PBX], B[NOB];
+            // operands of this batch: A = w1 w2 per cube column and row (pairs of columns: v_pk_mul_f32), B = v w3 per octet
+            v2f32 Ap[NCB][PBX / 2], Bp[(NOB + 1) / 2];
 #pragma unroll
-            for (int s = 0; s < NOB; ++s) B[s] = w3[s] * vcur;
+            for (int s = 0; s < (NOB + 1) / 2; ++s) Bp[s] = w3p[s] * vcur;
 #pragma unroll
             for (int o = 0; o < NCB; ++o)
 #pragma unroll
-                for (int cx = 0; cx < PBX; ++cx) A[o][cx] = (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? w1[cx] * w2[o] : 0.f;
+                for (int cx = 0; cx < PBX / 2; ++cx)
+                    Ap[o][cx] = (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? w1p[cx] * w2p[o / 2][o % 2] : v2f32{0.f, 0.f};
             const uint32_t mask = cxmask;
             // The operand reads of the next batch (and the meta data of the one after) are issued behind the matrix
             // instructions of cube column 1 — four fifths of the matrix work belongs to batches that touch it — so that
@@ -472,8 +498,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
                             for (int s = 0; s < NOB; ++s) {
                                 constexpr int dummy = 0;
                                 const int col = cy * PBX + cx;
-                                if (col < NCA) mfma_acc<true>(accA[s][col < NCA ? col : dummy], A[o][cx], B[s]);
-                                else mfma_acc<false>(accV[s][col >= NCA ? col - NCA : dummy], A[o][cx], B[s]);
+                                if (col < NCA) mfma_acc<true>(accA[s][col < NCA ? col : dummy], Ap[o][cx / 2][cx % 2], Bp[s / 2][s % 2]);
+                                else mfma_acc<false>(accV[s][col >= NCA ? col - NCA : dummy], Ap[o][cx / 2][cx % 2], Bp[s / 2][s % 2]);
                             }
                         }
                     }
