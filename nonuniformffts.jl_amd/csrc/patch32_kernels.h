@@ -158,12 +158,6 @@ __device__ __forceinline__ void lds_read_strided(v2f32 (&p)[(N + 1) / 2], uint32
     }
 }
 
-// w[cx] = row[clamp(t + 4 cx, -1, L)] for Float32 rows (see lds_read_clamped in patch_kernels.h): t4 = 4 (lane x - sx)
-template <int L, int N, int... CX>
-__device__ __forceinline__ void lds_read_clamped32(float (&w)[N], uint32_t base, int t4, std::integer_sequence<int, CX...>) {
-    ((lds_read_imm<float, 16 * CX>(w[CX], base + (uint32_t)max(-4 - 16 * CX, min(t4, 4 * L - 16 * CX)))), ...);
-}
-
 template <int M, bool OTHERK>
 __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread_patch32_kernel(PatchArgs<float> a) {
     using T = float;
@@ -358,7 +352,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
     typedef float v2f __attribute__((ext_vector_type(2)));
     const bool poly_eval = a.t.evalmode != NUFFT_EVAL_DIRECT;
     auto eval_chunk = [&](int n) __attribute__((always_inline)) {
-        WE we;
+        WE we;              // (hoisting this lane's coefficients out of the chunk loop: the allocator then shuttles accumulators, lint fails)
         we.init(a.t, q, ctab);
         wave_lds_fence();
         auto store = [&](int pt, const T (&v)[WE::NSLOT]) __attribute__((always_inline)) {

@@ -93,6 +93,10 @@ struct PatchCfg {
     static constexpr int PADB = 4 - M - 4 * CLO;        // zeros in front of / behind the 2M window values of a row
     static constexpr int PADA = 4 * CHI + 3 - M;
     static constexpr int LW = PADB + L + PADA;
+    // the row of dimension 1 is padded for every (lane x, stencil start) pair of the patch, so that its reads need no clamp
+    static constexpr int PADXB = 4 * (PBX - CLO) - M;
+    static constexpr int PADXA = 4 * PBX + 4 * CHI - M - 1;
+    static constexpr int LWX = PADXB + L + PADXA;
     static constexpr int G = next_pow2(L);              // lanes per point during window evaluation
     static constexpr int PPW = kWave / G;
     // points per chunk (staged in LDS): as much of a run of the sorted array as the LDS holds — every chunk pays the
@@ -102,12 +106,12 @@ struct PatchCfg {
         const int occ = patch_occupancy(NC, M);
         const int budget = (occ == 1 ? 160 : 80) * 1024 - 512;
         for (int ch = (occ == 1 ? 64 : 32); ch > 16; ch -= 8)
-            if (4 * ((ch + 1) * (3 * LW * 8 + META) + ch * 48 + 32) + 3 * (M + 4) * L * 8 + 64 <= budget) return ch;
+            if (4 * ((ch + 1) * ((LWX + 2 * LW) * 8 + META) + ch * 48 + 32) + 3 * (M + 4) * L * 8 + 64 <= budget) return ch;
         return 16;
     }
     static constexpr int META = round_up(16 + 8 * NC, 16) < 32 ? 32 : round_up(16 + 8 * NC, 16);   // bytes: {sx, offy, offz, rbx} + NC values
     static constexpr int CH = chunk_points();
-    static constexpr int PSTRIDE = 3 * LW * 8 + META;   // bytes per staged point
+    static constexpr int PSTRIDE = (LWX + 2 * LW) * 8 + META;   // bytes per staged point
     static constexpr int WBYTES = (CH + 1) * PSTRIDE;   // + the all-zero point
     static constexpr int ROWLEN = (PL ? 16 : 16 * NC) + 2;   // reals per row of the transposition buffer (+2: banks); planar: one component at a time
     static constexpr int TBYTES = 4 * 4 * PBY * ROWLEN * 8;
@@ -175,12 +179,21 @@ __global__ __launch_bounds__(256) void gather_planar_kernel(const unsigned char*
     }
 }
 
-// Window values of cube columns 0 .. N-1 of dimension 1: w[cx] = row[clamp(t8 / 8 + 4 cx, -1, L)] with `base` the LDS
-// byte address of row[0] and t8 = 8 (lane coordinate - stencil start); row[-1] and row[L] are padding zeros.
-// v_med3 clamps t8 against bounds shifted by the column, the column offset itself is the immediate of the read.
-template <int L, int N, int... CX>
-__device__ __forceinline__ void lds_read_clamped(double (&w)[N], uint32_t base, int t8, std::integer_sequence<int, CX...>) {
-    ((lds_read_imm<double, 32 * CX>(w[CX], base + (uint32_t)max(-8 - 32 * CX, min(t8, 8 * L - 32 * CX)))), ...);
+// N doubles at a stride of S doubles from one LDS address: pairs by ds_read2_b64 (offsets in units of 8 bytes) into
+// p[(N + 1) / 2]; an odd count reads its last value twice (no copy out of a register with a read in flight)
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+template <int O0, int O1>
+__device__ __forceinline__ void lds_read2_b64(v2f64& d, uint32_t addr) {
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(O0), "n"(O1));
+}
+template <int N, int S, int I = 0>
+__device__ __forceinline__ void lds_read_strided64(v2f64 (&p)[(N + 1) / 2], uint32_t addr) {
+    if constexpr (I + 1 < N) {
+        lds_read2_b64<I * S, (I + 1) * S>(p[I / 2], addr);
+        lds_read_strided64<N, S, I + 2>(p, addr);
+    } else if constexpr (I < N) {
+        lds_read2_b64<I * S, I * S>(p[I / 2], addr);
+    }
 }
 
 // f(std::integral_constant<int, r>) for the run-time row r in [I, N)
@@ -203,8 +216,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
     constexpr int NC = PLANAR ? NP : (CPLX ? 2 : 1);
     using P = PatchCfg<NC, M, PLANAR>;
     constexpr int L = P::L, CLO = P::CLO, CHI = P::CHI, NCB = P::NCB, PBX = P::PBX, PBY = P::PBY, NRB = P::NRB;
-    constexpr int PADB = P::PADB, LW = P::LW, CH = P::CH, PSTRIDE = P::PSTRIDE;
-    constexpr int WX = 0, WY = LW * 8, WZ = 2 * LW * 8, MT = 3 * LW * 8;      // byte offsets inside a staged point
+    constexpr int PADB = P::PADB, PADXB = P::PADXB, LW = P::LW, LWX = P::LWX, CH = P::CH, PSTRIDE = P::PSTRIDE;
+    constexpr int WX = 0, WY = LWX * 8, WZ = (LWX + LW) * 8, MT = (LWX + 2 * LW) * 8;      // byte offsets inside a staged point
     using WE = WindowEval<T, 1, 3, M, P::G, OTHERK>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
             if (sx > g.Nover[0] / 2) sx -= g.Nover[0];
             if (sx < -(g.Nover[0] / 2)) sx += g.Nover[0];
             int4 m;
-            m.x = -8 * sx;
+            m.x = (PADXB - sx) * 8;                                    // first read of dimension 1: cube column 0, lane x = 0
             m.y = (PADB + M - 1 - (cell[1] & 3) + 4 * CLO) * 8;        // cube offset CLO, lane row 0
             m.z = (PADB + M - 1 - (cell[2] & 3) + 4 * CLO) * 8;
             m.w = (sx + (M - 1)) >> 2;                                 // bin of the point relative to the patch
@@ -428,7 +441,10 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
             if (pt < n) {
 #pragma unroll
                 for (int sl = 0; sl < WE::NSLOT; ++sl)
-                    if (we.has[sl]) *reinterpret_cast<double*>(pw + we.dsel[sl] * (LW * 8) + (PADB + we.jsel[sl]) * 8) = (double)v[sl];
+                    if (we.has[sl]) {
+                        const int off = we.dsel[sl] == 0 ? WX + (PADXB + we.jsel[sl]) * 8 : (we.dsel[sl] == 1 ? WY : WZ) + (PADB + we.jsel[sl]) * 8;
+                        *reinterpret_cast<double*>(pw + off) = (double)v[sl];
+                    }
             }
         }
         wave_lds_fence();
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
         v4i m;                       // {sx, byte offset dim 2, byte offset dim 3, bin along dim 1 relative to the patch}
         v2d vv;                      // value (re, im) / components 0, 1
         double v3 = 0.0, v3n = 0.0;  // component 2 (planar, NC = 3)
-        double w3[NCB], w2[NCB], w1[PBX];
+        v2d w3p[(NCB + 1) / 2], w2p[(NCB + 1) / 2], w1p[PBX / 2];      // operand values in register pairs (ds_read2_b64)
         double vre = 0.0, vim = 0.0;
         uint32_t cxmask = 0u;                                          // cube columns the batch can touch
         auto issue_meta = [&](int b0) __attribute__((always_inline)) {
@@ -471,20 +487,18 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
             if constexpr (NC >= 3) v3 = v3n;
             // dimension 3: ring slot s <-> cube offset CLO + s; dimension 2: cube offset CLO + o (static offsets from
             // one address each); dimension 1: the window index is clamped into the zero padding
-            lds_read_rows<double, NCB, 0, 32>(w3, pb + WZ + (uint32_t)m.z + (uint32_t)mi * 8, std::make_integer_sequence<int, NCB>{});
-            lds_read_rows<double, NCB, 0, 32>(w2, pb + WY + (uint32_t)m.y + (uint32_t)mb * 8, std::make_integer_sequence<int, NCB>{});
-            const int t8 = mi * 8 + m.x;                               // 8 (x - sx) for cube column 0
-            const uint32_t pbx = pb + WX + PADB * 8;
-            lds_read_clamped<L, PBX>(w1, pbx, t8, std::make_integer_sequence<int, PBX>{});
+            lds_read_strided64<NCB, 4>(w3p, pb + WZ + (uint32_t)m.z + (uint32_t)mi * 8);
+            lds_read_strided64<NCB, 4>(w2p, pb + WY + (uint32_t)m.y + (uint32_t)mb * 8);
+            lds_read_strided64<PBX, 4>(w1p, pb + WX + (uint32_t)m.x + (uint32_t)mi * 8);
         };
         auto wait_all = [&]() __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(m), "+v"(vv));
             if constexpr (NC >= 3) asm volatile("" : "+v"(v3n));
 #pragma unroll
-            for (int s = 0; s < NCB; ++s) asm volatile("" : "+v"(w3[s]), "+v"(w2[s]));
+            for (int s = 0; s < (NCB + 1) / 2; ++s) asm volatile("" : "+v"(w3p[s]), "+v"(w2p[s]));
 #pragma unroll
-            for (int cx = 0; cx < PBX; ++cx) asm volatile("" : "+v"(w1[cx]));
+            for (int cx = 0; cx < PBX / 2; ++cx) asm volatile("" : "+v"(w1p[cx]));
         };
         // (the waits sit at the END of an iteration: registers that an inline-asm read has been issued into must not
         // cross the loop back edge, where the compiler may copy them before the data has arrived)
@@ -499,14 +513,15 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
             double A[NCB][PBX], bz_[NC][NCB];
 #pragma unroll
             for (int s = 0; s < NCB; ++s) {
-                bz_[0][s] = w3[s] * vre;
-                if constexpr (NC >= 2) bz_[NC >= 2 ? 1 : 0][s] = w3[s] * vim;
-                if constexpr (NC >= 3) bz_[NC >= 3 ? 2 : 0][s] = w3[s] * v3;
+                const double w3s = w3p[s / 2][s % 2];
+                bz_[0][s] = w3s * vre;
+                if constexpr (NC >= 2) bz_[NC >= 2 ? 1 : 0][s] = w3s * vim;
+                if constexpr (NC >= 3) bz_[NC >= 3 ? 2 : 0][s] = w3s * v3;
             }
 #pragma unroll
             for (int o = 0; o < NCB; ++o)
 #pragma unroll
-                for (int cx = 0; cx < PBX; ++cx) A[o][cx] = (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? w1[cx] * w2[o] : 0.0;
+                for (int cx = 0; cx < PBX; ++cx) A[o][cx] = (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? w1p[cx / 2][cx % 2] * w2p[o / 2][o % 2] : 0.0;
             const uint32_t mask = cxmask;
             issue_ops(b0 + 4);
             issue_meta(b0 + 8);
