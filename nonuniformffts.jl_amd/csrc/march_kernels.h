@@ -63,7 +63,23 @@ struct MarchCfg {
     static constexpr bool PAIR = CPLX && sizeof(T) == 4 && next_pow2(L) <= 16;
     using GP = Grp<PAIR ? 1 : NC, M>;
     static constexpr bool REGW = (!CPLX || PAIR) && (GP::G == 8 || GP::G == 16);   // window values stay in registers (DPP broadcasts)
-    static constexpr int strip_bytes() { return REGW ? 0 : round_up(GP::PPW * 3 * L * (int)sizeof(T), 16); }
+    // A row of 16 lanes reads 16 contiguous nodes = HALF the banks its 32-lane LDS group spans, so the two points that
+    // share a group collide on every read unless their rows happen to be complementary (C3: LDS array busy twice the
+    // ideal time, 80 % of the kernel).  ZP = 2: both rows of a group belong to ONE point and gather alternate stencil
+    // planes; the plane stride is padded to an odd multiple of the row's bytes, so the two rows always cover the
+    // group's banks exactly once.  (Two points per wave pass instead of four: the window evaluation is done by both rows.)
+#ifndef NUFFT_MARCH_ZP
+#define NUFFT_MARCH_ZP 2
+#endif
+    static constexpr int ZP = (REGW && GP::G == 16 && L == 16) ? NUFFT_MARCH_ZP : 1;   // (measured: M = 5..7 lose 6-17 % with their 10-14 of 16 lanes)
+    static constexpr int PPW = GP::PPW / ZP;            // points per wave pass
+    static constexpr int ROW_BYTES = GP::G * (PAIR ? 2 : 1) * (int)sizeof(T);
+    static constexpr int pad_plane(int ps) {            // plane stride in reals: = ROW_BYTES (mod 2 ROW_BYTES) bytes
+        if (ZP == 1) return ps;
+        const int b = ps * (int)sizeof(T), m = 2 * ROW_BYTES;
+        return ps + ((ROW_BYTES - b % m + m) % m) / (int)sizeof(T);
+    }
+    static constexpr int strip_bytes() { return REGW ? 0 : round_up(GP::PPW * 3 * L * (int)sizeof(T), 16); }   // (REGW = false: ZP = 1)
     // [runs of the segment: layer x row][passes of the longest run per layer][pass counter, flag]
     static constexpr int table_bytes(int segl) { return round_up(kMarchMaxRows * segl * 8 + segl * 4 + 64, 16); }
     static constexpr int kSegMax = 64;
@@ -75,7 +91,7 @@ struct MarchCfg {
         double best_cost = 1e300;
         for (int n2 = 4; n2 <= 4 * kMarchMaxRows; n2 += 4)
             for (int n1 = 4; n1 <= 64; n1 += 4) {
-                const long bytes = (long)NC * (n1 + HALO) * (n2 + HALO) * RZ * (long)sizeof(T) + fixed_bytes();
+                const long bytes = (long)pad_plane(NC * (n1 + HALO) * (n2 + HALO)) * RZ * (long)sizeof(T) + fixed_bytes();
                 if (bytes > 163840 - 256) continue;
                 // registers of the per-thread plane prefetch (the planes of the next layer are in flight during the gather)
                 if (((long)BZ * NC * (n1 + HALO) * (n2 + HALO) + THREADS - 1) / THREADS * (long)(sizeof(T) / 4) > 32) continue;
@@ -92,8 +108,9 @@ struct MarchCfg {
     static constexpr int N1 = DIMS.n1, N2 = DIMS.n2;
     static constexpr int P1 = N1 + HALO, P2 = N2 + HALO;
     static constexpr int RS = NC * P1;                  // row stride in reals
-    static constexpr int PS = RS * P2;                  // plane stride in reals
-    static constexpr int RING_BYTES = round_up(RZ * PS * (int)sizeof(T), 16);
+    static constexpr int PS = RS * P2;                  // reals per plane
+    static constexpr int PSP = pad_plane(PS);           // plane stride in the ring
+    static constexpr int RING_BYTES = round_up(RZ * PSP * (int)sizeof(T), 16);
     static constexpr int lds_bytes() { return RING_BYTES + fixed_bytes(); }
     static constexpr int NPF = (BZ * PS + THREADS - 1) / THREADS;    // prefetched reals per thread and layer
     static constexpr bool FITS = N1 > 0;                // (ComplexF64 at M >= 9: not even a 4 x 4 column fits 160 KiB)
@@ -105,7 +122,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
     constexpr int kMarchThreads = C::THREADS;
     using GP = typename C::GP;
     constexpr int NC = C::NC, L = C::L, RZ = C::RZ, BZ = C::BZ, RS = C::RS, PS = C::PS, P1 = C::P1, P2 = C::P2;
-    constexpr int N1 = C::N1, N2 = C::N2, NPF = C::NPF;
+    constexpr int N1 = C::N1, N2 = C::N2, NPF = C::NPF, PSP = C::PSP, ZP = C::ZP, PPW = C::PPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     if (*a.desc_total != mg.expect_slots) return;      // sliced tiles: interp_tile_kernel serves this point set
@@ -140,7 +157,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
             const uint2 pr = make_uint2(a.offsets[bin0], a.offsets[bin0 + nbx]);
             runs[lay * kMarchMaxRows + row] = pr;
             any |= pr.x != pr.y;
-            atomicMax(&maxp[lay], (int)((pr.y - pr.x + GP::PPW - 1) / GP::PPW));
+            atomicMax(&maxp[lay], (int)((pr.y - pr.x + PPW - 1) / PPW));
         }
         if (any) counter[1] = 1;
     }
@@ -162,7 +179,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
         const int k = e / PS;
         int gz = zbase + k;
         if (gz < 0) gz += g.Nover[2];
-        ring[e] = *src_of(gz, e % PS);
+        ring[k * PSP + e % PS] = *src_of(gz, e % PS);
     }
 
     // lane roles: G lanes per point, lane q = (j1, component) — or j1 alone with both components per lane (PAIR)
@@ -174,13 +191,27 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
         if constexpr (PAIR) return __builtin_elementwise_fma(x, VT{w, w}, acc);
         else return fma(x, w, acc);
     };
-    const int grp = lane / GP::G, q = lane % GP::G;
+    const int grp = lane / (GP::G * ZP), q = lane % GP::G;
+    const int zp = ZP > 1 ? (lane / GP::G) % ZP : 0;   // which of the point's rows: stencil planes zp, zp + ZP, ...
     const bool lane_active = q < GP::W1;
     const int comp = q % NCL, j1 = (q / NCL) % L;
     T* strip = strip_wave + grp * (3 * L);
     using WEv = WindowEval<T, NCL, 3, M, GP::G, false>;
     WEv we;
     we.init(a, q);
+    if constexpr (ZP == 2) {
+        // the second row holds the dimension-3 values with neighbouring pairs exchanged: a row broadcast from lane 2 jj
+        // then hands row 0 value 2 jj and row 1 value 2 jj + 1 — each row the weight of its own plane
+        if (zp) {
+#pragma unroll
+            for (int sl = 0; sl < WEv::NSLOT; ++sl)
+                if (we.dsel[sl] == 2) {
+                    we.jsel[sl] ^= 1;
+#pragma unroll
+                    for (int c = 0; c < WEv::NP; ++c) we.cs[sl][c] = a.coefs[(2 * WEv::NP + c) * L + we.jsel[sl]];
+                }
+        }
+    }
     const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.sorted);
     T* vout = a.vout[comp_id];
     __syncthreads();
@@ -219,7 +250,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
             if (item >= nitems) break;
             const int rl = item % nrl, kl = rl / nrows;
             const uint2 pr = runs[(lay0 + kl) * kMarchMaxRows + rl % nrows];
-            const uint32_t p0 = pr.x + (uint32_t)(item / nrl) * GP::PPW, p1 = pr.y;
+            const uint32_t p0 = pr.x + (uint32_t)(item / nrl) * PPW, p1 = pr.y;
             if (p0 >= p1) continue;
             const uint32_t p = p0 + grp;
             const bool have = p < p1;
@@ -233,7 +264,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
                 s[d] = c;
             }
             s[0] -= org1; s[1] -= org2;                   // first stencil node in padded-column coordinates
-            int s3 = pm + 4 * kl + (s[2] & 3);           // ring slot of the first stencil plane
+            int s3 = pm + 4 * kl + (s[2] & 3) + zp;      // ring slot of this lane's first stencil plane
             if (s3 >= RZ) s3 -= RZ;
             T wv[WEv::NSLOT];
             T w1;
@@ -254,7 +285,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
                 return (lane & 8) ? hi : lo;
             };
             const T* base = ring + (s[0] + j1) * NC + comp + s[1] * RS;
-            int poff = s3 * PS;                          // plane offset of stencil plane j3 (wraps at RZ * PS)
+            int poff = s3 * PSP;                         // plane offset of the lane's stencil plane (wraps at RZ * PSP)
             T acc = T(0);
             VT accv = VT(0);
             if constexpr (C::REGW) {
@@ -266,18 +297,26 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
                 if constexpr (R > 0) {
                 // hand-scheduled LDS reads (as in interp_tile_kernel): groups of R rows with immediate offsets from the
                 // plane's own address (the ring wraps between planes), the next group in flight while this one is consumed
-                constexpr int GPP = L / R, NG = L * GPP, RB = RS * (int)sizeof(T);
+                constexpr int GPP = L / R, NG = (L / ZP) * GPP, RB = RS * (int)sizeof(T);
 
                 const uint32_t a0 = (uint32_t)(uintptr_t)base;
                 VT buf[2][R];
                 lds_read_rows<VT, R, 0, RB>(buf[0], a0 + (uint32_t)poff * (uint32_t)sizeof(T), std::make_integer_sequence<int, R>{});
-                VT t2 = VT(0);
+                // (ComplexF32: two accumulation chains per plane — a v_pk_fma_f32 that depends on the previous one issues
+                // every 6.2 cycles instead of 4.5 even with other waves to fill the gap, scripts/microbench10.hip)
+#ifndef NUFFT_MARCH_NT_ALL
+#define NUFFT_MARCH_NT_ALL 0
+#endif
+                constexpr int NT = (PAIR || NUFFT_MARCH_NT_ALL) ? 2 : 1;
+                VT t2[NT];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) t2[c] = VT(0);
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     if (gi + 1 < NG) {
-                        if ((gi + 1) % GPP == 0) {                 // next group starts the next plane
-                            poff += PS;
-                            if (poff >= RZ * PS) poff -= RZ * PS;
+                        if ((gi + 1) % GPP == 0) {                 // next group starts the lane's next plane
+                            poff += ZP * PSP;
+                            if (poff >= RZ * PSP) poff -= RZ * PSP;
                         }
                         const uint32_t ad = a0 + (uint32_t)poff * (uint32_t)sizeof(T) + (uint32_t)(((gi + 1) % GPP) * R * RB);
                         lds_read_rows<VT, R, 0, RB>(buf[(gi + 1) & 1], ad, std::make_integer_sequence<int, R>{});
@@ -286,30 +325,33 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
                         lds_wait_rows<0>(buf[gi & 1]);
                     }
 #pragma unroll
-                    for (int r = 0; r < R; ++r) t2 = vfma(buf[gi & 1][r], w2[(gi % GPP) * R + r], t2);
+                    for (int r = 0; r < R; ++r) t2[r % NT] = vfma(buf[gi & 1][r], w2[(gi % GPP) * R + r], t2[r % NT]);
                     if (gi % GPP == GPP - 1) {
-                        accv = vfma(t2, wfetch(2, gi / GPP), accv);
-                        t2 = VT(0);
+                        VT tp = t2[0];
+                        if constexpr (NT == 2) tp += t2[1];
+                        accv = vfma(tp, wfetch(2, ZP * (gi / GPP)), accv);
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) t2[c] = VT(0);
                     }
                 }
                 } else {
                     // wide stencils: the unrolled hand-scheduled form (2M x M groups) spills; the compiler schedules the reads
 #pragma unroll
-                    for (int j3 = 0; j3 < L; ++j3) {
+                    for (int j3 = 0; j3 < L; j3 += ZP) {
                         const VT* plane = reinterpret_cast<const VT*>(base + poff);
                         VT t2 = VT(0);
 #pragma unroll
                         for (int j2 = 0; j2 < L; ++j2) t2 = vfma(*reinterpret_cast<const VT*>(reinterpret_cast<const T*>(plane) + j2 * RS), w2[j2], t2);
                         accv = vfma(t2, wfetch(2, j3), accv);
-                        poff += PS;
-                        if (poff >= RZ * PS) poff -= RZ * PS;
+                        poff += ZP * PSP;
+                        if (poff >= RZ * PSP) poff -= RZ * PSP;
                     }
                 }
                 if constexpr (PAIR) {
                     const bool okl = have && lane_active;
-                    const T re = group_sum<T, GP::G, false>(okl ? accv[0] * w1 : T(0));
-                    const T im = group_sum<T, GP::G, false>(okl ? accv[1] * w1 : T(0));
-                    if (have && q == 0) *reinterpret_cast<VT*>(vout + (int64_t)rec.idx * 2) = VT{re * a.prefactor, im * a.prefactor};
+                    const T re = group_sum<T, GP::G * ZP, false>(okl ? accv[0] * w1 : T(0));
+                    const T im = group_sum<T, GP::G * ZP, false>(okl ? accv[1] * w1 : T(0));
+                    if (have && q == 0 && zp == 0) *reinterpret_cast<VT*>(vout + (int64_t)rec.idx * 2) = VT{re * a.prefactor, im * a.prefactor};
                     continue;
                 } else {
                     acc = accv;
@@ -326,13 +368,13 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
 #pragma unroll
                     for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * RS], w2[j2], t2);
                     acc = fma(t2, strip[2 * L + j3], acc);
-                    poff += PS;
-                    if (poff >= RZ * PS) poff -= RZ * PS;
+                    poff += PSP;
+                    if (poff >= RZ * PSP) poff -= RZ * PSP;
                 }
                 acc *= w1;
             }
-            acc = group_sum<T, GP::G, CPLX>(acc);
-            if (have && q < NC) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
+            acc = group_sum<T, GP::G * ZP, CPLX>(acc);
+            if (have && q < NC && zp == 0) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
         }
         __syncthreads();                                 // every wave has finished with this phase's window
         if (more) {
@@ -344,7 +386,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
                 if (e < BZ * PS) {
                     int slot = pm + e / PS;
                     if (slot >= RZ) slot -= RZ;
-                    ring[slot * PS + e % PS] = pf[u];
+                    ring[slot * PSP + e % PS] = pf[u];
                 }
             }
             pm += BZ;

@@ -15,7 +15,7 @@ for sub in ("a","b","c"):
         for r in csv.DictReader(open(f)):
             agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in agg.items():
-            if 'tile_kernel' in k or 'bin_' in k or 'patch_kernel' in k or 'gather' in k:
+            if 'tile_kernel' in k or 'bin_' in k or 'patch' in k or 'gather' in k or 'march' in k:
                 print(k)
                 for c,vals in sorted(v.items()):
                     print("   %-24s %.4g"%(c,sum(vals)/len(vals)))
