@@ -58,37 +58,53 @@ __global__ __launch_bounds__(256) void tile_work_kernel(Geom g, int D, int M, co
     if (lane == 0) work[wave] = sum;
 }
 
-// Slices of tile t: 1 + its share of the extra budget, proportional to its work.  One workgroup: it first
-// sums the work of each tiling (a global atomic per tile on one address costs 0.4 ms for 3e4 tiles), then
-// writes nslices for every tile; entry nsp + nip is the terminator of the exclusive scan.
-__global__ __launch_bounds__(1024) void tile_slices_kernel(const uint32_t* __restrict__ work, int nsp, int nip,
-                                                          uint32_t extra_sp, uint32_t extra_ip, uint32_t smax,
-                                                          uint32_t* __restrict__ nslices) {
-    __shared__ unsigned long long part[2][1024 / kWave];
-    __shared__ unsigned long long tot[2];
+// Slices of tile t: 1 + its share of the extra budget, proportional to its work.  Two kernels: kSumBlocks workgroups sum
+// the work of each tiling into partial sums (a global atomic per tile on one address costs 0.4 ms for 3e4 tiles; one
+// workgroup doing everything took 0.62 ms for the 7e5 tiles of a 1024^3 grid), then every workgroup of the second kernel
+// adds the partial sums up and writes nslices for its tiles; entry nsp + nip is the terminator of the exclusive scan.
+constexpr int kSumBlocks = 128;
+
+__global__ __launch_bounds__(256) void tile_work_sums_kernel(const uint32_t* __restrict__ work, int nsp, int nip,
+                                                            unsigned long long* __restrict__ part) {
+    __shared__ unsigned long long wsum[2][256 / kWave];
     const int tid = threadIdx.x, n = nsp + nip;
     unsigned long long acc[2] = {0ull, 0ull};
-    for (int t = tid; t < n; t += blockDim.x) acc[t >= nsp ? 1 : 0] += work[t];
+    for (int t = blockIdx.x * blockDim.x + tid; t < n; t += gridDim.x * blockDim.x) acc[t >= nsp ? 1 : 0] += work[t];
     for (int k = 0; k < 2; ++k) {
         unsigned long long v = acc[k];
         for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
-        if ((tid & (kWave - 1)) == 0) part[k][tid / kWave] = v;
+        if ((tid & (kWave - 1)) == 0) wsum[k][tid / kWave] = v;
     }
     __syncthreads();
     if (tid < 2) {
         unsigned long long v = 0;
-        for (int w = 0; w < (int)blockDim.x / kWave; ++w) v += part[tid][w];
-        tot[tid] = v;
+        for (int w = 0; w < 256 / kWave; ++w) v += wsum[tid][w];
+        part[tid * kSumBlocks + blockIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_slices_kernel(const uint32_t* __restrict__ work, int nsp, int nip,
+                                                         uint32_t extra_sp, uint32_t extra_ip, uint32_t smax,
+                                                         const unsigned long long* __restrict__ part,
+                                                         uint32_t* __restrict__ nslices) {
+    __shared__ unsigned long long tot[2];
+    const int tid = threadIdx.x, n = nsp + nip;
+    if (tid < 2 * kWave) {                              // waves 0, 1: total work of the spreading / interpolation tiling
+        const int k = tid / kWave, lane = tid & (kWave - 1);
+        unsigned long long v = 0;
+        for (int b = lane; b < kSumBlocks; b += kWave) v += part[k * kSumBlocks + b];
+        for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+        if (lane == 0) tot[k] = v;
     }
     __syncthreads();
-    for (int t = tid; t <= n; t += blockDim.x) {
-        if (t == n) { nslices[t] = 0; continue; }
-        const bool interp = t >= nsp;
-        const unsigned long long W = tot[interp ? 1 : 0];
-        unsigned long long s = W ? (unsigned long long)work[t] * (interp ? extra_ip : extra_sp) / W : 0ull;
-        if (s > smax - 1) s = smax - 1;
-        nslices[t] = 1u + (uint32_t)s;
-    }
+    const int t = blockIdx.x * blockDim.x + tid;
+    if (t > n) return;
+    if (t == n) { nslices[t] = 0; return; }
+    const bool interp = t >= nsp;
+    const unsigned long long W = tot[interp ? 1 : 0];
+    unsigned long long s = W ? (unsigned long long)work[t] * (interp ? extra_ip : extra_sp) / W : 0ull;
+    if (s > smax - 1) s = smax - 1;
+    nslices[t] = 1u + (uint32_t)s;
 }
 
 // descriptor of slot q: x = tile, y = slice << 16 | slices of the tile.  Spreading slots start at desc[0],
@@ -110,6 +126,12 @@ __global__ __launch_bounds__(64) void fill_desc_kernel(const uint32_t* __restric
     }
 }
 
+// 32-bit words of the work buffer: one counter per tile of both tilings, then (8-byte aligned) the 2 x kSumBlocks
+// 64-bit partial sums of tile_work_sums_kernel
+size_t balance_work_words(int ntiles_both) {
+    return (((size_t)ntiles_both + 1 + 1) & ~(size_t)1) + 4 * (size_t)kSumBlocks;
+}
+
 size_t balance_scan_tmp_bytes(int ntiles_both) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, ntiles_both + 1);
@@ -121,8 +143,11 @@ hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream) {
     const int waves_per_block = 256 / kWave;
     hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((n + waves_per_block - 1) / waves_per_block)), dim3(256), 0, stream,
                        b.g, b.D, b.M, b.offsets, b.work);
-    hipLaunchKernelGGL(tile_slices_kernel, dim3(1), dim3(1024), 0, stream, b.work, nsp, nip,
-                       b.enabled ? b.extra_sp : 0u, b.enabled ? b.extra_ip : 0u, b.smax, b.nslices);
+    // (the partial sums live behind the n + 1 work counters: balance_work_words())
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(b.work + balance_work_words(n) - 4 * kSumBlocks);
+    hipLaunchKernelGGL(tile_work_sums_kernel, dim3(kSumBlocks), dim3(256), 0, stream, b.work, nsp, nip, part);
+    hipLaunchKernelGGL(tile_slices_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, b.work, nsp, nip,
+                       b.enabled ? b.extra_sp : 0u, b.enabled ? b.extra_ip : 0u, b.smax, part, b.nslices);
     size_t tmp = b.scan_tmp_bytes;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, tmp, b.nslices, b.desc_off, n + 1, stream);
     if (e != hipSuccess) return e;

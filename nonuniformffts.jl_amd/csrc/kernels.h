@@ -49,6 +49,7 @@ struct BalanceArgs {
     size_t scan_tmp_bytes;
 };
 size_t balance_scan_tmp_bytes(int ntiles_both);
+size_t balance_work_words(int ntiles_both);       // 32-bit words of BalanceArgs::work (tile counters + partial sums)
 hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream);
 hipError_t launch_zero_split_tiles(int dtype, const Geom& g, int D, int is_complex, int C, const uint32_t* nslices,
                                    void* grid, int64_t grid_stride_reals, hipStream_t stream);

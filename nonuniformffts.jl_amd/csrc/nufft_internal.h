@@ -146,7 +146,7 @@ struct nufft_plan {
     // load balance (balance.hip): arrays over the tiles of both tilings, spreading tiles first
     struct Balance {
         uint32_t extra[2] = {0, 0};        // budget of extra slices = extra workgroups in the launch grids
-        uint32_t* d_work = nullptr;        // [nsp + nip]
+        uint32_t* d_work = nullptr;        // [balance_work_words(nsp + nip)]: work per tile, then the partial sums
         uint32_t* d_nslices = nullptr;     // [nsp + nip + 1]
         uint32_t* d_desc_off = nullptr;    // [nsp + nip + 1]
         void* d_desc = nullptr;            // uint2[nsp + extra_sp + nip + extra_ip]

@@ -420,7 +420,7 @@ static int build_device(nufft_plan* p) {
         const int64_t nsp = p->tile.sp.ntiles, nip = p->tile.ip.ntiles;
         b.extra[0] = p->balance_enabled ? (uint32_t)std::max<int64_t>(1024, nsp / 4) : 0u;
         b.extra[1] = p->balance_enabled ? (uint32_t)std::max<int64_t>(1024, nip / 4) : 0u;
-        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_work), (size_t)(nsp + nip) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_work), balance_work_words((int)(nsp + nip)) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_nslices), (size_t)(nsp + nip + 1) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_desc_off), (size_t)(nsp + nip + 1) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, &b.d_desc, (size_t)(nsp + nip + b.extra[0] + b.extra[1]) * 8))) return rc;
