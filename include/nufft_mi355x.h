@@ -250,6 +250,12 @@ int nufft_get_stage_times(nufft_plan* plan, float* ms_out);
  * set that concentrates in a few patches goes to the LDS tiles, whose heavy tiles are shared by several workgroups);
  * this reads the decision back (4 bytes, synchronises `stream`).  Inspection only: nothing on the hot path needs it. */
 int nufft_spread_engine_used(nufft_plan* plan, int* engine_out, void* stream);
+/* The same for the interpolation stage of nufft_exec_type2: NUFFT_INTERP_LDS_TILES (padded boxes, heavy tiles shared by
+ * several workgroups: interp_tile_kernel) or NUFFT_INTERP_MARCHING_RING (3-D plans with the default window evaluation,
+ * point sets whose tiles needed no slices: interp_march_kernel).  Replaces nothing in the reference — its
+ * interpolate! (src/interpolation/gpu.jl:3-89) has one shared-memory kernel; inspection only. */
+enum { NUFFT_INTERP_LDS_TILES = 1, NUFFT_INTERP_MARCHING_RING = 2 };
+int nufft_interp_engine_used(nufft_plan* plan, int* engine_out, void* stream);
 
 /* ---- misc ----------------------------------------------------------------------------- */
 /* sizeof(nufft_params) / sizeof(nufft_info) of the library build: a binding that mirrors the structs by hand

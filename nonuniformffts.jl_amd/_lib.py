@@ -100,6 +100,7 @@ SYMBOLS = {
     "nufft_set_timing": (C.c_int, [_P, C.c_int]),
     "nufft_get_stage_times": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "nufft_spread_engine_used": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "nufft_interp_engine_used": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "nufft_sizeof_params": (C.c_int64, []),
     "nufft_sizeof_info": (C.c_int64, []),
     "nufft_strerror": (C.c_char_p, [C.c_int]),

@@ -60,9 +60,10 @@ struct MarchCfg {
     // window values can stay in registers as for real data.
     // (ComplexF32 only: 128-bit reads of ComplexF64 pairs run the LDS at a quarter of its rate, scripts/microbench7.hip —
     // measured here: ComplexF64 m = 4 interpolation 5.5 ms paired against 4.4 ms with the tile kernel)
-    static constexpr bool PAIR = CPLX && sizeof(T) == 4 && next_pow2(L) <= 16;
+    static constexpr bool PAIR = CPLX && sizeof(T) == 4 && (next_pow2(L) == 8 || next_pow2(L) == 16);   // (window values in registers: REGW)
     using GP = Grp<PAIR ? 1 : NC, M>;
     static constexpr bool REGW = (!CPLX || PAIR) && (GP::G == 8 || GP::G == 16);   // window values stay in registers (DPP broadcasts)
+    static_assert(!PAIR || REGW, "the paired gather exists in the register-window form only");
     // A row of 16 lanes reads 16 contiguous nodes = HALF the banks its 32-lane LDS group spans, so the two points that
     // share a group collide on every read unless their rows happen to be complementary (C3: LDS array busy twice the
     // ideal time, 80 % of the kernel).  ZP = 2: both rows of a group belong to ONE point and gather alternate stencil
@@ -113,7 +114,7 @@ struct MarchCfg {
     static constexpr int RING_BYTES = round_up(RZ * PSP * (int)sizeof(T), 16);
     static constexpr int lds_bytes() { return RING_BYTES + fixed_bytes(); }
     static constexpr int NPF = (BZ * PS + THREADS - 1) / THREADS;    // prefetched reals per thread and layer
-    static constexpr bool FITS = N1 > 0;                // (ComplexF64 at M >= 9: not even a 4 x 4 column fits 160 KiB)
+    static constexpr bool FITS = N1 > 0;                // (ComplexF64 at M = 10: not even a 4 x 4 column fits 160 KiB)
 };
 
 template <typename T, bool CPLX, int M>
@@ -293,7 +294,8 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
 #pragma unroll
                 for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
                 // rows per group of the hand-scheduled form (0: compiler-scheduled reads): what compiles without spills
-                constexpr int R = L <= 8 ? ((CPLX || C::THREADS != 512) ? 2 : 4) : (L % 8 == 0 ? 8 : (L % 4 == 0 ? 4 : 0));
+                constexpr int R = L <= 8 ? ((CPLX || C::THREADS != 512 || L % 4 != 0) ? 2 : 4) : (L % 8 == 0 ? 8 : (L % 4 == 0 ? 4 : 0));
+                static_assert(R == 0 || L % R == 0, "row groups must tile the stencil");
                 if constexpr (R > 0) {
                 // hand-scheduled LDS reads (as in interp_tile_kernel): groups of R rows with immediate offsets from the
                 // plane's own address (the ring wraps between planes), the next group in flight while this one is consumed

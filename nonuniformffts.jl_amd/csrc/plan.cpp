@@ -418,8 +418,11 @@ static int build_device(nufft_plan* p) {
     {
         nufft_plan::Balance& b = p->bal;
         const int64_t nsp = p->tile.sp.ntiles, nip = p->tile.ip.ntiles;
-        b.extra[0] = p->balance_enabled ? (uint32_t)std::max<int64_t>(1024, nsp / 4) : 0u;
-        b.extra[1] = p->balance_enabled ? (uint32_t)std::max<int64_t>(1024, nip / 4) : 0u;
+        // budget of extra slices per tiling (NUFFT_BALANCE_EXTRA: tests force 0 so that small grids, where the budget
+        // always reaches some tile, still run the engines that serve unsliced point sets)
+        const int64_t extra_env = env_int("NUFFT_BALANCE_EXTRA", -1);
+        b.extra[0] = p->balance_enabled ? (uint32_t)(extra_env >= 0 ? extra_env : std::max<int64_t>(1024, nsp / 4)) : 0u;
+        b.extra[1] = p->balance_enabled ? (uint32_t)(extra_env >= 0 ? extra_env : std::max<int64_t>(1024, nip / 4)) : 0u;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_work), balance_work_words((int)(nsp + nip)) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_nslices), (size_t)(nsp + nip + 1) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&b.d_desc_off), (size_t)(nsp + nip + 1) * sizeof(uint32_t)))) return rc;
@@ -1026,6 +1029,21 @@ int nufft_spread_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
     NUFFT_HIP(hipMemcpyAsync(&flag, p->d_patch_choice + 2, sizeof(flag), hipMemcpyDeviceToHost, stream));
     NUFFT_HIP(hipStreamSynchronize(stream));
     *engine_out = flag ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
+    return NUFFT_OK;
+}
+
+int nufft_interp_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    if (!engine_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
+    *engine_out = NUFFT_INTERP_LDS_TILES;
+    if (!p->interp_march || !p->balance_enabled) return NUFFT_OK;
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    uint32_t slots = 0;                   // interpolation slots in use: more than one per tile = sliced tiles
+    NUFFT_HIP(hipMemcpyAsync(&slots, p->bal.d_slots + 1, sizeof(slots), hipMemcpyDeviceToHost, stream));
+    NUFFT_HIP(hipStreamSynchronize(stream));
+    if (slots == (uint32_t)p->tile.ip.ntiles) *engine_out = NUFFT_INTERP_MARCHING_RING;
     return NUFFT_OK;
 }
 

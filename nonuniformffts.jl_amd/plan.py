@@ -320,6 +320,13 @@ class PlanNUFFT:
         _check(lib.nufft_spread_engine_used(self._handle, C.byref(out), self._stream()))
         return {1: "lds_tiles", 2: "mfma_patches"}[out.value]
 
+    def interp_engine_used(self) -> str:
+        """Engine that interpolates the point set of the last set_points in exec_type2: "lds_tiles" or "marching_ring"
+        (decided on the device: the ring serves point sets whose tiles needed no slices); synchronises."""
+        out = C.c_int(0)
+        _check(lib.nufft_interp_engine_used(self._handle, C.byref(out), self._stream()))
+        return {1: "lds_tiles", 2: "marching_ring"}[out.value]
+
     @property
     def size(self) -> Tuple[int, ...]:
         """size(p): dims of the uniform arrays in Julia order (N1÷2+1, N2, ...) for real Z."""

@@ -418,6 +418,42 @@ def test_patch_engine_every_instantiation(Z, M, monkeypatch):
     assert _rel(u.cpu().numpy(), ref) < _rtol(Z)
 
 
+@pytest.mark.parametrize("M", range(2, 11))
+@pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
+def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
+    """Every (element type, M) instantiation of interp_march_kernel against the oracle (type 2, both window evaluations).
+    Oversampled grid 96 x 80 x 112: partial columns at the upper ends of dimensions 1 and 2, several segments along
+    dimension 3.  The ring serves point sets whose tiles needed no slices; on a grid this small the slice budget (at
+    least 1024 extra workgroups) always reaches some tile, so the test plans get no budget (NUFFT_BALANCE_EXTRA=0) and
+    nufft_interp_engine_used confirms the device-side decision.  ComplexF64 at M = 10 has no ring (no column fits
+    160 KiB): LDS tiles there, and for the default-budget plan at the end."""
+    has_ring = not (np.dtype(Z) == np.complex128 and M >= 10)
+    dims, Np = (48, 40, 56), 4000
+    monkeypatch.setenv("NUFFT_BALANCE_EXTRA", "0")
+    for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
+        nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=100 + M)
+        dev = plan.device
+        rng = np.random.default_rng(5 + M)
+        w = (rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape))
+        w = w.astype(np.complex64 if plan_real_dtype(Z) == np.float32 else np.complex128)
+        wd = torch.from_numpy(w).to(dev)
+        nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+        O.set_points(oplan, xs)
+        out = torch.empty(Np, dtype=plan.Z, device=dev)
+        nufft.exec_type2(out, plan, wd)
+        assert plan.interp_engine_used() == ("marching_ring" if has_ring else "lds_tiles"), evalmode
+        ref = O.exec_type2(oplan, _oracle_inputs(oplan, [w])[0])
+        assert _rel(out.cpu().numpy(), ref) < _rtol(Z), evalmode
+    # the same transform on a plan with the default budget: sliced tiles, LDS-tile kernel, same result
+    monkeypatch.delenv("NUFFT_BALANCE_EXTRA")
+    nufft, plan2, _, _, _ = _make_case(Z, dims, M, 2.0, O.DIRECT, 1, Np, seed=100 + M)
+    nufft.set_points(plan2, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    out2 = torch.empty(Np, dtype=plan2.Z, device=dev)
+    nufft.exec_type2(out2, plan2, wd)
+    assert plan2.interp_engine_used() == "lds_tiles"
+    assert _rel(out2.cpu().numpy(), ref) < _rtol(Z)
+
+
 def test_spreading_engine_selection():
     nufft = _nufft()
     # explicit request on a plan the patches cannot serve (2-D; odd oversampled size) -> ArgumentError, nothing silent
