@@ -420,6 +420,46 @@ def test_patch_engine_every_instantiation(Z, M, monkeypatch):
 
 @pytest.mark.parametrize("M", range(2, 11))
 @pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
+def test_lds_tile_spreading_every_instantiation(Z, M):
+    """Every (element type, M) instantiation of spread_tile_kernel on a 3-D grid larger than its tile (compile-time tile
+    variants where the plan has them) against the oracle, type 1, both window evaluations."""
+    dims, Np = (48, 40, 56), 3000
+    for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
+        nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M, spread_method="lds_tiles")
+        assert plan.info().spread_method == 1
+        dev = plan.device
+        nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+        O.set_points(oplan, xs)
+        u = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+        nufft.exec_type1(u, plan, torch.from_numpy(vs[0]).to(dev))
+        assert plan.spread_engine_used() == "lds_tiles"
+        ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs)[0])
+        assert _rel(u.cpu().numpy(), ref) < _rtol(Z), evalmode
+
+
+@pytest.mark.parametrize("M", range(2, 7))
+@pytest.mark.parametrize("C", [2, 3])
+@pytest.mark.parametrize("Z", [np.float32, np.float64])
+def test_planar_patch_every_instantiation(Z, C, M):
+    """Every (element type, ntransforms, M) instantiation of the patch kernel with planar components (one set-up for the
+    C value vectors of a real plan) against the oracle, type 1; 96 x 80 x 112 oversampled: partial patch rows."""
+    Np = 2500
+    nufft, plan, oplan, xs, vs = _make_case(Z, (48, 40, 56), M, 2.0, O.FAST_APPROXIMATION, C, Np, seed=200 + 10 * C + M,
+                                            spread_method="mfma_patches")
+    assert plan.info().spread_method == 2 and plan.info().patch_planar == C
+    dev = plan.device
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    O.set_points(oplan, xs)
+    us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    nufft.exec_type1(us, plan, tuple(torch.from_numpy(v).to(dev) for v in vs))
+    assert plan.spread_engine_used() == "mfma_patches"
+    ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs))
+    for c in range(C):
+        assert _rel(us[c].cpu().numpy(), ref[c]) < _rtol(Z), c
+
+
+@pytest.mark.parametrize("M", range(2, 11))
+@pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
 def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
     """Every (element type, M) instantiation of interp_march_kernel against the oracle (type 2, both window evaluations).
     Oversampled grid 96 x 80 x 112: partial columns at the upper ends of dimensions 1 and 2, several segments along
