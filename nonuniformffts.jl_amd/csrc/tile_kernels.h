@@ -833,14 +833,13 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
 // ---------------------------------------------------------------------------------------------
 // FIXED: the tile shape is the compile-time one of fixed_interp_tile() (the host launches this variant
 // only when the plan's tile equals it), which turns the LDS strides into immediates.
-template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK = false>
-__global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
+template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK>
+__device__ __forceinline__ void interp_tile_slot(const TileArgs<T>& a, const uint32_t slot, const uint32_t nslots, unsigned char* smem) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
     using GP = Grp<NC, M>;
     constexpr FixedTileDims FD = fixed_interp_tile((int)sizeof(T), NC, D, M);
     static_assert(!FIXED || FD.n[0] > 0, "no compile-time tile for this instantiation");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -850,10 +849,7 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     const Geom& g = a.g;
     const TileShape& ts = g.ip;
 
-    const uint32_t nslots = *a.desc_total;
-    if (blockIdx.x >= nslots) return;
-    if (a.march_slots != 0u && nslots == a.march_slots) return;     // this point set goes to interp_march_kernel
-    const uint2 de = a.desc[xcd_remap_chunked(blockIdx.x, (int)nslots, a.xcd_chunk)];
+    const uint2 de = a.desc[xcd_remap_chunked((int)slot, (int)nslots, a.xcd_chunk)];
     const int tile_id = (int)de.x, slice = (int)(de.y >> 16), nslices = (int)(de.y & 0xffffu);
     const int comp_id = blockIdx.y;
     int t[3];
@@ -1109,6 +1105,20 @@ __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
             }
             rec = recn;
         }
+    }
+}
+
+// One workgroup per slot — or, where the z-marching ring may serve the point set instead, a bounded grid whose workgroups
+// stride over the slots: the launch that finds nothing to do then costs 8192 workgroups, not one per tile (0.76 ms of
+// 1024-thread workgroups that only returned, at C3's 7e5 tiles).
+template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK = false>
+__global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t nslots = *a.desc_total;
+    if (a.march_slots != 0u && nslots == a.march_slots) return;     // this point set goes to interp_march_kernel
+    for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+        interp_tile_slot<T, CPLX, D, M, FIXED, OTHERK>(a, slot, nslots, smem);
+        __syncthreads();                                            // the next slot reuses the tile and the item table
     }
 }
 

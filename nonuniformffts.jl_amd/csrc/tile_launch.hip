@@ -6,6 +6,8 @@
 #include "kernels.h"
 #include "tile_kernels.h"
 #include "patch_kernels.h"
+#include <algorithm>
+
 #include "march_kernels.h"
 #include "patch32_kernels.h"
 
@@ -183,7 +185,9 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
         k.march_slots = march_slots;
         void* params[] = {&k};
-        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
+        // (a.ntiles = the slot budget; with the ring beside it the tile kernel strides over the slots from a bounded grid)
+        const unsigned grid_x = march ? (unsigned)std::min<int64_t>(a.ntiles, 8192) : (unsigned)a.ntiles;
+        hipError_t e = hipLaunchKernel(fn, dim3(grid_x, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
                                        params, (size_t)a.lds_bytes, stream);
         if (e != hipSuccess) return e;
         if (march) {
