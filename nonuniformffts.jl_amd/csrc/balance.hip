@@ -9,6 +9,8 @@
 // tile simply load the same tile.  The launch grid is fixed (tiles + a budget of extra slices), so no
 // device-to-host synchronisation is needed; surplus workgroups exit at once.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 
 #include "device_common.h"
@@ -156,31 +158,175 @@ hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Which spreading engine serves this point set (plans whose engine is the MFMA patches): the patches have no slices —
-// a wave owns its patch for a whole segment of cube layers — so a point set that concentrates in a few patches would
-// serialise on them (folded N(0, 1) coordinates, the reference's own benchmark distribution, put 15x the mean into the
-// central tasks).  One wave per patch task counts the points of its own bins; the last workgroup to finish compares
-// the heaviest task with an even share of the wave slots and writes the verdict: choice[2] = 1 (patches) and no
-// slots for the LDS-tile kernel, or choice[2] = 0 and the tile kernel runs as usual.  No host read-back.
-__global__ __launch_bounds__(256) void patch_choice_kernel(Geom g, PatchPlan pp, int pby, const uint32_t* __restrict__ offsets,
-                                                          unsigned long long np, unsigned long long slots_num,
-                                                          unsigned long long share_den, uint32_t* __restrict__ choice,
-                                                          uint32_t* __restrict__ slots_in_use) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    const int lane = threadIdx.x & (kWave - 1);
-    if (wave < pp.ntasks) {
-        const int px = wave % pp.npx, py = (wave / pp.npx) % pp.npy, seg = wave / (pp.npx * pp.npy);
-        const int bx0 = px * 4, by0 = py * pby;
-        const int ncx = min(4, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
-        const int z0 = seg * pp.segl, z1 = min(z0 + pp.segl, g.nb[2]);
+// ---- tasks of the MFMA-patch engine, per point set ------------------------------------------------------------------
+// A patch task is a wave that owns a patch column (4 x pby cube columns) for a segment of cube layers along dimension 3;
+// it is not shared between workgroups, so the heaviest task bounds the kernel.  Segments of equal LENGTH serialise on
+// non-uniform point sets (folded N(0, 1) coordinates, the reference's own benchmark distribution, put 15x the mean into
+// the central tasks), so set_points cuts every column into segments of about equal point COUNT: column c gets
+// S_c = 1 + (T - columns) * points(c) / Np of the plan's T tasks, and its segment boundaries are the quantiles of its
+// points along dimension 3 (multiples of `zq` layers: the Float32-accumulating kernel retires whole octets).  The table
+// {column, first layer, end layer} per task stays on the device; tasks that received nothing are empty entries.
+// The last workgroup then decides which engine serves this point set: a segment cannot be shorter than zq layers, so a
+// point set that concentrates in a few layers of a few columns still leaves tasks too heavy for the patches and goes to
+// the LDS tiles, whose heavy tiles are shared by several workgroups.  choice[2] = 1: patches (and no slots for the LDS-tile
+// kernel), 0: tiles.  No host read-back.
+constexpr int kPatchMaxLayers = 2048;                   // bin layers of a column the splitter holds in LDS (per wave)
+
+__global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx, int npy, int pby, int segl, const uint32_t* __restrict__ offsets,
+                                                               uint32_t* __restrict__ colsum, uint32_t* __restrict__ choice) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, lane = threadIdx.x & (kWave - 1);
+    if (c >= npx * npy) return;
+    const int bx0 = (c % npx) * 4, by0 = (c / npx) * pby;
+    const int ncx = min(4, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
+    uint32_t total = 0, heaviest = 0;
+    for (int z0 = 0; z0 < g.nb[2]; z0 += segl) {        // segments of equal length: the partition uniform point sets keep
+        const int nl = min(segl, g.nb[2] - z0);
         uint32_t sum = 0;
-        for (int item = lane; item < ncy * (z1 - z0); item += kWave) {
-            const int by = by0 + item % ncy, bz = z0 + item / ncy;
-            const int64_t bin0 = ((int64_t)bz * g.nb[1] + by) * g.nb[0] + bx0;
+        for (int item = lane; item < ncy * nl; item += kWave) {
+            const int64_t bin0 = ((int64_t)(z0 + item / ncy) * g.nb[1] + by0 + item % ncy) * g.nb[0] + bx0;
             sum += offsets[bin0 + ncx] - offsets[bin0];
         }
         for (int o = kWave / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, kWave);
-        if (lane == 0) atomicMax(&choice[0], sum);
+        sum = __shfl(sum, 0, kWave);
+        total += sum;
+        heaviest = max(heaviest, sum);
+    }
+    if (lane == 0) {
+        colsum[c] = total;
+        atomicMax(&choice[3], heaviest);
+    }
+}
+
+// one workgroup: equal-length segments if their heaviest task is within 10 % (+ 5 sigma of a Poisson count) of the mean
+// task — uniform point sets keep exactly the partition they always had, whose tasks differ by a per cent, where quantile
+// boundaries on whole layers would make them differ by a layer's worth (9 % at 11 layers per segment) — else
+// S_c = round(T points(c) / Np) segments per column; their exclusive scan (first[c]; first[ncols] = tasks in use; the table
+// holds T + columns entries, enough for any rounding), empty entries behind.  choice[3] = 1: equal-length mode.
+__global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int ntasks, int ntab, int nseg, int max_seg, unsigned long long np,
+                                                                const uint32_t* __restrict__ colsum, uint32_t* __restrict__ first,
+                                                                uint2* __restrict__ tasktab, uint32_t* __restrict__ choice) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    __shared__ int uniform_mode;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        carry = 0;
+        const double mean = (double)np / (double)ntasks;
+        const uint32_t heaviest = choice[3];
+        uniform_mode = (double)heaviest <= 1.1 * mean + 5.0 * sqrt(mean) + 8.0;
+        choice[3] = uniform_mode ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool uni = uniform_mode != 0;
+    for (int c0 = 0; c0 < ncols; c0 += 1024) {
+        const int c = c0 + tid;
+        uint32_t S = 0;
+        if (c < ncols) {
+            if (uni) S = (uint32_t)nseg;
+            else {
+                S = np ? (uint32_t)(((unsigned long long)ntasks * colsum[c] + np / 2) / np) : 1u;
+                S = S < 1u ? 1u : (S > (uint32_t)max_seg ? (uint32_t)max_seg : S);
+            }
+        }
+        part[tid] = S;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {             // inclusive scan of the chunk
+            const uint32_t v = tid >= o ? part[tid - o] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (c < ncols) first[c] = carry + part[tid] - S;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) first[ncols] = carry;
+    for (int t = (int)carry + tid; t < ntab; t += 1024) tasktab[t] = make_uint2(0u, 0u);
+}
+
+__global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int npy, int pby, int clo, int chi, int zq, int segl,
+                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ first,
+                                                         unsigned long long limit, unsigned long long slots_eff,
+                                                         uint2* __restrict__ tasktab, uint32_t* __restrict__ choice,
+                                                         uint32_t* __restrict__ slots_in_use) {
+    __shared__ uint32_t cum_all[256 / kWave][kPatchMaxLayers + 1];
+    const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.x * (256 / kWave) + w;
+    const int nz = g.nb[2];
+    uint32_t* cum = cum_all[w];
+    unsigned long long wsum = 0;
+    uint32_t wmax = 0;
+    if (c < npx * npy) {
+        const int bx0 = (c % npx) * 4, by0 = (c / npx) * pby;
+        const int ncx = min(4, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
+        // points per layer, then their running sum: lane l owns the layers [l * per, (l + 1) * per)
+        const int per = (nz + kWave - 1) / kWave;
+        uint32_t run = 0;
+        for (int k = 0; k < per; ++k) {
+            const int z = lane * per + k;
+            if (z < nz) {
+                uint32_t n = 0;
+                for (int y = 0; y < ncy; ++y) {
+                    const int64_t bin0 = ((int64_t)z * g.nb[1] + by0 + y) * g.nb[0] + bx0;
+                    n += offsets[bin0 + ncx] - offsets[bin0];
+                }
+                run += n;
+                cum[z + 1] = run;                        // (local to the lane's chunk for now)
+            }
+        }
+        uint32_t incl = run;                             // inclusive scan of the chunk sums over the lanes
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += v;
+        }
+        const uint32_t before = incl - run;
+        for (int k = 0; k < per; ++k) {
+            const int z = lane * per + k;
+            if (z < nz) cum[z + 1] += before;
+        }
+        if (lane == 0) cum[0] = 0;
+        wave_lds_fence();
+        const uint32_t total = cum[nz];
+        const uint32_t t0 = first[c], S = first[c + 1] - t0;
+        const bool uni = choice[3] != 0u;                 // equal-length segments, stored in launch order (segment, column)
+        auto boundary = [&](uint32_t k) -> int {          // first layer of segment k (k = S: the end)
+            if (k == 0) return 0;
+            if (k >= S) return nz;
+            if (uni) return min(nz, (int)k * segl);
+            int z;
+            if (total == 0) {
+                z = (int)((unsigned long long)k * nz / S);
+            } else {
+                const uint32_t target = (uint32_t)(((unsigned long long)k * total + S - 1) / S);
+                int lo = 0, hi = nz;                      // smallest z with cum[z] >= target
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cum[mid] >= target) hi = mid; else lo = mid + 1;
+                }
+                z = lo;
+            }
+            z = (z + zq - 1) / zq * zq;
+            return z < nz ? z : nz;
+        };
+        for (uint32_t k = lane; k < S; k += kWave) {
+            const int z0 = boundary(k), z1 = boundary(k + 1);
+            tasktab[uni ? k * (uint32_t)(npx * npy) + (uint32_t)c : t0 + k] = make_uint2((uint32_t)c, z1 > z0 ? ((uint32_t)z1 << 16) | (uint32_t)z0 : 0u);
+            if (z1 > z0) {
+                // the points a task visits along dimension 3: its own layers and the stencil's reach beyond them
+                const uint32_t work = cum[min(nz, z1 - clo)] - cum[max(0, z0 - chi)];
+                wsum += work;
+                wmax = max(wmax, work);
+            }
+        }
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            wsum += __shfl_down(wsum, o, kWave);
+            wmax = max(wmax, (uint32_t)__shfl_down(wmax, o, kWave));
+        }
+        if (lane == 0) {
+            atomicMax(&choice[0], wmax);
+            atomicAdd(reinterpret_cast<unsigned long long*>(choice + 4), wsum);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -189,26 +335,91 @@ __global__ __launch_bounds__(256) void patch_choice_kernel(Geom g, PatchPlan pp,
         if (ticket == gridDim.x - 1) {
             __threadfence();
             const unsigned long long mx = atomicExch(&choice[0], 0u);
+            const unsigned long long sum = atomicExch(reinterpret_cast<unsigned long long*>(choice + 4), 0ull);
             choice[1] = 0u;
-            // heaviest task <= np * slots_num / share_den (+ 64 points: tiny point sets fluctuate)
-            const bool patches = mx * share_den <= np * slots_num + 64ull * share_den || np == 0;
+            // the kernel takes about max(heaviest task, all tasks / wave slots) point visits per wave: patches while that
+            // stays within `limit` (launch_patch_tasks)
+            const bool patches = (mx <= limit && sum <= limit * slots_eff) || sum == 0ull || choice[3] != 0u;   // (equal-length mode: always)
             choice[2] = patches ? 1u : 0u;
             if (patches) slots_in_use[0] = 0u;
         }
     }
 }
 
-hipError_t launch_patch_choice(const Geom& g, const PatchPlan& pp, int pby, const uint32_t* offsets, int64_t np, int wave_slots,
-                               uint32_t* choice, uint32_t* slots_in_use, hipStream_t stream) {
-    const int waves_per_block = 256 / kWave;
-    // Patches while the heaviest task holds at most one even share of the wave slots, max_task <= np / wave_slots — or,
-    // on grids with fewer tasks than that (no point set could meet the first bound: the mean task already exceeds it),
-    // at most twice the mean task, max_task <= 2 np / ntasks.  A patch task is not shared between workgroups, so its
-    // heaviest task bounds the kernel; the LDS tiles split heavy tiles into slices.
-    unsigned long long num = 1ull, den = (unsigned long long)wave_slots;
-    if (2ull * (unsigned long long)wave_slots > (unsigned long long)pp.ntasks) { num = 2ull; den = (unsigned long long)pp.ntasks; }
-    hipLaunchKernelGGL(patch_choice_kernel, dim3((unsigned)((pp.ntasks + waves_per_block - 1) / waves_per_block)), dim3(256), 0, stream,
-                       g, pp, pby, offsets, (unsigned long long)np, num, den, choice, slots_in_use);
+// Launch order of the tasks: segment index first, patch column (x fastest) second — the four waves of a workgroup then
+// own neighbouring columns over about the same layers and share the records, values and bin offsets they read (with
+// uniform points exactly the order of equal-length segments; column-major order cost 8-16 % there).  One workgroup
+// sorts the table in LDS (bitonic, 64-bit keys {segment, column, layers}; empty tasks go last).
+constexpr int kPatchSortMax = 16384;
+
+__global__ __launch_bounds__(1024) void patch_task_sort_kernel(int ntasks, int npad, const uint32_t* __restrict__ first, int ncols,
+                                                              const uint32_t* __restrict__ choice, uint2* __restrict__ tasktab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sort[];
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(smem_sort);
+    const int tid = threadIdx.x;
+    if (choice[3] != 0u) return;                          // equal-length mode: patch_split_kernel wrote the table in this order
+    for (int t = tid; t < npad; t += 1024) {
+        unsigned long long k = ~0ull;
+        if (t < ntasks) {
+            const uint2 e = tasktab[t];
+            if (e.y != 0u) k = ((unsigned long long)(t - first[e.x]) << 48) | ((unsigned long long)e.x << 32) | e.y;
+        }
+        key[t] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= npad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < npad / 2; i += 1024) {
+                const int lo = 2 * i - (i & (stride - 1));            // index of the pair's lower element
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = tid; t < ntasks; t += 1024) {
+        const unsigned long long k = key[t];
+        tasktab[t] = k == ~0ull ? make_uint2(0u, 0u) : make_uint2((uint32_t)(k >> 32) & 0xffffu, (uint32_t)k);
+    }
+}
+
+bool patch_tasks_supported(const Geom& g) { return g.nb[2] <= kPatchMaxLayers; }
+int patch_task_table_entries(const PatchPlan& pp) { return pp.ntasks + pp.npx * pp.npy; }      // any rounding of the segment counts fits
+
+hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int chi, const uint32_t* offsets, int64_t np,
+                              int wave_slots, double advantage, uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first,
+                              uint2* tasktab, hipStream_t stream) {
+    const int ncols = pp.npx * pp.npy, wpb = 256 / kWave;
+    const int zq = pp.f32acc ? 2 : 1;
+    const int ntab = patch_task_table_entries(pp);
+    // Which engine: with `slots` = min(wave slots, tasks) waves at work the patch kernel takes about
+    // max(heaviest task, all tasks / slots) point visits per wave, where a task visits its own layers and the ncb - 1 layers
+    // the stencils reach beyond them.  For uniform points that is np * (segl + ncb - 1) / segl / slots; the patches keep
+    // a point set while their estimate stays within `advantage` x that figure — their measured advantage over the LDS tiles
+    // on uniform points.  Short segments in dense regions inflate the visits (a 2-layer segment at
+    // m = 8 visits 6 layers), which is why heavily clustered sets still go to the tiles.  advantage <= 0: always the patches.
+    const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(wave_slots, pp.ntasks));
+    const double infl0 = (double)(pp.segl + (chi - clo)) / (double)pp.segl;
+    const unsigned long long limit = advantage > 0.0 ? (unsigned long long)(advantage * infl0 * (double)np / (double)slots_eff) + 64ull
+                                                     : ~0ull / (slots_eff + 1ull);
+    hipLaunchKernelGGL(patch_column_sums_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, pp.npx, pp.npy, pp.pby,
+                       pp.segl, offsets, colsum, choice);
+    hipLaunchKernelGGL(patch_task_counts_kernel, dim3(1), dim3(1024), 0, stream, ncols, pp.ntasks, ntab, pp.nseg, g.nb[2] / zq,
+                       (unsigned long long)np, colsum, first, tasktab, choice);
+    hipLaunchKernelGGL(patch_split_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, pp.npx, pp.npy, pp.pby,
+                       clo, chi, zq, pp.segl, offsets, first, limit, slots_eff, tasktab, choice, slots_in_use);
+    if (ntab <= kPatchSortMax && ncols < 65536) {
+        int npad = 2;
+        while (npad < ntab) npad <<= 1;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(patch_task_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchSortMax * 8);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(patch_task_sort_kernel, dim3(1), dim3(1024), (size_t)npad * 8, stream, ntab, npad, first, ncols, choice, tasktab);
+    }
     return hipGetLastError();
 }
 

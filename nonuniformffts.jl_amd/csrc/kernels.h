@@ -109,17 +109,23 @@ struct PatchPlan {
 // allow_f32acc: ComplexF32 plans may take the FP32-matrix-pipe kernel where the grid allows it (octets along dimension 3)
 // planar_nc: ntransforms of a real plan whose components may be spread together (2 or 3; 0 = one component per launch)
 PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc = true, int planar_nc = 0);
-// set_points: decides on the device which engine serves this point set (balance.hip); choice = uint32[4], zeroed once
-hipError_t launch_patch_choice(const Geom& g, const PatchPlan& pp, int pby, const uint32_t* offsets, int64_t np, int wave_slots,
-                               uint32_t* choice, uint32_t* slots_in_use, hipStream_t stream);
+// set_points: cuts the patch columns into tasks of about equal point count and decides on the device which engine serves
+// this point set (balance.hip); choice = uint32[8], zeroed once; colsum[columns], first[columns + 1], tasktab[pp.ntasks]
+// advantage: how much faster than the LDS tiles the patches are on uniform points (<= 0: always the patches)
+hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int chi, const uint32_t* offsets, int64_t np,
+                              int wave_slots, double advantage, uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first,
+                              uint2* tasktab, hipStream_t stream);
+bool patch_tasks_supported(const Geom& g);
+int patch_task_table_entries(const PatchPlan& pp);       // entries of the task table = tasks the patch kernels are launched with
 hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other, int planar_nc = 0);
 // all C value vectors of a real plan gathered into one interleaved buffer vout[p * C + c] (planar patch kernel)
 hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np, const void* const* vin, int C,
                                 const void* weights, void* vout, const uint32_t* enabled, hipStream_t stream);
 // vsorted: C value vectors in sorted order (launch_gather_values), vstride_reals reals apart
 // enabled: device flag (null: always run); both kernels return at once when *enabled == 0
+// tasktab: the task table of launch_patch_tasks
 hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
-                               const uint32_t* enabled, hipStream_t stream);
+                               const uint32_t* enabled, const uint2* tasktab, hipStream_t stream);
 hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* sorted, int64_t np, const void* vin,
                                 const void* weights, void* vout, const uint32_t* enabled, hipStream_t stream);
 

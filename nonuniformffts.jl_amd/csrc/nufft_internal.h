@@ -117,7 +117,9 @@ struct nufft_plan {
         bool eligible = false;
         int npx = 0, npy = 0, nseg = 0, segl = 0, ntasks = 0, lds_bytes = 0, pby = 0, occ = 2, f32acc = 0, planar = 0;
     } patch;
-    uint32_t* d_patch_choice = nullptr;   // [4]: scratch of patch_choice_kernel; [2] = 1: this point set is spread by the patches
+    uint32_t* d_patch_choice = nullptr;   // [8]: scratch of patch_split_kernel; [2] = 1: this point set is spread by the patches
+    uint32_t* d_patch_cols = nullptr;     // [columns] points per patch column, then [columns + 1] first task of each column
+    void* d_patch_tasks = nullptr;        // uint2[ntasks]: {column, end layer << 16 | first layer}, rebuilt by every set_points
     int wave_slots = 2048;             // resident waves of the patch kernel on this device (CUs x 4 SIMDs x its waves per SIMD)
     void* d_vsorted = nullptr;         // C value vectors in sorted order (MFMA-patch spreading)
     int64_t lds_spread = 0, lds_interp = 0;

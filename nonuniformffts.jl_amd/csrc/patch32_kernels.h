@@ -184,9 +184,20 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
     const int task = wg * kPatchWaves + wave;
     if (task >= pg.ntasks) return;
     const int comp_id = blockIdx.y;
-    const int px = task % pg.npx, py = (task / pg.npx) % pg.npy, seg = task / (pg.npx * pg.npy);
+    // the task: a patch column and its segment of cube layers — from set_points' table (segments of about equal point
+    // count, balance.hip), or segments of equal length
+    int px, py, z0, z1;
+    if (a.tasktab) {
+        const uint2 te = a.tasktab[task];
+        px = (int)te.x % pg.npx; py = (int)te.x / pg.npx;
+        z0 = (int)(te.y & 0xffffu); z1 = (int)(te.y >> 16);
+        if (z1 <= z0) return;                           // a task that received no layers
+    } else {
+        const int seg = task / (pg.npx * pg.npy);
+        px = task % pg.npx; py = (task / pg.npx) % pg.npy;
+        z0 = seg * pg.segl; z1 = min(z0 + pg.segl, g.nb[2]);
+    }
     const int ncx = min(PBX, g.nb[0] - px * PBX), ncy = min(PBY, g.nb[1] - py * PBY);   // cube columns that exist
-    const int z0 = seg * pg.segl, z1 = min(z0 + pg.segl, g.nb[2]);                      // owned cube layers (both even)
     const int X0 = px * PBX * 4;
     const int bx0 = px * PBX, by0 = py * PBY;
 

@@ -139,7 +139,8 @@ struct PatchArgs {
     PatchGeom pg;
     const T* vsorted[kMaxCompPerLaunch];   // values in sorted order (gather_values_kernel), NC reals per point
     unsigned long long* prof;              // NUFFT_PATCH_PROFILE builds: cycles per phase, summed over the waves
-    const uint32_t* enabled;               // device flag written by set_points (patch_choice_kernel); null: always run
+    const uint32_t* enabled;               // device flag written by set_points (patch_split_kernel); null: always run
+    const uint2* tasktab;                  // per point set: {patch column, end layer << 16 | first layer} per task (balance.hip)
 };
 
 // Values in sorted order: vs[p] = v[idx[p]] (* weight[idx[p]]: callbacks.nonuniform, src/spreading/gpu.jl:289)
@@ -238,9 +239,20 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
     const int task = wg * kPatchWaves + wave;
     if (task >= pg.ntasks) return;
     const int comp_id = blockIdx.y;
-    const int px = task % pg.npx, py = (task / pg.npx) % pg.npy, seg = task / (pg.npx * pg.npy);
+    // the task: a patch column and its segment of cube layers — from set_points' table (segments of about equal point
+    // count, balance.hip), or segments of equal length
+    int px, py, z0, z1;
+    if (a.tasktab) {
+        const uint2 te = a.tasktab[task];
+        px = (int)te.x % pg.npx; py = (int)te.x / pg.npx;
+        z0 = (int)(te.y & 0xffffu); z1 = (int)(te.y >> 16);
+        if (z1 <= z0) return;                           // a task that received no layers
+    } else {
+        const int seg = task / (pg.npx * pg.npy);
+        px = task % pg.npx; py = (task / pg.npx) % pg.npy;
+        z0 = seg * pg.segl; z1 = min(z0 + pg.segl, g.nb[2]);
+    }
     const int ncx = min(PBX, g.nb[0] - px * PBX), ncy = min(PBY, g.nb[1] - py * PBY);   // cube columns that exist
-    const int z0 = seg * pg.segl, z1 = min(z0 + pg.segl, g.nb[2]);                      // owned cube layers
     const int X0 = px * PBX * 4;
     const int bx0 = px * PBX, by0 = py * PBY;
 

@@ -535,8 +535,13 @@ static int build_device(nufft_plan* p) {
 
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false, p->patch.planar));
-        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 4 * sizeof(uint32_t)))) return rc;
-        NUFFT_HIP(hipMemset(p->d_patch_choice, 0, 4 * sizeof(uint32_t)));
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 8 * sizeof(uint32_t)))) return rc;
+        NUFFT_HIP(hipMemset(p->d_patch_choice, 0, 8 * sizeof(uint32_t)));
+        // task table of the patch engine, rebuilt by every set_points (balance.hip): [columns] points, [columns + 1] first task,
+        // [ntasks] {column, layers}
+        const size_t ncols = (size_t)p->patch.npx * p->patch.npy;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, &p->d_patch_tasks, ((size_t)p->patch.ntasks + ncols) * 8))) return rc;
         hipDeviceProp_t prop;
         NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
         p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
@@ -560,7 +565,7 @@ static void release(nufft_plan* p) {
         auto fr = [](void* q) { if (q) (void)hipFree(q); };
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
-        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice);
+        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -1009,8 +1014,18 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         pp.eligible = true;
         pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
         pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc; pp.planar = p->patch.planar;
-        const int slots = p->spread_method_req == NUFFT_SPREAD_MFMA_PATCHES ? 1 : p->wave_slots;    // explicit request: always the patches
-        NUFFT_HIP(launch_patch_choice(s.g, pp, p->patch.pby, p->d_offsets, np, slots, p->d_patch_choice, p->bal.d_slots, stream));
+        // the patches' measured advantage over the LDS tiles on uniform points grows with the matrix work per point visit
+        // (ComplexF64 m = 4 1.17, m = 7 3.7; Float64 m = 6 1.5-1.7, m = 9 3.7; ComplexF32 on the FP32
+        // matrix pipe m = 8 3.4-4): 1.15 x g^(m - 4) with g = 1.2 (real) / 1.45 (complex), x 1.3 with Float32 accumulators,
+        // x 0.85 because the estimate counts a task's own column only and no scheduling tail.  An explicit request always
+        // takes the patches.
+        double advantage = 0.85 * 1.15 * std::pow(p->is_complex ? 1.45 : 1.2, (double)std::max(p->M - 4, 0)) * (p->patch.f32acc ? 1.3 : 1.0);
+        if (p->spread_method_req == NUFFT_SPREAD_MFMA_PATCHES) advantage = 0.0;
+        const int slots = p->wave_slots;
+        const int clo = -((p->M + 2) / 4), chi = (3 + p->M) / 4;          // cubes a stencil reaches beside its bin (PatchCfg::CLO, CHI)
+        const size_t ncols = (size_t)pp.npx * pp.npy;
+        NUFFT_HIP(launch_patch_tasks(s.g, pp, clo, chi, p->d_offsets, np, slots, advantage, p->d_patch_choice, p->bal.d_slots, p->d_patch_cols,
+                                     p->d_patch_cols + ncols, static_cast<uint2*>(p->d_patch_tasks), stream));
     }
     p->Np = np;
     p->counts_clean = np > 0;      // the scatter pass has cleared the histogram (no point, no scatter pass: cleared next time)
@@ -1091,7 +1106,7 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
         pp.eligible = true;
         pp.npx = p->patch.npx; pp.npy = p->patch.npy; pp.nseg = p->patch.nseg; pp.segl = p->patch.segl;
         pp.ntasks = p->patch.ntasks; pp.lds_bytes = p->patch.lds_bytes; pp.pby = p->patch.pby; pp.f32acc = p->patch.f32acc; pp.planar = p->patch.planar;
-        NUFFT_HIP(launch_spread_patch(a, pp, p->d_vsorted, vstride, enabled, stream));
+        NUFFT_HIP(launch_spread_patch(a, pp, p->d_vsorted, vstride, enabled, static_cast<const uint2*>(p->d_patch_tasks), stream));
     }
     return NUFFT_OK;
 }

@@ -259,6 +259,7 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
         if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return pp;
         if (g.nb[d] < 2 * (pb[d] + ncb)) return pp;
     }
+    if (!patch_tasks_supported(g)) return pp;          // (more bin layers than set_points' task splitter holds)
     pp.npx = (g.nb[0] + 3) / 4;
     pp.npy = (g.nb[1] + pby - 1) / pby;
     // segments along dimension 3: enough tasks for ~4 rounds of the 2048 resident waves, at least 8 cube layers each
@@ -300,7 +301,7 @@ hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other, in
 
 template <typename T>
 static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
-                                 const uint32_t* enabled, hipStream_t stream) {
+                                 const uint32_t* enabled, const uint2* tasktab, hipStream_t stream) {
     int lds = 0, pby = 0;
     const void* fn = pp.planar ? patch_planar_kernel(a.dtype, pp.planar, a.M, &lds, &pby)
                    : (pp.f32acc ? patch32_kernel_f32c(a.M, false, &lds, &pby) : patch_kernel(a.dtype, a.is_complex, a.M, false, &lds, &pby));
@@ -309,7 +310,8 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
         int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         PatchArgs<T> k{};
         k.t = fill_tile_args<T>(a, c0, nc);
-        k.pg.npx = pp.npx; k.pg.npy = pp.npy; k.pg.nseg = pp.nseg; k.pg.segl = pp.segl; k.pg.ntasks = pp.ntasks;
+        k.pg.npx = pp.npx; k.pg.npy = pp.npy; k.pg.nseg = pp.nseg; k.pg.segl = pp.segl;
+        k.pg.ntasks = tasktab ? patch_task_table_entries(pp) : pp.ntasks;
         for (int c = 0; c < nc; ++c) k.vsorted[c] = static_cast<const T*>(vsorted) + (int64_t)(c0 + c) * vstride_reals;
         if (pp.planar) {                 // all components in one launch: vsorted is one interleaved buffer, gridDim.y = 1
             k.vsorted[0] = static_cast<const T*>(vsorted);
@@ -317,6 +319,7 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
         }
         k.prof = nullptr;
         k.enabled = enabled;
+        k.tasktab = tasktab;
 #if defined(NUFFT_PATCH_PROFILE)
         static unsigned long long* prof_dev = nullptr;       // development builds: phase cycles of the last launch on stderr
         if (!prof_dev) { (void)hipMalloc(&prof_dev, 8 * sizeof(unsigned long long)); }
@@ -324,7 +327,7 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
         k.prof = prof_dev;
 #endif
         void* params[] = {&k};
-        const unsigned nwg = (unsigned)((pp.ntasks + kPatchWaves - 1) / kPatchWaves);
+        const unsigned nwg = (unsigned)((k.pg.ntasks + kPatchWaves - 1) / kPatchWaves);
         hipError_t e = hipLaunchKernel(fn, dim3(nwg, (unsigned)nc, 1), dim3(kPatchWaves * kWave, 1, 1), params, (size_t)lds, stream);
         if (e != hipSuccess) return e;
 #if defined(NUFFT_PATCH_PROFILE)
@@ -342,9 +345,9 @@ static hipError_t launch_patch_t(const TileKernelArgs& a, const PatchPlan& pp, c
 }
 
 hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, const void* vsorted, int64_t vstride_reals,
-                               const uint32_t* enabled, hipStream_t stream) {
-    return a.dtype == NUFFT_F32 ? launch_patch_t<float>(a, pp, vsorted, vstride_reals, enabled, stream)
-                                : launch_patch_t<double>(a, pp, vsorted, vstride_reals, enabled, stream);
+                               const uint32_t* enabled, const uint2* tasktab, hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_patch_t<float>(a, pp, vsorted, vstride_reals, enabled, tasktab, stream)
+                                : launch_patch_t<double>(a, pp, vsorted, vstride_reals, enabled, tasktab, stream);
 }
 
 // values of one component in sorted order (times the per-point weights of the callback menu)
