@@ -172,12 +172,12 @@ hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream) {
 // kernel), 0: tiles.  No host read-back.
 constexpr int kPatchMaxLayers = 2048;                   // bin layers of a column the splitter holds in LDS (per wave)
 
-__global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx, int npy, int pby, int segl, const uint32_t* __restrict__ offsets,
+__global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx, int npy, int pbx, int pby, int segl, const uint32_t* __restrict__ offsets,
                                                                uint32_t* __restrict__ colsum, uint32_t* __restrict__ choice) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, lane = threadIdx.x & (kWave - 1);
     if (c >= npx * npy) return;
-    const int bx0 = (c % npx) * 4, by0 = (c / npx) * pby;
-    const int ncx = min(4, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
+    const int bx0 = (c % npx) * pbx, by0 = (c / npx) * pby;
+    const int ncx = min(pbx, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
     uint32_t total = 0, heaviest = 0;
     for (int z0 = 0; z0 < g.nb[2]; z0 += segl) {        // segments of equal length: the partition uniform point sets keep
         const int nl = min(segl, g.nb[2] - z0);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx,
 // boundaries on whole layers would make them differ by a layer's worth (9 % at 11 layers per segment) — else
 // S_c = round(T points(c) / Np) segments per column; their exclusive scan (first[c]; first[ncols] = tasks in use; the table
 // holds T + columns entries, enough for any rounding), empty entries behind.  choice[3] = 1: equal-length mode.
-__global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int ntasks, int ntab, int nseg, int max_seg, unsigned long long np,
+__global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int ntasks, int ntab, int nseg, int min_seg, int max_seg, unsigned long long np,
                                                                 const uint32_t* __restrict__ colsum, uint32_t* __restrict__ first,
                                                                 uint2* __restrict__ tasktab, uint32_t* __restrict__ choice) {
     __shared__ uint32_t part[1024];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int 
             if (uni) S = (uint32_t)nseg;
             else {
                 S = np ? (uint32_t)(((unsigned long long)ntasks * colsum[c] + np / 2) / np) : 1u;
-                S = S < 1u ? 1u : (S > (uint32_t)max_seg ? (uint32_t)max_seg : S);
+                S = S < (uint32_t)min_seg ? (uint32_t)min_seg : (S > (uint32_t)max_seg ? (uint32_t)max_seg : S);
             }
         }
         part[tid] = S;
@@ -245,12 +245,13 @@ __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int 
     for (int t = (int)carry + tid; t < ntab; t += 1024) tasktab[t] = make_uint2(0u, 0u);
 }
 
-__global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int npy, int pby, int clo, int chi, int zq, int segl,
+__global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int npy, int pbx, int pby, int clo, int chi, int zq, int segl, int maxlen,
                                                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ first,
-                                                         unsigned long long limit, unsigned long long slots_eff,
+                                                         unsigned long long limit, unsigned long long slots_eff, int uniform_always,
                                                          uint2* __restrict__ tasktab, uint32_t* __restrict__ choice,
                                                          uint32_t* __restrict__ slots_in_use) {
     __shared__ uint32_t cum_all[256 / kWave][kPatchMaxLayers + 1];
+    __shared__ uint16_t bnd_all[256 / kWave][kPatchMaxLayers + 2];      // segment boundaries of the wave's column
     const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     const int c = blockIdx.x * (256 / kWave) + w;
     const int nz = g.nb[2];
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
     unsigned long long wsum = 0;
     uint32_t wmax = 0;
     if (c < npx * npy) {
-        const int bx0 = (c % npx) * 4, by0 = (c / npx) * pby;
-        const int ncx = min(4, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
+        const int bx0 = (c % npx) * pbx, by0 = (c / npx) * pby;
+        const int ncx = min(pbx, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
         // points per layer, then their running sum: lane l owns the layers [l * per, (l + 1) * per)
         const int per = (nz + kWave - 1) / kWave;
         uint32_t run = 0;
@@ -309,8 +310,18 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
             z = (z + zq - 1) / zq * zq;
             return z < nz ? z : nz;
         };
+        uint16_t* bnd = bnd_all[w];
+        for (uint32_t k = lane; k <= S; k += kWave) bnd[k] = (uint16_t)boundary(k);
+        wave_lds_fence();
+        if (maxlen > 0 && !uni && lane == 0) {
+            // no segment longer than the consumer's tables hold (S >= nz / maxlen by construction): pull boundaries forward,
+            // then push the ones in front of a long last stretch back
+            for (uint32_t k = 1; k < S; ++k) bnd[k] = (uint16_t)min((int)bnd[k], (int)bnd[k - 1] + maxlen);
+            for (int k = (int)S - 1; k > 0; --k) bnd[k] = (uint16_t)max((int)bnd[k], (int)bnd[k + 1] - maxlen);
+        }
+        wave_lds_fence();
         for (uint32_t k = lane; k < S; k += kWave) {
-            const int z0 = boundary(k), z1 = boundary(k + 1);
+            const int z0 = bnd[k], z1 = bnd[k + 1];
             tasktab[uni ? k * (uint32_t)(npx * npy) + (uint32_t)c : t0 + k] = make_uint2((uint32_t)c, z1 > z0 ? ((uint32_t)z1 << 16) | (uint32_t)z0 : 0u);
             if (z1 > z0) {
                 // the points a task visits along dimension 3: its own layers and the stencil's reach beyond them
@@ -339,9 +350,9 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
             choice[1] = 0u;
             // the kernel takes about max(heaviest task, all tasks / wave slots) point visits per wave: patches while that
             // stays within `limit` (launch_patch_tasks)
-            const bool patches = (mx <= limit && sum <= limit * slots_eff) || sum == 0ull || choice[3] != 0u;   // (equal-length mode: always)
+            const bool patches = (mx <= limit && sum <= limit * slots_eff) || sum == 0ull || (uniform_always && choice[3] != 0u);
             choice[2] = patches ? 1u : 0u;
-            if (patches) slots_in_use[0] = 0u;
+            if (patches && slots_in_use) slots_in_use[0] = 0u;
         }
     }
 }
@@ -386,30 +397,21 @@ __global__ __launch_bounds__(1024) void patch_task_sort_kernel(int ntasks, int n
 }
 
 bool patch_tasks_supported(const Geom& g) { return g.nb[2] <= kPatchMaxLayers; }
-int patch_task_table_entries(const PatchPlan& pp) { return pp.ntasks + pp.npx * pp.npy; }      // any rounding of the segment counts fits
+int patch_task_table_entries(const PatchPlan& pp) { return pp.ntasks + 2 * pp.npx * pp.npy; }      // column_task_table_entries of its columns
 
-hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int chi, const uint32_t* offsets, int64_t np,
-                              int wave_slots, double advantage, uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first,
-                              uint2* tasktab, hipStream_t stream) {
-    const int ncols = pp.npx * pp.npy, wpb = 256 / kWave;
-    const int zq = pp.f32acc ? 2 : 1;
-    const int ntab = patch_task_table_entries(pp);
-    // Which engine: with `slots` = min(wave slots, tasks) waves at work the patch kernel takes about
-    // max(heaviest task, all tasks / slots) point visits per wave, where a task visits its own layers and the ncb - 1 layers
-    // the stencils reach beyond them.  For uniform points that is np * (segl + ncb - 1) / segl / slots; the patches keep
-    // a point set while their estimate stays within `advantage` x that figure — their measured advantage over the LDS tiles
-    // on uniform points (DESIGN.md section 4.4).  Short segments in dense regions inflate the visits (a 2-layer segment at
-    // m = 8 visits 6 layers), which is why heavily clustered sets still go to the tiles.  advantage <= 0: always the patches.
-    const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(wave_slots, pp.ntasks));
-    const double infl0 = (double)(pp.segl + (chi - clo)) / (double)pp.segl;
-    const unsigned long long limit = advantage > 0.0 ? (unsigned long long)(advantage * infl0 * (double)np / (double)slots_eff) + 64ull
-                                                     : ~0ull / (slots_eff + 1ull);
-    hipLaunchKernelGGL(patch_column_sums_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, pp.npx, pp.npy, pp.pby,
-                       pp.segl, offsets, colsum, choice);
-    hipLaunchKernelGGL(patch_task_counts_kernel, dim3(1), dim3(1024), 0, stream, ncols, pp.ntasks, ntab, pp.nseg, g.nb[2] / zq,
+// limit / slots_eff: the engine keeps the point set while max(heaviest task, all tasks / slots_eff) <= limit
+static hipError_t launch_column_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, unsigned long long limit,
+                                      unsigned long long slots_eff, bool uniform_always, uint32_t* choice, uint32_t* slots_in_use,
+                                      uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
+    const int ncols = ct.ncolx * ct.ncoly, wpb = 256 / kWave;
+    const int ntab = column_task_table_entries(ct, g.nb[2]);
+    hipLaunchKernelGGL(patch_column_sums_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, ct.ncolx, ct.ncoly, ct.bxw, ct.byw,
+                       ct.segl, offsets, colsum, choice);
+    const int min_seg = ct.maxlen > 0 ? (g.nb[2] + ct.maxlen - 1) / ct.maxlen : 1;
+    hipLaunchKernelGGL(patch_task_counts_kernel, dim3(1), dim3(1024), 0, stream, ncols, ct.ntasks, ntab, ct.nseg, min_seg, g.nb[2] / ct.zq,
                        (unsigned long long)np, colsum, first, tasktab, choice);
-    hipLaunchKernelGGL(patch_split_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, pp.npx, pp.npy, pp.pby,
-                       clo, chi, zq, pp.segl, offsets, first, limit, slots_eff, tasktab, choice, slots_in_use);
+    hipLaunchKernelGGL(patch_split_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, ct.ncolx, ct.ncoly, ct.bxw, ct.byw,
+                       ct.clo, ct.chi, ct.zq, ct.segl, ct.maxlen, offsets, first, limit, slots_eff, uniform_always ? 1 : 0, tasktab, choice, slots_in_use);
     if (ntab <= kPatchSortMax && ncols < 65536) {
         int npad = 2;
         while (npad < ntab) npad <<= 1;
@@ -421,6 +423,35 @@ hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int c
         hipLaunchKernelGGL(patch_task_sort_kernel, dim3(1), dim3(1024), (size_t)npad * 8, stream, ntab, npad, first, ncols, choice, tasktab);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int chi, const uint32_t* offsets, int64_t np,
+                              int wave_slots, double advantage, uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first,
+                              uint2* tasktab, hipStream_t stream) {
+    ColumnTasks ct{pp.npx, pp.npy, 4, pp.pby, pp.nseg, pp.segl, pp.ntasks, pp.f32acc ? 2 : 1, clo, chi, 0};
+    // Which engine: with `slots` = min(wave slots, tasks) waves at work the patch kernel takes about
+    // max(heaviest task, all tasks / slots) point visits per wave, where a task visits its own layers and the ncb - 1 layers
+    // the stencils reach beyond them.  For uniform points that is np * (segl + ncb - 1) / segl / slots; the patches keep
+    // a point set while their estimate stays within `advantage` x that figure — their measured advantage over the LDS tiles
+    // on uniform points (DESIGN.md section 4.4).  Short segments in dense regions inflate the visits (a 2-layer segment at
+    // m = 8 visits 6 layers), which is why heavily clustered sets still go to the tiles.  advantage <= 0: always the patches.
+    const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(wave_slots, pp.ntasks));
+    const double infl0 = (double)(pp.segl + (chi - clo)) / (double)pp.segl;
+    const unsigned long long limit = advantage > 0.0 ? (unsigned long long)(advantage * infl0 * (double)np / (double)slots_eff) + 64ull
+                                                     : ~0ull / (slots_eff + 1ull);
+    return launch_column_tasks(g, ct, offsets, np, limit, slots_eff, true, choice, slots_in_use, colsum, first, tasktab, stream);
+}
+
+// The same for the z-marching interpolation ring (march_kernels.h): a task is a workgroup that owns a column of the grid
+// for a segment of bin layers.  Points are gathered once, by the task of their own column — cutting a dense column into
+// short segments duplicates only the (2M - 1)-plane window load, not point work — so the ring keeps a point set while
+// max(heaviest task, all points / workgroups at work) stays within `advantage` x an even share of the whole chip
+// (np / cus): small grids, whose few tasks cannot fill the chip, go to the LDS-tile kernel with its slices.
+hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, int cus, double advantage,
+                              uint32_t* choice, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
+    const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(cus, ct.ntasks));
+    const unsigned long long limit = (unsigned long long)(advantage * (double)np / (double)cus) + 64ull;
+    return launch_column_tasks(g, ct, offsets, np, limit, slots_eff, false, choice, nullptr, colsum, first, tasktab, stream);
 }
 
 // Zero the interior of the spreading tiles that are processed by several slices (they accumulate with

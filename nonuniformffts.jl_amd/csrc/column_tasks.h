@@ -1,0 +1,21 @@
+// Columns of the oversampled grid cut into tasks along dimension 3: the per-point-set work decomposition of the MFMA-patch
+// spreading engine (patch columns) and of the z-marching interpolation ring (grid columns); built by balance.hip.
+#pragma once
+
+namespace nufft {
+
+// ncolx x ncoly columns of bxw x byw bins, nseg segments of segl layers when cut evenly (ntasks = columns x
+// nseg), boundaries at multiples of zq layers, a task's work counted over clo .. chi layers beyond its own, no segment
+// longer than maxlen layers (0: any length)
+struct ColumnTasks {
+    int ncolx, ncoly, bxw, byw, nseg, segl, ntasks, zq, clo, chi, maxlen;
+};
+
+// Entries of a task table: column c gets max(min_seg, round(T points(c) / Np)) segments, where min_seg covers the column
+// with segments of at most maxlen layers — at most T + columns / 2 + min_seg x columns in all.
+inline int column_task_table_entries(const ColumnTasks& ct, int nz) {
+    const int min_seg = ct.maxlen > 0 ? (nz + ct.maxlen - 1) / ct.maxlen : 1;
+    return ct.ntasks + (min_seg + 1) * ct.ncolx * ct.ncoly;
+}
+
+}  // namespace nufft

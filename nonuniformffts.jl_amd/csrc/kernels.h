@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "column_tasks.h"
 #include "device_common.h"
 #include "nufft_mi355x.h"
 
@@ -55,6 +56,7 @@ hipError_t launch_zero_split_tiles(int dtype, const Geom& g, int D, int is_compl
                                    void* grid, int64_t grid_stride_reals, hipStream_t stream);
 
 // ---- spreading / interpolation (spread_*.hip, interp_*.hip) -------------------------------------
+
 struct TileKernelArgs {
     int dtype, is_complex, D, M, evalmode, C;
     int kernel;                // NUFFT_KERNEL_*
@@ -77,6 +79,9 @@ struct TileKernelArgs {
     const uint32_t* desc_total;    // number of slots in use
     int xcd_chunk;
     int march;                 // interpolation: also launch the z-marching kernel (march_kernels.h); decided per point set on the device
+    ColumnTasks march_ct;      // ... its columns and tasks (march_column_tasks),
+    const uint32_t* march_flag;   // the device flag of set_points (1: the ring serves this point set)
+    const uint2* march_tasks;     // and the task table
     int fixed_tile;            // the tile (g.ip / g.sp) equals the compile-time one (kernel variant with constant strides)
     int cubes;                 // spreading with the compile-time tile: accumulate cube by cube with the FP64 matrix instruction
 };
@@ -89,6 +94,8 @@ bool spread_cubes_available(int dtype, int is_complex, int D, int M);
 // z-marching interpolation (march_kernels.h): available for this plan?  (3-D, 4-cell bins, default window evaluation)
 bool interp_march_available(int dtype, int is_complex, int D, int M, const Geom& g, bool other);
 hipError_t prepare_interp_march(int dtype, int is_complex, int M);
+// columns (the kernel's compile-time column) and evenly cut tasks of the ring for this grid
+ColumnTasks march_column_tasks(int dtype, int is_complex, int M, const Geom& g);
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
 hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);
 // Sets the dynamic-LDS attribute of every instantiation that may be launched for this configuration.
@@ -111,6 +118,8 @@ struct PatchPlan {
 PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc = true, int planar_nc = 0);
 // set_points: cuts the patch columns into tasks of about equal point count and decides on the device which engine serves
 // this point set (balance.hip); choice = uint32[8], zeroed once; colsum[columns], first[columns + 1], tasktab[pp.ntasks]
+hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, int cus, double advantage,
+                              uint32_t* choice, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream);
 // advantage: how much faster than the LDS tiles the patches are on uniform points (<= 0: always the patches)
 hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int chi, const uint32_t* offsets, int64_t np,
                               int wave_slots, double advantage, uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first,

@@ -30,9 +30,10 @@
 namespace nufft {
 
 struct MarchGeom {
-    int ntx, nty, nseg, segl;       // columns along x, y; segments along z; bin layers per segment
-    int ntasks;
-    uint32_t expect_slots;          // run only if *desc_total equals this (no tile of the regular tiling was sliced)
+    int ntx, nty, nseg, segl;       // columns along x, y; segments along z and bin layers per segment when cut evenly
+    int ntasks;                     // entries of the task table = workgroups of the launch
+    const uint32_t* flag;           // per point set (set_points, balance.hip): 1 = the ring serves it, 0 = interp_tile_kernel
+    const uint2* tasktab;           // per point set: {column, end layer << 16 | first layer} per task
 };
 
 constexpr int kMarchMaxRows = 16;   // rows of bins of a column (n2 <= 64)
@@ -117,6 +118,8 @@ struct MarchCfg {
     static constexpr bool FITS = N1 > 0;                // (ComplexF64 at M = 10: not even a 4 x 4 column fits 160 KiB)
 };
 
+// A task is a column and a segment of its bin layers (at most kSegMax) from set_points' table: segments of about equal
+// point count, or of equal length for uniform point sets (balance.hip).
 template <typename T, bool CPLX, int M>
 __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_kernel(TileArgs<T> a, MarchGeom mg) {
     using C = MarchCfg<T, CPLX, M>;
@@ -126,16 +129,18 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
     constexpr int N1 = C::N1, N2 = C::N2, NPF = C::NPF, PSP = C::PSP, ZP = C::ZP, PPW = C::PPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    if (*a.desc_total != mg.expect_slots) return;      // sliced tiles: interp_tile_kernel serves this point set
+    if (*mg.flag == 0u) return;                         // interp_tile_kernel serves this point set
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const Geom& g = a.g;
     const int task = xcd_remap_chunked((int)blockIdx.x, (int)gridDim.x, a.xcd_chunk);
     if (task >= mg.ntasks) return;
     const int comp_id = blockIdx.y;
-    const int tx = task % mg.ntx, ty = (task / mg.ntx) % mg.nty, seg = task / (mg.ntx * mg.nty);
+    const uint2 te = mg.tasktab[task];
+    const int tx = (int)te.x % mg.ntx, ty = (int)te.x / mg.ntx;
+    const int zb0 = (int)(te.y & 0xffffu), zb1 = (int)(te.y >> 16);
+    if (zb1 <= zb0) return;                             // a task that received no layers
     const int org1 = tx * N1, org2 = ty * N2;
     const int neff1 = min(N1, g.Nover[0] - org1), neff2 = min(N2, g.Nover[1] - org2);
-    const int zb0 = seg * mg.segl, zb1 = min(zb0 + mg.segl, g.nb[2]);
     const int nlay = zb1 - zb0;
     const int nrows = (neff2 + 3) >> 2;                 // rows of bins of the column
     const int bx0 = org1 >> 2, nbx = (neff1 + 3) >> 2, by0 = org2 >> 2;

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "column_tasks.h"
 #include "nufft_mi355x.h"
 
 struct rocfft_plan_t;
@@ -68,6 +69,7 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
                   int spread_waves, int interp_waves, const int* forced_sp, const int* forced_ip, int bin_log2,
                   TileGeom& g);
 
+
 }  // namespace nufft
 
 // -------------------------------------------------------------------------------------------
@@ -107,7 +109,12 @@ struct nufft_plan {
     std::vector<double> phihat[3];
     std::vector<int64_t> index_map[3];
     nufft::TileGeom tile;
-    bool interp_march = false;         // the z-marching interpolation kernel serves un-sliced point sets (march_kernels.h)
+    bool interp_march = false;         // the z-marching interpolation kernel may serve point sets of this plan (march_kernels.h)
+    nufft::ColumnTasks march_ct{};     // ... its columns and evenly cut tasks
+    int num_cus = 256;                 // compute units of the device (one ring workgroup per CU)
+    uint32_t* d_march_choice = nullptr;   // [8]: scratch of the task kernels (balance.hip); [2] = 1: the ring serves this point set
+    uint32_t* d_march_cols = nullptr;     // [columns] points per column, then [columns + 1] first task of each column
+    void* d_march_tasks = nullptr;        // uint2[ntasks + columns]: {column, end layer << 16 | first layer}
     bool interp_fixed = false;         // tile.ip is the compile-time tile of the kernel instantiation
     bool spread_fixed = false;         // tile.sp likewise
     bool spread_cubes = false;         // LDS-tile spreading accumulates cube by cube (v_mfma_f64_4x4x4 + one ds_add_f64 per cube)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -531,7 +532,21 @@ static int build_device(nufft_plan* p) {
     // the balance pass exists (its slot count is the per-point-set switch); NUFFT_INTERP_MARCH=0: off (A/B runs)
     p->interp_march = env_int("NUFFT_INTERP_MARCH", 1) != 0 && p->balance_enabled &&
                       interp_march_available(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
-    if (p->interp_march) NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M));
+    if (p->interp_march) {
+        NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M));
+        p->march_ct = march_column_tasks(p->dtype, p->is_complex, p->M, make_geom(p));
+        const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
+        if (ncols >= 65536 || p->tile.nb[2] > 2048) p->interp_march = false;      // (beyond the task kernels' table formats)
+        else {
+            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_march_choice), 8 * sizeof(uint32_t)))) return rc;
+            NUFFT_HIP(hipMemset(p->d_march_choice, 0, 8 * sizeof(uint32_t)));
+            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_march_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
+            if ((rc = dev_alloc(p, &p->d_march_tasks, (size_t)column_task_table_entries(p->march_ct, p->tile.nb[2]) * 8))) return rc;
+            hipDeviceProp_t prop;
+            NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
+            p->num_cus = prop.multiProcessorCount;
+        }
+    }
 
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false, p->patch.planar));
@@ -541,7 +556,7 @@ static int build_device(nufft_plan* p) {
         // [ntasks] {column, layers}
         const size_t ncols = (size_t)p->patch.npx * p->patch.npy;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
-        if ((rc = dev_alloc(p, &p->d_patch_tasks, ((size_t)p->patch.ntasks + ncols) * 8))) return rc;
+        if ((rc = dev_alloc(p, &p->d_patch_tasks, ((size_t)p->patch.ntasks + 2 * ncols) * 8))) return rc;      // patch_task_table_entries
         hipDeviceProp_t prop;
         NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
         p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
@@ -565,7 +580,7 @@ static void release(nufft_plan* p) {
         auto fr = [](void* q) { if (q) (void)hipFree(q); };
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
-        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks);
+        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks); fr(p->d_march_choice); fr(p->d_march_cols); fr(p->d_march_tasks);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -624,6 +639,9 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
     a.march = interp && p->interp_march && !p->cb_point_weights;
+    a.march_ct = p->march_ct;
+    a.march_flag = p->d_march_choice ? p->d_march_choice + 2 : nullptr;
+    a.march_tasks = static_cast<const uint2*>(p->d_march_tasks);
     a.cubes = !interp && p->spread_cubes && !needs_other_eval(p->kernel, p->evalmode) && !p->cb_point_weights;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
     const nufft_plan::Balance& b = p->bal;
@@ -1027,6 +1045,49 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         NUFFT_HIP(launch_patch_tasks(s.g, pp, clo, chi, p->d_offsets, np, slots, advantage, p->d_patch_choice, p->bal.d_slots, p->d_patch_cols,
                                      p->d_patch_cols + ncols, static_cast<uint2*>(p->d_patch_tasks), stream));
     }
+    if (p->interp_march) {
+        // tasks of the interpolation ring for this point set, and whether it serves it (balance.hip).  Its measured advantage
+        // over interp_tile_kernel on uniform points: 1.26 at C2 (m = 4), 1.55 at Float64 m = 6, 1.9 at C3 (m = 8).
+        // (NUFFT_INTERP_MARCH=2: always the ring — tests of its instantiations on small grids)
+        const double advantage = env_int("NUFFT_INTERP_MARCH", 1) == 2 ? 1e12 : 1.2 * std::pow(1.1, (double)std::max(p->M - 4, 0));
+        const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
+        NUFFT_HIP(launch_march_tasks(s.g, p->march_ct, p->d_offsets, np, p->num_cus, advantage, p->d_march_choice, p->d_march_cols,
+                                     p->d_march_cols + ncols, static_cast<uint2*>(p->d_march_tasks), stream));
+    }
+    if (env_int("NUFFT_DEBUG_TASKS", 0) != 0) {
+        // development check: every column's tasks tile [0, nb[2]) without gaps or overlaps
+        auto check = [&](const char* name, const ColumnTasks& ct, const void* tab, const uint32_t* choice) {
+            const size_t ncols = (size_t)ct.ncolx * ct.ncoly, ntab = (size_t)column_task_table_entries(ct, p->tile.nb[2]);
+            std::vector<uint32_t> h(2 * ntab), ch(8);
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h.data(), tab, ntab * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ch.data(), choice, 32, hipMemcpyDeviceToHost);
+            std::vector<std::vector<std::pair<int, int>>> segs(ncols);
+            size_t used = 0, maxlen = 0;
+            for (size_t t = 0; t < ntab; ++t) {
+                const uint32_t c = h[2 * t], y = h[2 * t + 1];
+                if (!y) continue;
+                ++used;
+                if (c >= ncols) { fprintf(stderr, "[tasks %s] entry %zu: column %u out of range\n", name, t, c); continue; }
+                segs[c].push_back({(int)(y & 0xffffu), (int)(y >> 16)});
+                maxlen = std::max(maxlen, (size_t)((y >> 16) - (y & 0xffffu)));
+            }
+            size_t bad = 0;
+            for (size_t c = 0; c < ncols; ++c) {
+                std::sort(segs[c].begin(), segs[c].end());
+                int z = 0;
+                for (auto& sg : segs[c]) { if (sg.first != z) ++bad; z = sg.second; }
+                if (z != p->tile.nb[2]) ++bad;
+            }
+            fprintf(stderr, "[tasks %s] columns %zu, table %zu, in use %zu, longest %zu layers, flag %u, uniform %u, bad columns %zu\n", name, ncols, ntab,
+                    used, maxlen, ch[2], ch[3], bad);
+        };
+        if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
+            ColumnTasks ct{p->patch.npx, p->patch.npy, 4, p->patch.pby, p->patch.nseg, p->patch.segl, p->patch.ntasks, 1, 0, 0, 0};
+            check("patches", ct, p->d_patch_tasks, p->d_patch_choice);
+        }
+        if (p->interp_march) check("ring", p->march_ct, p->d_march_tasks, p->d_march_choice);
+    }
     p->Np = np;
     p->counts_clean = np > 0;      // the scatter pass has cleared the histogram (no point, no scatter pass: cleared next time)
     return NUFFT_OK;
@@ -1052,13 +1113,13 @@ int nufft_interp_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
     if (rc) return rc;
     if (!engine_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
     *engine_out = NUFFT_INTERP_LDS_TILES;
-    if (!p->interp_march || !p->balance_enabled) return NUFFT_OK;
+    if (!p->interp_march) return NUFFT_OK;
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    uint32_t slots = 0;                   // interpolation slots in use: more than one per tile = sliced tiles
-    NUFFT_HIP(hipMemcpyAsync(&slots, p->bal.d_slots + 1, sizeof(slots), hipMemcpyDeviceToHost, stream));
+    uint32_t flag = 0;
+    NUFFT_HIP(hipMemcpyAsync(&flag, p->d_march_choice + 2, sizeof(flag), hipMemcpyDeviceToHost, stream));
     NUFFT_HIP(hipStreamSynchronize(stream));
-    if (slots == (uint32_t)p->tile.ip.ntiles) *engine_out = NUFFT_INTERP_MARCHING_RING;
+    if (flag) *engine_out = NUFFT_INTERP_MARCHING_RING;
     return NUFFT_OK;
 }
 

@@ -66,8 +66,8 @@ struct TileArgs {
     const uint2* desc;                    // slot -> (tile, slice << 16 | slices of the tile), balance.hip
     const uint32_t* desc_total;           // slots in use (the launch grid may be larger)
     int xcd_chunk;                        // slots per XCD chunk (0: one contiguous range per XCD)
-    uint32_t march_slots;                 // interpolation: nonzero = the z-marching kernel (march_kernels.h) serves point sets
-                                          // whose slot count equals this (no sliced tile); interp_tile_kernel then returns
+    const uint32_t* march_flag;           // interpolation: device flag of set_points (balance.hip), 1 = the z-marching kernel
+                                          // (march_kernels.h) serves this point set and interp_tile_kernel returns; null: no ring
     int evalmode;
     int kernel;                           // NUFFT_KERNEL_*; beta / bop per kernel: see WindowEval
 };
@@ -1115,7 +1115,7 @@ template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK = false>
 __global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t nslots = *a.desc_total;
-    if (a.march_slots != 0u && nslots == a.march_slots) return;     // this point set goes to interp_march_kernel
+    if (a.march_flag && *a.march_flag != 0u) return;                // this point set goes to interp_march_kernel
     for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
         interp_tile_slot<T, CPLX, D, M, FIXED, OTHERK>(a, slot, nslots, smem);
         __syncthreads();                                            // the next slot reuses the tile and the item table

@@ -36,6 +36,31 @@ hipError_t prepare_interp_march(int dtype, int is_complex, int M) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
+ColumnTasks march_column_tasks(int dtype, int is_complex, int M, const Geom& g) {
+    int lds = 0, n[4];
+    ColumnTasks ct{};
+    if (!march_kernel(dtype, is_complex, M, &lds, n)) return ct;
+    ct.ncolx = (g.Nover[0] + n[0] - 1) / n[0];
+    ct.ncoly = (g.Nover[1] + n[1] - 1) / n[1];
+    ct.bxw = n[0] / 4;
+    ct.byw = n[1] / 4;
+    // segments along z: about four workgroups per CU in flight over the run, whole bin layers, at most n[2] each
+    const int cols = ct.ncolx * ct.ncoly;
+    int nseg = (1024 + cols - 1) / cols;
+    const int min_seg = (g.nb[2] + n[2] - 1) / n[2];
+    if (nseg < min_seg) nseg = min_seg;
+    if (nseg > g.nb[2] / 8 && g.nb[2] / 8 >= min_seg) nseg = g.nb[2] / 8;
+    if (nseg < 1) nseg = 1;
+    ct.segl = (g.nb[2] + nseg - 1) / nseg;
+    ct.nseg = (g.nb[2] + ct.segl - 1) / ct.segl;
+    ct.ntasks = cols * ct.nseg;
+    ct.zq = 1;
+    ct.clo = 0;                 // a point is gathered once, by the task of its own column and layer
+    ct.chi = 0;
+    ct.maxlen = n[2];           // layers the kernel's run tables hold (MarchCfg::kSegMax)
+    return ct;
+}
+
 const void* spread_kernel_f32r(int D, int M, bool flag, bool other);
 const void* spread_kernel_f32c(int D, int M, bool flag, bool other);
 const void* spread_kernel_f64r(int D, int M, bool flag, bool other);
@@ -154,7 +179,7 @@ static TileArgs<T> fill_tile_args(const TileKernelArgs& a, int c0, int nc) {
     k.desc = static_cast<const uint2*>(a.desc);
     k.desc_total = a.desc_total;
     k.xcd_chunk = a.xcd_chunk;
-    k.march_slots = 0u;
+    k.march_flag = nullptr;
     k.evalmode = a.evalmode;
     k.kernel = a.kernel;
     return k;
@@ -179,11 +204,10 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
     // z-marching interpolation: launched next to the tile kernel; the slot count set_points left on the device decides
     // which of the two finds work (no sliced tile: the marching kernel)
     const bool march = interp && a.march != 0 && !other;
-    const uint32_t march_slots = march ? (uint32_t)a.g.ip.ntiles : 0u;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
-        k.march_slots = march_slots;
+        k.march_flag = march ? a.march_flag : nullptr;
         void* params[] = {&k};
         // (a.ntiles = the slot budget; with the ring beside it the tile kernel strides over the slots from a bounded grid)
         const unsigned grid_x = march ? (unsigned)std::min<int64_t>(a.ntiles, 8192) : (unsigned)a.ntiles;
@@ -194,19 +218,13 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
             int lds = 0, n[4];
             const void* mfn = march_kernel(a.dtype, a.is_complex, a.M, &lds, n);
             MarchGeom mg{};
-            mg.ntx = (a.g.Nover[0] + n[0] - 1) / n[0];
-            mg.nty = (a.g.Nover[1] + n[1] - 1) / n[1];
-            // segments along z: about four workgroups per CU in flight over the run, whole bin layers, at most n[2] each
-            const int cols = mg.ntx * mg.nty;
-            int nseg = (1024 + cols - 1) / cols;
-            const int min_seg = (a.g.nb[2] + n[2] - 1) / n[2];
-            if (nseg < min_seg) nseg = min_seg;
-            if (nseg > a.g.nb[2] / 8 && a.g.nb[2] / 8 >= min_seg) nseg = a.g.nb[2] / 8;
-            if (nseg < 1) nseg = 1;
-            mg.segl = (a.g.nb[2] + nseg - 1) / nseg;
-            mg.nseg = (a.g.nb[2] + mg.segl - 1) / mg.segl;
-            mg.ntasks = cols * mg.nseg;
-            mg.expect_slots = march_slots;
+            mg.ntx = a.march_ct.ncolx;
+            mg.nty = a.march_ct.ncoly;
+            mg.nseg = a.march_ct.nseg;
+            mg.segl = a.march_ct.segl;
+            mg.ntasks = column_task_table_entries(a.march_ct, a.g.nb[2]);
+            mg.flag = a.march_flag;
+            mg.tasktab = a.march_tasks;
             void* mparams[] = {&k, &mg};
             e = hipLaunchKernel(mfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)n[3], 1, 1), mparams, (size_t)lds, stream);
             if (e != hipSuccess) return e;

@@ -463,13 +463,14 @@ def test_planar_patch_every_instantiation(Z, C, M):
 def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
     """Every (element type, M) instantiation of interp_march_kernel against the oracle (type 2, both window evaluations).
     Oversampled grid 96 x 80 x 112: partial columns at the upper ends of dimensions 1 and 2, several segments along
-    dimension 3.  The ring serves point sets whose tiles needed no slices; on a grid this small the slice budget (at
-    least 1024 extra workgroups) always reaches some tile, so the test plans get no budget (NUFFT_BALANCE_EXTRA=0) and
-    nufft_interp_engine_used confirms the device-side decision.  ComplexF64 at M = 10 has no ring (no column fits
-    160 KiB): LDS tiles there, and for the default-budget plan at the end."""
+    dimension 3.  On a grid this small the ring's few tasks cannot fill the chip and set_points gives the point set to
+    the LDS-tile kernel, so the test plans force the ring (NUFFT_INTERP_MARCH=2) and nufft_interp_engine_used confirms the
+    device-side flag; a point set concentrated in a corner exercises the tasks of equal point count (quantile segments,
+    empty tasks).  ComplexF64 at M = 10 has no ring (no column fits 160 KiB): LDS tiles there, and for the plan with
+    the ring switched off at the end."""
     has_ring = not (np.dtype(Z) == np.complex128 and M >= 10)
     dims, Np = (48, 40, 56), 4000
-    monkeypatch.setenv("NUFFT_BALANCE_EXTRA", "0")
+    monkeypatch.setenv("NUFFT_INTERP_MARCH", "2")
     for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
         nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=100 + M)
         dev = plan.device
@@ -477,21 +478,53 @@ def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
         w = (rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape))
         w = w.astype(np.complex64 if plan_real_dtype(Z) == np.float32 else np.complex128)
         wd = torch.from_numpy(w).to(dev)
-        nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
-        O.set_points(oplan, xs)
-        out = torch.empty(Np, dtype=plan.Z, device=dev)
-        nufft.exec_type2(out, plan, wd)
-        assert plan.interp_engine_used() == ("marching_ring" if has_ring else "lds_tiles"), evalmode
-        ref = O.exec_type2(oplan, _oracle_inputs(oplan, [w])[0])
-        assert _rel(out.cpu().numpy(), ref) < _rtol(Z), evalmode
-    # the same transform on a plan with the default budget: sliced tiles, LDS-tile kernel, same result
-    monkeypatch.delenv("NUFFT_BALANCE_EXTRA")
+        for name in ("uniform", "corner"):
+            pts = xs if name == "uniform" else tuple((0.3 * x * x / (2 * np.pi)).astype(x.dtype) for x in xs)
+            nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
+            O.set_points(oplan, pts)
+            out = torch.empty(Np, dtype=plan.Z, device=dev)
+            nufft.exec_type2(out, plan, wd)
+            assert plan.interp_engine_used() == ("marching_ring" if has_ring else "lds_tiles"), (name, evalmode)
+            ref = O.exec_type2(oplan, _oracle_inputs(oplan, [w])[0])
+            assert _rel(out.cpu().numpy(), ref) < _rtol(Z), (name, evalmode)
+    # the same transform with the ring switched off: LDS-tile kernel, same result
+    monkeypatch.setenv("NUFFT_INTERP_MARCH", "0")
     nufft, plan2, _, _, _ = _make_case(Z, dims, M, 2.0, O.DIRECT, 1, Np, seed=100 + M)
-    nufft.set_points(plan2, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    nufft.set_points(plan2, tuple(torch.from_numpy(x).to(dev) for x in pts))
     out2 = torch.empty(Np, dtype=plan2.Z, device=dev)
     nufft.exec_type2(out2, plan2, wd)
     assert plan2.interp_engine_used() == "lds_tiles"
     assert _rel(out2.cpu().numpy(), ref) < _rtol(Z)
+
+
+@pytest.mark.parametrize("Z,M", [(np.float64, 4), (np.complex64, 8), (np.float32, 6), (np.complex128, 5), (np.float64, 8)])
+def test_tasks_of_equal_point_count_on_nonuniform_sets(Z, M, monkeypatch):
+    """Patch engine and interpolation ring on point sets far from uniform (set_points cuts their columns into segments of
+    about equal point count; 72 bin layers along dimension 3: the ring's segments are capped at the 64 layers its run
+    tables hold), both engines forced, against the oracle."""
+    monkeypatch.setenv("NUFFT_INTERP_MARCH", "2")
+    dims, Np = (48, 40, 144), 6000
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, O.FAST_APPROXIMATION, 1, Np, seed=400 + M, spread_method="mfma_patches")
+    dev = plan.device
+    rng = np.random.default_rng(9)
+    w = (rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape))
+    w = w.astype(np.complex64 if plan_real_dtype(Z) == np.float32 else np.complex128)
+    sets = {
+        "folded normal": tuple(np.mod(rng.standard_normal(Np), 2 * np.pi).astype(x.dtype) for x in xs),
+        "slab": (xs[0], xs[1], (np.pi + 0.15 * rng.standard_normal(Np)).astype(xs[2].dtype)),        # a few bin layers hold everything
+        "two columns": ((0.2 * xs[0]).astype(xs[0].dtype), (5.5 + 0.1 * xs[1]).astype(xs[1].dtype), xs[2]),
+    }
+    for name, pts in sets.items():
+        nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
+        O.set_points(oplan, pts)
+        u = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+        nufft.exec_type1(u, plan, torch.from_numpy(vs[0]).to(dev))
+        assert plan.spread_engine_used() == "mfma_patches", name
+        assert _rel(u.cpu().numpy(), O.exec_type1(oplan, _oracle_inputs(oplan, vs)[0])) < _rtol(Z), name
+        out = torch.empty(Np, dtype=plan.Z, device=dev)
+        nufft.exec_type2(out, plan, torch.from_numpy(w).to(dev))
+        assert plan.interp_engine_used() == "marching_ring", name
+        assert _rel(out.cpu().numpy(), O.exec_type2(oplan, _oracle_inputs(oplan, [w])[0])) < _rtol(Z), name
 
 
 def test_spreading_engine_selection():
