@@ -247,7 +247,7 @@ __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int 
 
 __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int npy, int pbx, int pby, int clo, int chi, int zq, int segl, int maxlen,
                                                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ first,
-                                                         unsigned long long limit, unsigned long long slots_eff, int uniform_always,
+                                                         unsigned long long limit, unsigned long long limit_cut, unsigned long long slots_eff, int uniform_always,
                                                          uint2* __restrict__ tasktab, uint32_t* __restrict__ choice,
                                                          uint32_t* __restrict__ slots_in_use) {
     __shared__ uint32_t cum_all[256 / kWave][kPatchMaxLayers + 1];
@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
             choice[1] = 0u;
             // the kernel takes about max(heaviest task, all tasks / wave slots) point visits per wave: patches while that
             // stays within `limit` (launch_patch_tasks)
-            const bool patches = (mx <= limit && sum <= limit * slots_eff) || sum == 0ull || (uniform_always && choice[3] != 0u);
+            const unsigned long long lim = choice[3] != 0u ? limit : limit_cut;      // (the estimate is exact for equal-length tasks)
+            const bool patches = (mx <= lim && sum <= lim * slots_eff) || sum == 0ull || (uniform_always && choice[3] != 0u);
             choice[2] = patches ? 1u : 0u;
             if (patches && slots_in_use) slots_in_use[0] = 0u;
         }
@@ -399,9 +400,10 @@ __global__ __launch_bounds__(1024) void patch_task_sort_kernel(int ntasks, int n
 bool patch_tasks_supported(const Geom& g) { return g.nb[2] <= kPatchMaxLayers; }
 int patch_task_table_entries(const PatchPlan& pp) { return pp.ntasks + 2 * pp.npx * pp.npy; }      // column_task_table_entries of its columns
 
-// limit / slots_eff: the engine keeps the point set while max(heaviest task, all tasks / slots_eff) <= limit
+// limit / slots_eff: the engine keeps the point set while max(heaviest task, all tasks / slots_eff) <= limit (limit_cut for
+// tasks of equal point count)
 static hipError_t launch_column_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, unsigned long long limit,
-                                      unsigned long long slots_eff, bool uniform_always, uint32_t* choice, uint32_t* slots_in_use,
+                                      unsigned long long limit_cut, unsigned long long slots_eff, bool uniform_always, uint32_t* choice, uint32_t* slots_in_use,
                                       uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
     const int ncols = ct.ncolx * ct.ncoly, wpb = 256 / kWave;
     const int ntab = column_task_table_entries(ct, g.nb[2]);
@@ -411,7 +413,7 @@ static hipError_t launch_column_tasks(const Geom& g, const ColumnTasks& ct, cons
     hipLaunchKernelGGL(patch_task_counts_kernel, dim3(1), dim3(1024), 0, stream, ncols, ct.ntasks, ntab, ct.nseg, min_seg, g.nb[2] / ct.zq,
                        (unsigned long long)np, colsum, first, tasktab, choice);
     hipLaunchKernelGGL(patch_split_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, ct.ncolx, ct.ncoly, ct.bxw, ct.byw,
-                       ct.clo, ct.chi, ct.zq, ct.segl, ct.maxlen, offsets, first, limit, slots_eff, uniform_always ? 1 : 0, tasktab, choice, slots_in_use);
+                       ct.clo, ct.chi, ct.zq, ct.segl, ct.maxlen, offsets, first, limit, limit_cut, slots_eff, uniform_always ? 1 : 0, tasktab, choice, slots_in_use);
     if (ntab <= kPatchSortMax && ncols < 65536) {
         int npad = 2;
         while (npad < ntab) npad <<= 1;
@@ -439,7 +441,7 @@ hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int c
     const double infl0 = (double)(pp.segl + (chi - clo)) / (double)pp.segl;
     const unsigned long long limit = advantage > 0.0 ? (unsigned long long)(advantage * infl0 * (double)np / (double)slots_eff) + 64ull
                                                      : ~0ull / (slots_eff + 1ull);
-    return launch_column_tasks(g, ct, offsets, np, limit, slots_eff, true, choice, slots_in_use, colsum, first, tasktab, stream);
+    return launch_column_tasks(g, ct, offsets, np, limit, limit, slots_eff, true, choice, slots_in_use, colsum, first, tasktab, stream);
 }
 
 // The same for the z-marching interpolation ring (march_kernels.h): a task is a workgroup that owns a column of the grid
@@ -451,7 +453,10 @@ hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32
                               uint32_t* choice, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
     const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(cus, ct.ntasks));
     const unsigned long long limit = (unsigned long long)(advantage * (double)np / (double)cus) + 64ull;
-    return launch_column_tasks(g, ct, offsets, np, limit, slots_eff, false, choice, nullptr, colsum, first, tasktab, stream);
+    // tasks of equal point count: x 0.85 for what the estimate leaves out (per-task window loads, the scheduling tail —
+    // folded N(0, 1) points at 0.3 points per cell: the ring takes 1.27x its time for uniform points)
+    const unsigned long long limit_cut = (unsigned long long)(0.85 * advantage * (double)np / (double)cus) + 64ull;
+    return launch_column_tasks(g, ct, offsets, np, limit, limit_cut, slots_eff, false, choice, nullptr, colsum, first, tasktab, stream);
 }
 
 // Zero the interior of the spreading tiles that are processed by several slices (they accumulate with

@@ -1046,10 +1046,17 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
                                      p->d_patch_cols + ncols, static_cast<uint2*>(p->d_patch_tasks), stream));
     }
     if (p->interp_march) {
-        // tasks of the interpolation ring for this point set, and whether it serves it (balance.hip).  Its measured advantage
-        // over interp_tile_kernel on uniform points: 1.26 at C2 (m = 4), 1.55 at Float64 m = 6, 1.9 at C3 (m = 8).
+        // tasks of the interpolation ring for this point set, and whether it serves it (balance.hip).  What the ring saves
+        // over interp_tile_kernel is grid traffic (halo 1.5x instead of 2.6x at m = 4, 3.75x instead of 12.5x at m = 8), which
+        // it also takes off the critical path; its gather itself is ~9 % slower per point (ring index arithmetic, two barriers
+        // per bin layer).  So its advantage falls with the point density rho = points per oversampled cell,
+        //   advantage = (rho + c_t) / (1.09 rho + c_r),  c_t = 0.038 (m/4)^1.85,  c_r = 0.0086 (m/4)^1.2
+        // fitted to: C2 (m = 4, rho = 0.075) 1.26, Float64 m = 6 1.55, C3 (m = 8, rho = 0.093) 1.9, and Float64 m = 4 at
+        // rho = 0.3 (1.68e7 points on 384^3) 1.0 — above that density the tile kernel is the faster one even for uniform points.
         // (NUFFT_INTERP_MARCH=2: always the ring — tests of its instantiations on small grids)
-        const double advantage = env_int("NUFFT_INTERP_MARCH", 1) == 2 ? 1e12 : 1.2 * std::pow(1.1, (double)std::max(p->M - 4, 0));
+        const double rho = (double)np / (double)std::max<int64_t>(p->grid_elems, 1), mr = (double)p->M / 4.0;
+        const double fitted = (rho + 0.038 * std::pow(mr, 1.85)) / (1.09 * rho + 0.0086 * std::pow(mr, 1.2));
+        const double advantage = env_int("NUFFT_INTERP_MARCH", 1) == 2 ? 1e12 : fitted;
         const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
         NUFFT_HIP(launch_march_tasks(s.g, p->march_ct, p->d_offsets, np, p->num_cus, advantage, p->d_march_choice, p->d_march_cols,
                                      p->d_march_cols + ncols, static_cast<uint2*>(p->d_march_tasks), stream));

@@ -833,13 +833,14 @@ __global__ __launch_bounds__(1024) void spread_tile_kernel(TileArgs<T> a) {
 // ---------------------------------------------------------------------------------------------
 // FIXED: the tile shape is the compile-time one of fixed_interp_tile() (the host launches this variant
 // only when the plan's tile equals it), which turns the LDS strides into immediates.
-template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK>
-__device__ __forceinline__ void interp_tile_slot(const TileArgs<T>& a, const uint32_t slot, const uint32_t nslots, unsigned char* smem) {
+template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK = false>
+__global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
     constexpr int NC = CPLX ? 2 : 1;
     constexpr int L = 2 * M;
     using GP = Grp<NC, M>;
     constexpr FixedTileDims FD = fixed_interp_tile((int)sizeof(T), NC, D, M);
     static_assert(!FIXED || FD.n[0] > 0, "no compile-time tile for this instantiation");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -849,7 +850,13 @@ __device__ __forceinline__ void interp_tile_slot(const TileArgs<T>& a, const uin
     const Geom& g = a.g;
     const TileShape& ts = g.ip;
 
-    const uint2 de = a.desc[xcd_remap_chunked((int)slot, (int)nslots, a.xcd_chunk)];
+    // (one workgroup per slot.  A bounded grid whose workgroups stride over the slots would make the launch that finds the
+    // ring at work cost 8192 workgroups instead of one per tile — 0.76 ms at C3's 7e5 tiles — but the loop around the body
+    // cost 15-60 spilled registers in half of the instantiations, including every 1-D / 2-D one: not kept.)
+    const uint32_t nslots = *a.desc_total;
+    if (blockIdx.x >= nslots) return;
+    if (a.march_flag && *a.march_flag != 0u) return;                // this point set goes to interp_march_kernel
+    const uint2 de = a.desc[xcd_remap_chunked(blockIdx.x, (int)nslots, a.xcd_chunk)];
     const int tile_id = (int)de.x, slice = (int)(de.y >> 16), nslices = (int)(de.y & 0xffffu);
     const int comp_id = blockIdx.y;
     int t[3];
@@ -1105,20 +1112,6 @@ __device__ __forceinline__ void interp_tile_slot(const TileArgs<T>& a, const uin
             }
             rec = recn;
         }
-    }
-}
-
-// One workgroup per slot — or, where the z-marching ring may serve the point set instead, a bounded grid whose workgroups
-// stride over the slots: the launch that finds nothing to do then costs 8192 workgroups, not one per tile (0.76 ms of
-// 1024-thread workgroups that only returned, at C3's 7e5 tiles).
-template <typename T, bool CPLX, int D, int M, bool FIXED, bool OTHERK = false>
-__global__ __launch_bounds__(1024) void interp_tile_kernel(TileArgs<T> a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t nslots = *a.desc_total;
-    if (a.march_flag && *a.march_flag != 0u) return;                // this point set goes to interp_march_kernel
-    for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
-        interp_tile_slot<T, CPLX, D, M, FIXED, OTHERK>(a, slot, nslots, smem);
-        __syncthreads();                                            // the next slot reuses the tile and the item table
     }
 }
 

@@ -209,9 +209,7 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
         k.march_flag = march ? a.march_flag : nullptr;
         void* params[] = {&k};
-        // (a.ntiles = the slot budget; with the ring beside it the tile kernel strides over the slots from a bounded grid)
-        const unsigned grid_x = march ? (unsigned)std::min<int64_t>(a.ntiles, 8192) : (unsigned)a.ntiles;
-        hipError_t e = hipLaunchKernel(fn, dim3(grid_x, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
+        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)a.ntiles, (unsigned)nc, 1), dim3((unsigned)a.threads, 1, 1),
                                        params, (size_t)a.lds_bytes, stream);
         if (e != hipSuccess) return e;
         if (march) {
