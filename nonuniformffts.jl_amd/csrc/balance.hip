@@ -18,14 +18,17 @@
 
 namespace nufft {
 
-// One wave per tile of either tiling (waves [0, nsp): spreading tiles, [nsp, nsp + nip): interpolation
+// kWorkLanes lanes per tile of either tiling (groups [0, nsp): spreading tiles, [nsp, nsp + nip): interpolation
 // tiles): number of point visits of a spreading tile (points of all bins within M cells of the interior)
-// or number of points of an interpolation tile.
+// or number of points of an interpolation tile.  (A tile has 6 - 40 runs of bins: a whole wave per tile left most lanes
+// idle and cost 0.32 ms for the 7e5 tiles of a 1024^3 grid.)
+constexpr int kWorkLanes = 16;
+
 __global__ __launch_bounds__(256) void tile_work_kernel(Geom g, int D, int M, const uint32_t* __restrict__ offsets,
                                                        uint32_t* __restrict__ work) {
     const int nsp = g.sp.ntiles, nip = g.ip.ntiles;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWorkLanes;      // (the tile of this group of lanes)
+    const int lane = threadIdx.x & (kWorkLanes - 1);
     if (wave >= nsp + nip) return;
     const bool interp = wave >= nsp;
     const TileShape& ts = interp ? g.ip : g.sp;
@@ -49,14 +52,14 @@ __global__ __launch_bounds__(256) void tile_work_kernel(Geom g, int D, int M, co
     const int R2 = seg[1].total(), R3 = seg[2].total();
     const int nruns = R2 * R3 * seg[0].n;
     uint32_t sum = 0;
-    for (int item = lane; item < nruns; item += kWave) {
+    for (int item = lane; item < nruns; item += kWorkLanes) {
         const int sg = item % seg[0].n;
         const int r2 = (item / seg[0].n) % R2;
         const int r3 = item / (seg[0].n * R2);
         const int bin0 = (seg[2].bin(r3) * g.nb[1] + seg[1].bin(r2)) * g.nb[0] + (sg ? seg[0].lo[1] : seg[0].lo[0]);
         sum += offsets[bin0 + (sg ? seg[0].len[1] : seg[0].len[0])] - offsets[bin0];
     }
-    for (int o = kWave / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, kWave);
+    for (int o = kWorkLanes / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, kWorkLanes);
     if (lane == 0) work[wave] = sum;
 }
 
@@ -111,18 +114,20 @@ __global__ __launch_bounds__(256) void tile_slices_kernel(const uint32_t* __rest
 
 // descriptor of slot q: x = tile, y = slice << 16 | slices of the tile.  Spreading slots start at desc[0],
 // interpolation slots at desc[ip_base]; slots_in_use[0 / 1] receive the two slot counts.
-__global__ __launch_bounds__(64) void fill_desc_kernel(const uint32_t* __restrict__ nslices,
-                                                      const uint32_t* __restrict__ desc_off, int nsp, int nip,
-                                                      uint32_t ip_base, uint2* __restrict__ desc,
-                                                      uint32_t* __restrict__ slots_in_use) {
-    const int t = blockIdx.x;
+__global__ __launch_bounds__(256) void fill_desc_kernel(const uint32_t* __restrict__ nslices,
+                                                       const uint32_t* __restrict__ desc_off, int nsp, int nip,
+                                                       uint32_t ip_base, uint2* __restrict__ desc,
+                                                       uint32_t* __restrict__ slots_in_use) {
+    constexpr int kLanes = 8;                            // lanes per tile (most tiles have one slice)
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanes, lane = threadIdx.x & (kLanes - 1);
+    if (t >= nsp + nip) return;
     const uint32_t split = desc_off[nsp];
     const bool interp = t >= nsp;
     const uint32_t S = nslices[t];
     const uint32_t off = interp ? ip_base + (desc_off[t] - split) : desc_off[t];
     const uint32_t tile = interp ? (uint32_t)(t - nsp) : (uint32_t)t;
-    for (uint32_t s = threadIdx.x; s < S; s += blockDim.x) desc[off + s] = make_uint2(tile, (s << 16) | S);
-    if (t == 0 && threadIdx.x == 0) {
+    for (uint32_t s = lane; s < S; s += kLanes) desc[off + s] = make_uint2(tile, (s << 16) | S);
+    if (t == 0 && lane == 0) {
         slots_in_use[0] = split;
         slots_in_use[1] = desc_off[nsp + nip] - split;
     }
@@ -142,7 +147,7 @@ size_t balance_scan_tmp_bytes(int ntiles_both) {
 
 hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream) {
     const int nsp = b.g.sp.ntiles, nip = b.g.ip.ntiles, n = nsp + nip;
-    const int waves_per_block = 256 / kWave;
+    const int waves_per_block = 256 / kWorkLanes;
     hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((n + waves_per_block - 1) / waves_per_block)), dim3(256), 0, stream,
                        b.g, b.D, b.M, b.offsets, b.work);
     // (the partial sums live behind the n + 1 work counters: balance_work_words())
@@ -153,7 +158,7 @@ hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream) {
     size_t tmp = b.scan_tmp_bytes;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, tmp, b.nslices, b.desc_off, n + 1, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fill_desc_kernel, dim3((unsigned)n), dim3(64), 0, stream, b.nslices, b.desc_off, nsp, nip,
+    hipLaunchKernelGGL(fill_desc_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, b.nslices, b.desc_off, nsp, nip,
                        (uint32_t)nsp + b.extra_sp, b.desc, b.slots_in_use);
     return hipGetLastError();
 }
@@ -174,22 +179,32 @@ constexpr int kPatchMaxLayers = 2048;                   // bin layers of a colum
 
 __global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx, int npy, int pbx, int pby, int segl, const uint32_t* __restrict__ offsets,
                                                                uint32_t* __restrict__ colsum, uint32_t* __restrict__ choice) {
-    const int c = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, lane = threadIdx.x & (kWave - 1);
+    __shared__ uint32_t seg_all[256 / kWave][kPatchMaxLayers];          // points per equal-length segment of the wave's column
+    const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.x * (256 / kWave) + w;
     if (c >= npx * npy) return;
     const int bx0 = (c % npx) * pbx, by0 = (c / npx) * pby;
     const int ncx = min(pbx, g.nb[0] - bx0), ncy = min(pby, g.nb[1] - by0);
-    uint32_t total = 0, heaviest = 0;
-    for (int z0 = 0; z0 < g.nb[2]; z0 += segl) {        // segments of equal length: the partition uniform point sets keep
-        const int nl = min(segl, g.nb[2] - z0);
-        uint32_t sum = 0;
-        for (int item = lane; item < ncy * nl; item += kWave) {
-            const int64_t bin0 = ((int64_t)(z0 + item / ncy) * g.nb[1] + by0 + item % ncy) * g.nb[0] + bx0;
-            sum += offsets[bin0 + ncx] - offsets[bin0];
+    const int nz = g.nb[2], nseg = (nz + segl - 1) / segl;
+    uint32_t* seg = seg_all[w];
+    for (int s = lane; s < nseg; s += kWave) seg[s] = 0u;
+    wave_lds_fence();
+    uint32_t total = 0;
+    for (int z = lane; z < nz; z += kWave) {              // one bin layer per lane and step: all its loads in flight together
+        uint32_t n = 0;
+        for (int y = 0; y < ncy; ++y) {
+            const int64_t bin0 = ((int64_t)z * g.nb[1] + by0 + y) * g.nb[0] + bx0;
+            n += offsets[bin0 + ncx] - offsets[bin0];
         }
-        for (int o = kWave / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, kWave);
-        sum = __shfl(sum, 0, kWave);
-        total += sum;
-        heaviest = max(heaviest, sum);
+        total += n;
+        if (n) atomicAdd(&seg[z / segl], n);
+    }
+    wave_lds_fence();
+    uint32_t heaviest = 0;                                // of the segments of equal length: the partition uniform point sets keep
+    for (int s = lane; s < nseg; s += kWave) heaviest = max(heaviest, seg[s]);
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        total += __shfl_down(total, o, kWave);
+        heaviest = max(heaviest, (uint32_t)__shfl_down(heaviest, o, kWave));
     }
     if (lane == 0) {
         colsum[c] = total;
@@ -203,8 +218,10 @@ __global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx,
 // S_c = round(T points(c) / Np) segments per column; their exclusive scan (first[c]; first[ncols] = tasks in use; the table
 // holds T + columns entries, enough for any rounding), empty entries behind.  choice[3] = 1: equal-length mode.
 __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int ntasks, int ntab, int nseg, int min_seg, int max_seg, unsigned long long np,
+                                                                unsigned long long limit, unsigned long long slots_eff, int uniform_always,
                                                                 const uint32_t* __restrict__ colsum, uint32_t* __restrict__ first,
-                                                                uint2* __restrict__ tasktab, uint32_t* __restrict__ choice) {
+                                                                uint2* __restrict__ tasktab, uint32_t* __restrict__ choice,
+                                                                uint32_t* __restrict__ slots_in_use) {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t carry;
     __shared__ int uniform_mode;
@@ -215,6 +232,13 @@ __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int 
         const uint32_t heaviest = choice[3];
         uniform_mode = (double)heaviest <= 1.1 * mean + 5.0 * sqrt(mean) + 8.0;
         choice[3] = uniform_mode ? 1u : 0u;
+        if (uniform_mode) {
+            // equal-length tasks: the engine is decided here (patch_split_kernel only writes the table then).  The patches
+            // always keep such a point set; the ring's estimate needs no halo (clo = chi = 0): heaviest task and np are exact.
+            const bool keep = uniform_always || np == 0ull || ((unsigned long long)heaviest <= limit && np <= limit * slots_eff);
+            choice[2] = keep ? 1u : 0u;
+            if (keep && slots_in_use) slots_in_use[0] = 0u;
+        }
     }
     __syncthreads();
     const bool uni = uniform_mode != 0;
@@ -255,6 +279,17 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
     const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     const int c = blockIdx.x * (256 / kWave) + w;
     const int nz = g.nb[2];
+    if (choice[3] != 0u) {
+        // equal-length mode: the table in launch order (segment, column); patch_task_counts_kernel has decided the engine
+        if (c < npx * npy) {
+            const uint32_t S = first[c + 1] - first[c];
+            for (uint32_t k = lane; k < S; k += kWave) {
+                const int z0 = min(nz, (int)k * segl), z1 = min(nz, ((int)k + 1) * segl);
+                tasktab[k * (uint32_t)(npx * npy) + (uint32_t)c] = make_uint2((uint32_t)c, z1 > z0 ? ((uint32_t)z1 << 16) | (uint32_t)z0 : 0u);
+            }
+        }
+        return;
+    }
     uint32_t* cum = cum_all[w];
     unsigned long long wsum = 0;
     uint32_t wmax = 0;
@@ -290,7 +325,7 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
         wave_lds_fence();
         const uint32_t total = cum[nz];
         const uint32_t t0 = first[c], S = first[c + 1] - t0;
-        const bool uni = choice[3] != 0u;                 // equal-length segments, stored in launch order (segment, column)
+        constexpr bool uni = false;                       // (equal-length mode returned above)
         auto boundary = [&](uint32_t k) -> int {          // first layer of segment k (k = S: the end)
             if (k == 0) return 0;
             if (k >= S) return nz;
@@ -411,7 +446,7 @@ static hipError_t launch_column_tasks(const Geom& g, const ColumnTasks& ct, cons
                        ct.segl, offsets, colsum, choice);
     const int min_seg = ct.maxlen > 0 ? (g.nb[2] + ct.maxlen - 1) / ct.maxlen : 1;
     hipLaunchKernelGGL(patch_task_counts_kernel, dim3(1), dim3(1024), 0, stream, ncols, ct.ntasks, ntab, ct.nseg, min_seg, g.nb[2] / ct.zq,
-                       (unsigned long long)np, colsum, first, tasktab, choice);
+                       (unsigned long long)np, limit, slots_eff, uniform_always ? 1 : 0, colsum, first, tasktab, choice, slots_in_use);
     hipLaunchKernelGGL(patch_split_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, ct.ncolx, ct.ncoly, ct.bxw, ct.byw,
                        ct.clo, ct.chi, ct.zq, ct.segl, ct.maxlen, offsets, first, limit, limit_cut, slots_eff, uniform_always ? 1 : 0, tasktab, choice, slots_in_use);
     if (ntab <= kPatchSortMax && ncols < 65536) {
