@@ -118,6 +118,9 @@ struct FftLineArgs {
     const void* twiddle;      // complex<T>[N]: exp(SIGN 2πi m / N)
     double scale;             // extra scalar factor (normfactor)
     const void* mult;         // optional T[]: real multiplier indexed like the pruned side (uniform callback), or null
+    // rows: a = r * row_a + k1 enumerates rows r of row_a columns of which k1 < row_valid exist; the row strides of the two
+    // sides differ (intermediates pad their rows to 128 bytes, the caller's array does not).  row_a = 0: no row structure.
+    int row_a, row_valid, row_in, row_out;
 };
 
 // One radix-R Stockham stage of a line held in LDS (in place, wave-synchronous).
@@ -201,6 +204,21 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     const T* fk = static_cast<const T*>(a.fk);
     const T scale = (T)a.scale;
     const T* mult = static_cast<const T*>(a.mult);
+    // this thread's column (NT is a multiple of TA: e % TA is the same in every loop below)
+    const int64_t acol = a0 + tid % TA;
+    bool cvalid = acol < a.a_total;
+    int64_t in_col = acol, out_col = acol;
+    int fidx = 0;
+    if (a.row_a > 0) {
+        const int64_t r = acol / a.row_a;
+        const int k1 = (int)(acol - r * a.row_a);
+        cvalid = cvalid && k1 < a.row_valid;
+        in_col = r * a.row_in + k1;
+        out_col = r * a.row_out + k1;
+        fidx = k1;
+    } else if (a.ka > 1) {
+        fidx = (int)(acol % a.ka);
+    }
 
     if (!FWD && a0 >= a.a_total) {
         // backward: columns beyond the kept ones are zeros of the oversampled spectrum
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
         for (int e = tid; e < TA * N; e += NT) {
             const int ai = e % TA, j = e / TA;
             C v; v.x = T(0); v.y = T(0);
-            if (a0 + ai < a.a_total) v = in[a0 + ai + (int64_t)j * a.in_stride_j];
+            if (cvalid) v = in[in_col + (int64_t)j * a.in_stride_j];
             lines[ai * LINE + lpad(j)] = v;
         }
     } else {
@@ -228,10 +246,10 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
         __syncthreads();
         for (int e = tid; e < TA * a.nk; e += NT) {
             const int ai = e % TA, k = e / TA;
-            if (a0 + ai < a.a_total) {
-                const int64_t off = a0 + ai + (int64_t)k * a.in_stride_j;
+            if (cvalid) {
+                const int64_t off = in_col + (int64_t)k * a.in_stride_j;
                 C v = in[off];
-                T f = fa[(a0 + ai) % a.ka] * fk[k] * scale;
+                T f = fa[fidx] * fk[k] * scale;
                 if constexpr (MULT) f *= mult[off];
                 v.x *= f; v.y *= f;
                 lines[ai * LINE + lpad(a.map[k])] = v;
@@ -246,10 +264,10 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     if (FWD) {
         for (int e = tid; e < TA * a.nk; e += NT) {
             const int ai = e % TA, k = e / TA;
-            if (a0 + ai < a.a_total) {
+            if (cvalid) {
                 C v = lines[ai * LINE + lpad(a.map[k])];
-                const int64_t off = a0 + ai + (int64_t)k * a.out_stride_j;
-                T f = fa[(a0 + ai) % a.ka] * fk[k] * scale;
+                const int64_t off = out_col + (int64_t)k * a.out_stride_j;
+                T f = fa[fidx] * fk[k] * scale;
                 if constexpr (MULT) f *= mult[off];
                 v.x *= f; v.y *= f;
                 out[off] = v;
@@ -258,7 +276,9 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     } else {
         for (int e = tid; e < TA * N; e += NT) {
             const int ai = e % TA, j = e / TA;
-            if (a0 + ai < a.a_out) {
+            if (a.row_a > 0) {
+                if (cvalid) out[out_col + (int64_t)j * a.out_stride_j] = lines[ai * LINE + lpad(j)];
+            } else if (a0 + ai < a.a_out) {
                 C v = lines[ai * LINE + lpad(j)];
                 if (a0 + ai >= a.a_total) { v.x = T(0); v.y = T(0); }
                 out[a0 + ai + (int64_t)j * a.out_stride_j] = v;
@@ -277,6 +297,7 @@ struct RealLineArgs {
     void* out;
     int64_t nlines;
     int k1;                 // kept modes per line
+    int row;                // row stride of the compact spectrum in complex elements (>= k1: rows padded to 128 bytes)
     const void* twiddle;    // complex<T>[N]: exp(SIGN 2πi m / N), N = 2M
 };
 
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         for (int n = lane; n < M; n += kWave) line[lpad(n)] = zin[n];
         wave_lds_fence();
         fft_line<T, M, -1, 2>(line, tw, lane);
-        C* xout = static_cast<C*>(a.out) + line_id * a.k1;
+        C* xout = static_cast<C*>(a.out) + line_id * a.row;
         for (int k = lane; k < a.k1; k += kWave) {
             const C zk = line[lpad(k == M ? 0 : k)];
             C zm = line[lpad(k == 0 ? 0 : M - k)];
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         // Z[k] = E'[k] + i O'[k] with E' = X[k] + conj(X[M-k]), O' = w^k (X[k] - conj(X[M-k])), w = exp(+2πi/N).
         // The partner of k is M - k: Z[M-k] = conj(E'[k]) + i conj(O'[k]), so one lane builds both from two
         // global loads and no staging copy of X is needed in LDS (X is zero beyond the kept modes).
-        const C* xin = static_cast<const C*>(a.in) + line_id * a.k1;
+        const C* xin = static_cast<const C*>(a.in) + line_id * a.row;
         for (int k = lane; k <= M / 2; k += kWave) {
             C xk, xm;
             xk.x = xk.y = xm.x = xm.y = T(0);
@@ -462,10 +483,10 @@ bool real_lines_supported(int dtype, int64_t n) {
     return n % 2 == 0 && size_instantiated(n / 2);
 }
 
-hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
+hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1, int row,
                              const void* twiddle, hipStream_t stream) {
     RealLineArgs a;
-    a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.twiddle = twiddle;
+    a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.row = row; a.twiddle = twiddle;
     const int m = (int)(n / 2);
     if (dtype == NUFFT_F32) return forward ? launch_real_t<float, true>(m, a, stream) : launch_real_t<float, false>(m, a, stream);
     return forward ? launch_real_t<double, true>(m, a, stream) : launch_real_t<double, false>(m, a, stream);
@@ -566,6 +587,7 @@ hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePas
     a.out_stride_j = p.out_stride_j; a.out_stride_c = p.out_stride_c;
     a.nc = p.nc; a.nk = p.nk; a.map = p.map; a.fa = p.fa; a.ka = p.ka; a.fk = p.fk;
     a.twiddle = p.twiddle; a.scale = p.scale; a.mult = p.mult;
+    a.row_a = p.row_a; a.row_valid = p.row_valid; a.row_in = p.row_in; a.row_out = p.row_out;
     if (dtype == NUFFT_F32) return forward ? launch_t<float, true>((int)n, a, stream) : launch_t<float, false>((int)n, a, stream);
     return forward ? launch_t<double, true>((int)n, a, stream) : launch_t<double, false>((int)n, a, stream);
 }

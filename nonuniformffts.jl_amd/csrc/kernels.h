@@ -168,11 +168,13 @@ struct FftLinePass {
     const void* twiddle;                    // complex<T>[N]
     double scale;
     const void* mult;                       // optional T[...]: real multiplier indexed like the pruned side, or null
+    int row_a = 0, row_valid = 0, row_in = 0, row_out = 0;      // rows of the enumeration and their strides on both sides (0: none)
 };
 bool fft_lines_supported(int dtype, int64_t n);
 bool real_lines_supported(int dtype, int64_t n);
 // r2c (forward) / c2r of `nlines` contiguous real lines of length n with a compact spectrum of k1 modes per line
-hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
+// (row: row stride of the compact spectrum in complex elements, >= k1)
+hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1, int row,
                              const void* twiddle, hipStream_t stream);
 hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePass& p, hipStream_t stream);
 // c2c of `nlines` contiguous complex lines of length n with a compact spectrum of k1 kept modes (map: kept -> FFT index)

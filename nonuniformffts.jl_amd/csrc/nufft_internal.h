@@ -170,6 +170,8 @@ struct nufft_plan {
     // pruned strided passes fused with the deconvolution
     bool pruned_fft = false;
     bool compact_dim1 = false;         // dimension 1 by real_lines_kernel with a compact spectrum (row length N_out1)
+    int64_t spec_row = 0;             // row stride (complex elements) of the dimension-1 spectrum and of tmp2 on the pruned path:
+                                       // N_out1 padded to 128 bytes for real plans with the compact spectrum (aligned strided passes)
     rocfft_plan_t* fft1_fw = nullptr;
     rocfft_plan_t* fft1_bw = nullptr;
     void* d_tmp2 = nullptr;            // complex<T>[N_out1 * N_out2 * Ñ3] (3-D only)

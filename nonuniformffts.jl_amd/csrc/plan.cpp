@@ -514,8 +514,17 @@ static int build_device(nufft_plan* p) {
             rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_tw_bw[d], twb) : upload<double>(p, &p->d_tw_bw[d], twb);
             if (rc) return rc;
         }
+        // row stride of the compact dimension-1 spectrum and of tmp2: the strided passes read groups of adjacent columns,
+        // 128 bytes per row — with rows of N1/2 + 1 = 129 elements every group straddled two cache lines (PMC: 1.6x the bytes
+        // read); real plans pad their intermediate rows to 128 bytes (the buffers of the general path are large enough)
+        p->spec_row = p->compact_dim1 ? p->Nout[0] : p->Nspec[0];
+        if (p->compact_dim1 && !p->is_complex && env_int("NUFFT_FFT_PAD_ROWS", 1) != 0) {
+            const int64_t q = 128 / (int64_t)(2 * real_bytes(p));
+            p->spec_row = (p->Nout[0] + q - 1) / q * q;
+            if (p->spec_row > p->Nspec[0]) p->spec_row = p->Nout[0];      // (cannot happen for sigma >= 1.25; keeps d_uhat's size)
+        }
         if (D == 3) {
-            const size_t elems = (size_t)p->Nout[0] * p->Nout[1] * p->Nover[2];
+            const size_t elems = (size_t)(p->compact_dim1 ? p->spec_row : p->Nout[0]) * p->Nout[1] * p->Nover[2];
             if ((rc = dev_alloc(p, &p->d_tmp2, elems * 2 * real_bytes(p)))) return rc;
         }
     }
@@ -717,14 +726,14 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
         // components are contiguous both in us (Ñ1 reals per line) and in the compact spectrum (N_out1 per line);
         // the per-component offset of the compact spectrum is nlines_per_component * N_out1 <= spec_elems
         if (p->C == 1) {
-            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, p->d_us, p->d_uhat, nlines, (int)p->Nout[0], p->d_tw_fw[0], stream));
+            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, p->d_us, p->d_uhat, nlines, (int)p->Nout[0], (int)p->spec_row, p->d_tw_fw[0], stream));
         } else {
             const int64_t per = nlines / p->C;
             const size_t rb = real_bytes(p);
             for (int c = 0; c < p->C; ++c) {
                 const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
                 void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
-                NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], p->d_tw_fw[0], stream));
+                NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], (int)p->spec_row, p->d_tw_fw[0], stream));
             }
         }
         return NUFFT_OK;
@@ -739,7 +748,11 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
 static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hipStream_t stream) {
     const size_t cb = 2 * real_bytes(p);
     const int64_t K1 = p->Nout[0];
-    const int64_t S1 = p->compact_dim1 ? K1 : p->Nspec[0];      // row length of the dimension-1 spectrum
+    const int64_t S1 = p->spec_row;                              // row stride of the dimension-1 spectrum
+    // ... and of tmp2: unpadded on the way forward — the last pass would transform the pad columns too (5 % more lines at
+    // 129 -> 136) and is not bound by its reads: measured 0.172 against 0.146 ms at C2; the padded rows of the dimension-1
+    // spectrum do pay (pass 2 reads them: -0.015 ms), and so does a padded tmp2 on the way back (type 2: -0.06 ms)
+    const int64_t T1 = K1;
     FftLinePass q{};
     q.map = p->d_index_map[dim];
     q.nk = (int)p->Nout[dim];
@@ -751,18 +764,19 @@ static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hi
         q.in_stride_j = S1;
         q.in_stride_c = S1 * p->Nover[1];
         q.nc = p->D == 3 ? (int)p->Nover[2] : 1;
-        q.out_stride_j = K1;
-        q.out_stride_c = K1 * p->Nout[1];
+        q.out_stride_j = last ? K1 : T1;
+        q.out_stride_c = q.out_stride_j * p->Nout[1];
         q.out = last ? user_out : p->d_tmp2;
     } else {
         q.in = p->d_tmp2;
-        q.a_total = q.a_out = K1 * p->Nout[1];
-        q.in_stride_j = K1 * p->Nout[1];
+        q.a_total = q.a_out = T1 * p->Nout[1];
+        q.in_stride_j = T1 * p->Nout[1];
         q.in_stride_c = 0;
         q.nc = 1;
         q.out_stride_j = K1 * p->Nout[1];
         q.out_stride_c = 0;
         q.out = user_out;
+        if (T1 != K1) { q.row_a = (int)T1; q.row_valid = (int)K1; q.row_in = (int)T1; q.row_out = (int)K1; }
     }
     q.mult = last ? p->cb_mode_factors : nullptr;      // uniform callback menu: same layout as the caller's array
     if (last) {
@@ -783,7 +797,8 @@ static int pruned_forward_pass(nufft_plan* p, int c, int dim, void* user_out, hi
 static int pruned_backward_pass(nufft_plan* p, int c, int dim, const void* user_in, hipStream_t stream) {
     const size_t cb = 2 * real_bytes(p);
     const int64_t K1 = p->Nout[0];
-    const int64_t S1 = p->compact_dim1 ? K1 : p->Nspec[0];      // compact: no zero columns are written
+    const int64_t S1 = p->spec_row;                              // row stride of the dimension-1 spectrum
+    const int64_t T1 = p->compact_dim1 ? p->spec_row : K1;       // ... and of tmp2
     FftLinePass q{};
     q.map = p->d_index_map[dim];
     q.nk = (int)p->Nout[dim];
@@ -792,19 +807,20 @@ static int pruned_backward_pass(nufft_plan* p, int c, int dim, const void* user_
     const bool first = dim == p->D - 1;       // the pass that reads the caller's array
     if (dim == 2) {
         q.in = user_in;
-        q.a_total = q.a_out = K1 * p->Nout[1];
+        q.a_total = q.a_out = T1 * p->Nout[1];
         q.in_stride_j = K1 * p->Nout[1];
         q.in_stride_c = 0;
         q.nc = 1;
         q.out = p->d_tmp2;
-        q.out_stride_j = K1 * p->Nout[1];
+        q.out_stride_j = T1 * p->Nout[1];
         q.out_stride_c = 0;
+        if (T1 != K1) { q.row_a = (int)T1; q.row_valid = (int)K1; q.row_in = (int)K1; q.row_out = (int)T1; }
     } else {
         q.in = first ? user_in : p->d_tmp2;
         q.a_total = K1;
-        q.a_out = S1;                          // columns k1 >= N_out1 of the oversampled spectrum are zeros
-        q.in_stride_j = K1;
-        q.in_stride_c = K1 * p->Nout[1];
+        q.a_out = p->compact_dim1 ? K1 : S1;   // general path: columns k1 >= N_out1 of the oversampled spectrum are written as zeros
+        q.in_stride_j = first ? K1 : T1;
+        q.in_stride_c = q.in_stride_j * p->Nout[1];
         q.nc = p->D == 3 ? (int)p->Nover[2] : 1;
         q.out = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * cb;
         q.out_stride_j = S1;
@@ -1262,7 +1278,7 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
         for (int c = 0; c < p->C; ++c) {
             const void* in = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
             void* out = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
-            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], false, in, out, per, (int)p->Nout[0], p->d_tw_bw[0], stream));
+            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], false, in, out, per, (int)p->Nout[0], (int)p->spec_row, p->d_tw_bw[0], stream));
         }
         return NUFFT_OK;
     }
