@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 
 #include "device_common.h"
@@ -433,6 +434,11 @@ __global__ __launch_bounds__(1024) void patch_task_sort_kernel(int ntasks, int n
 }
 
 bool patch_tasks_supported(const Geom& g) { return g.nb[2] <= kPatchMaxLayers; }
+
+// plan creation: the sort kernel's 128 KiB of dynamic LDS (the attribute is per device)
+hipError_t prepare_column_tasks() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(patch_task_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchSortMax * 8);
+}
 int patch_task_table_entries(const PatchPlan& pp) { return pp.ntasks + 2 * pp.npx * pp.npy; }      // column_task_table_entries of its columns
 
 // limit / slots_eff: the engine keeps the point set while max(heaviest task, all tasks / slots_eff) <= limit (limit_cut for
@@ -452,11 +458,6 @@ static hipError_t launch_column_tasks(const Geom& g, const ColumnTasks& ct, cons
     if (ntab <= kPatchSortMax && ncols < 65536) {
         int npad = 2;
         while (npad < ntab) npad <<= 1;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(patch_task_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPatchSortMax * 8);
-            attr_set = true;
-        }
         hipLaunchKernelGGL(patch_task_sort_kernel, dim3(1), dim3(1024), (size_t)npad * 8, stream, ntab, npad, first, ncols, choice, tasktab);
     }
     return hipGetLastError();

@@ -125,6 +125,7 @@ hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int c
                               int wave_slots, double advantage, uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first,
                               uint2* tasktab, hipStream_t stream);
 bool patch_tasks_supported(const Geom& g);
+hipError_t prepare_column_tasks();       // once per plan (device attribute of the task sort kernel)
 int patch_task_table_entries(const PatchPlan& pp);       // entries of the task table = tasks the patch kernels are launched with
 hipError_t prepare_spread_patch(int dtype, int is_complex, int M, bool other, int planar_nc = 0);
 // all C value vectors of a real plan gathered into one interleaved buffer vout[p * C + c] (planar patch kernel)

@@ -571,6 +571,8 @@ static int build_device(nufft_plan* p) {
         p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
     }
 
+    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->interp_march) NUFFT_HIP(prepare_column_tasks());
+
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
         hipEvent_t a, b;
         NUFFT_HIP(hipEventCreate(&a));
