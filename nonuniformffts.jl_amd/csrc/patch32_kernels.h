@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
     const Geom& g = a.t.g;
     const PatchGeom& pg = a.pg;
 
-    if (a.enabled && *a.enabled == 0u) return;      // this point set goes to the LDS-tile kernel (patch_choice_kernel)
+    if (a.enabled && *a.enabled == 0u) return;      // this point set goes to the LDS-tile kernel (set_points: balance.hip)
     T* ctab = reinterpret_cast<T*>(smem);
     for (int i = threadIdx.x; i < 3 * P::NPOLY * L; i += kPatchWaves * kWave) ctab[i] = a.t.coefs[i];
     __syncthreads();

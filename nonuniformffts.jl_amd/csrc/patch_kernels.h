@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kPatchWaves * kWave, patch_occupancy(NP > 0 ? NP : 
     const Geom& g = a.t.g;
     const PatchGeom& pg = a.pg;
 
-    if (a.enabled && *a.enabled == 0u) return;      // this point set goes to the LDS-tile kernel (patch_choice_kernel)
+    if (a.enabled && *a.enabled == 0u) return;      // this point set goes to the LDS-tile kernel (set_points: balance.hip)
     // polynomial coefficients of the window: one copy per workgroup in LDS (re-read by every chunk evaluation)
     T* ctab = reinterpret_cast<T*>(smem);
     for (int i = threadIdx.x; i < 3 * P::NPOLY * L; i += kPatchWaves * kWave) ctab[i] = a.t.coefs[i];
