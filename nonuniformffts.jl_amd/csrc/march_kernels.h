@@ -13,9 +13,12 @@
 // passes of PPW points from an LDS counter.  The gather itself is the one of interp_tile_kernel (group mapping, DPP
 // broadcasts of the window values for real data, DPP / permlane reduction) with the plane index taken modulo RZ.
 //
-// Heavy columns are not shared between workgroups: set_points' balance pass (balance.hip) gives heavy tiles of the
-// regular tiling extra slices, and this kernel runs only when it gave none (uniform-like point sets; otherwise
-// interp_tile_kernel runs, which has the slices) — decided on the device, no host read-back.
+// Tasks: a workgroup's column and segment of bin layers come from a table that set_points builds per point set on the
+// device (balance.hip): segments of equal length for uniform point sets, of about equal point count (column quantiles,
+// at most kSegMax layers) otherwise.  A point is gathered once, by the task of its own column and layer, so short
+// segments in dense regions cost only window loads.  Point sets whose heaviest task would still hold the chip up —
+// and grids with too few columns to fill it — go to interp_tile_kernel, which shares heavy tiles between workgroups:
+// a device flag decides, no host read-back.
 #pragma once
 
 #include <hip/hip_runtime.h>
