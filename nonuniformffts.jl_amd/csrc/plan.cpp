@@ -1138,7 +1138,7 @@ int nufft_interp_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
     if (rc) return rc;
     if (!engine_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
     *engine_out = NUFFT_INTERP_LDS_TILES;
-    if (!p->interp_march) return NUFFT_OK;
+    if (!p->interp_march || p->cb_point_weights) return NUFFT_OK;      // (per-point weights of the callback menu: always the tile kernel)
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t flag = 0;
