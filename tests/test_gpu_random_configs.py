@@ -2,6 +2,8 @@
 sizes incl. primes and sizes smaller than a tile, M, sigma, kernel, evaluation mode, element type, ntransforms,
 fftshift, point distribution).  Complements the hand-picked matrix of tests/test_gpu_parity.py, which mirrors
 test/pseudo_gpu.jl."""
+import os
+
 import numpy as np
 import pytest
 
@@ -114,7 +116,7 @@ def _draw_large(rng):
     return M, sigma, dims, Z, mode, C, dist, engine
 
 
-@pytest.mark.parametrize("seed", range(56))
+@pytest.mark.parametrize("seed", range(56 + int(os.environ.get("NUFFT_TEST_EXTRA_SEEDS", "0"))))      # (soak runs: more seeds)
 def test_random_configuration_large_3d(seed, monkeypatch):
     """The same differential test on 3-D grids large enough for the engines that need room — register patches (Float64 and
     Float32 accumulators, planar components), the z-marching interpolation ring — with the default window, both evaluation
