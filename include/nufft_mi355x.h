@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define NUFFT_MI355X_VERSION 100 /* 0.1.0 */
+#define NUFFT_MI355X_VERSION 101 /* 0.1.1: nufft_info grew (patch_dims .. ring_segments) since 100 — a caller built against an older
+                                    header must compare nufft_sizeof_info() / nufft_version() with its own before nufft_plan_info() */
 
 /* ---- return codes ------------------------------------------------------------------- */
 enum {
@@ -113,8 +114,11 @@ typedef struct nufft_params {
  *   LDS tiles    — output-driven LDS tile with native ds_add_f64 (every D, M, kernel, grid size)
  *   MFMA patches — register-resident patches accumulated by the matrix pipe (3-D grids of 4-cell bins):
  *                  v_mfma_f64_4x4x4_4b with Float64 accumulators, or — ComplexF32 plans whose dimension 3 is a
- *                  multiple of 8 cells — v_mfma_f32_16x16x4 with Float32 accumulators (nufft_info.patch_f32acc) */
-enum { NUFFT_SPREAD_AUTO = 0, NUFFT_SPREAD_LDS_TILES = 1, NUFFT_SPREAD_MFMA_PATCHES = 2 };
+ *                  multiple of 8 cells — v_mfma_f32_16x16x4 with Float32 accumulators (nufft_info.patch_f32acc)
+ *   marching ring — a workgroup owns a column of the grid and marches along dimension 3 with a ring of 2M - 1 + 4 planes in
+ *                  LDS (ds_add_f64 as for the tiles, 1.4 - 1.5 point visits per point instead of 2.1, finished planes leave with
+ *                  coalesced stores while the ring moves on): 3-D grids of 4-cell bins; the automatic choice for real data, M <= 4 */
+enum { NUFFT_SPREAD_AUTO = 0, NUFFT_SPREAD_LDS_TILES = 1, NUFFT_SPREAD_MFMA_PATCHES = 2, NUFFT_SPREAD_MARCHING_RING = 3 };
 
 typedef struct nufft_info {
     int32_t dtype, is_complex, ndim, half_support, ntransforms, evalmode, fftshift, device;
@@ -137,12 +141,15 @@ typedef struct nufft_info {
     int32_t window_scale_log2[3]; /* device windows and phi_hat are scaled by 2^k_d (exact) */
     int32_t kernel;          /* NUFFT_KERNEL_*                                                     */
     int32_t spread_max_items, interp_max_items; /* capacity of the per-tile work-item tables (runs of sorted points) */
-    int32_t spread_method;   /* NUFFT_SPREAD_LDS_TILES or NUFFT_SPREAD_MFMA_PATCHES (what nufft_spread launches)      */
+    int32_t spread_method;   /* NUFFT_SPREAD_LDS_TILES, _MFMA_PATCHES or _MARCHING_RING (what nufft_spread launches)  */
     int32_t patch_dims[2];   /* MFMA patches: cube columns (of 4 x 4 cells) a wave owns along dimensions 1, 2; 0 otherwise */
     int32_t patch_f32acc;    /* MFMA patches: 1 = ComplexF32 on v_mfma_f32_16x16x4 with Float32 accumulators (the reference's
                                 accumulation type, src/spreading/gpu.jl:271-283), 0 = v_mfma_f64_4x4x4 with Float64 ones  */
     int32_t patch_planar;    /* MFMA patches: real plans with ntransforms = 2 / 3 spread that many components together (shared window
                                 evaluation and operands — the reference's TODO at src/spreading/gpu.jl:293); 0 = one at a time    */
+    int32_t ring_column[2];  /* marching ring: cells of a workgroup's column along dimensions 1, 2; 0 otherwise         */
+    int32_t ring_segments;   /* marching ring: segments a column is cut into along dimension 3 for uniform point sets  */
+    int32_t reserved_info;
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */
@@ -245,9 +252,10 @@ int nufft_set_timing(nufft_plan* plan, int enable);
  * Synchronises on the recorded events. */
 int nufft_get_stage_times(nufft_plan* plan, float* ms_out);
 
-/* Which engine served the point set of the last nufft_set_points: NUFFT_SPREAD_LDS_TILES or NUFFT_SPREAD_MFMA_PATCHES.
- * On plans whose nufft_info.spread_method is MFMA patches, set_points decides per point set on the device (a point
- * set that concentrates in a few patches goes to the LDS tiles, whose heavy tiles are shared by several workgroups);
+/* Which engine served the point set of the last nufft_set_points: NUFFT_SPREAD_LDS_TILES, _MFMA_PATCHES or _MARCHING_RING.
+ * On plans whose nufft_info.spread_method is MFMA patches or the marching ring, set_points decides per point set on the
+ * device (a point set that concentrates in a few patches / columns goes to the LDS tiles, whose heavy tiles are shared by
+ * several workgroups);
  * this reads the decision back (4 bytes, synchronises `stream`).  Inspection only: nothing on the hot path needs it. */
 int nufft_spread_engine_used(nufft_plan* plan, int* engine_out, void* stream);
 /* The same for the interpolation stage of nufft_exec_type2: NUFFT_INTERP_LDS_TILES (padded boxes, heavy tiles shared by

@@ -495,6 +495,20 @@ hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32
     return launch_column_tasks(g, ct, offsets, np, limit, limit_cut, slots_eff, false, choice, nullptr, colsum, first, tasktab, stream);
 }
 
+// The same for the z-marching spreading ring (smarch_kernels.h): a task is a workgroup that owns a column for a segment of bin
+// layers and visits the points of the hlo / hhi layers beyond it as well (clipped along z), so short segments in dense
+// regions multiply the visits as they do for the patches.  The ring keeps a point set while max(heaviest task, all tasks /
+// workgroups at work) stays within `advantage` x an even share of the chip; when it does, the LDS-tile kernel gets no slots.
+hipError_t launch_smarch_tasks(const Geom& g, const SMarchPlan& sp, const uint32_t* offsets, int64_t np, int cus, double advantage,
+                               uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
+    const ColumnTasks& ct = sp.ct;
+    const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(cus, ct.ntasks));
+    const double infl0 = (double)(ct.segl + sp.hlo + sp.hhi) / (double)ct.segl;
+    const unsigned long long limit = advantage > 0.0 ? (unsigned long long)(advantage * infl0 * (double)np / (double)cus) + 64ull
+                                                     : ~0ull / (slots_eff + 1ull);
+    return launch_column_tasks(g, ct, offsets, np, limit, limit, slots_eff, advantage <= 0.0, choice, slots_in_use, colsum, first, tasktab, stream);
+}
+
 // Zero the interior of the spreading tiles that are processed by several slices (they accumulate with
 // atomics; tiles with one slice store every cell exactly once and need no zero fill).
 template <typename T>

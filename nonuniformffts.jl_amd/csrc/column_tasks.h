@@ -18,4 +18,14 @@ inline int column_task_table_entries(const ColumnTasks& ct, int nz) {
     return ct.ntasks + (min_seg + 1) * ct.ncolx * ct.ncoly;
 }
 
+// Decomposition of a grid for the z-marching spreading ring (smarch_kernels.h), chosen at plan creation (smarch_plan)
+struct SMarchPlan {
+    bool eligible;
+    int n1, n2;                 // column interior chosen for this grid (multiples of the bin edge, <= the kernel's compile-time column)
+    int hlo, hhi;               // layers of points a segment visits below / above its own
+    int lds_bytes, threads;
+    ColumnTasks ct;             // columns and evenly cut tasks
+    double visits, efficiency;  // model: point visits per point, and the share of the chip the launch keeps busy
+};
+
 }  // namespace nufft

@@ -139,6 +139,16 @@ hipError_t launch_spread_patch(const TileKernelArgs& a, const PatchPlan& pp, con
 hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* sorted, int64_t np, const void* vin,
                                 const void* weights, void* vout, const uint32_t* enabled, hipStream_t stream);
 
+// ---- spreading on the z-marching LDS ring (smarch_kernels.h, smarch_*.hip) -------------------------------------------
+// 3-D plans with 4-cell bins and the default window evaluation whose axes are long enough; cus: compute units, C: components
+SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C);
+hipError_t prepare_spread_march(int dtype, int is_complex, int M);
+// flag: device flag of set_points (1: the ring serves this point set); tasktab: its task table
+hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream);
+// set_points: tasks of the ring for this point set and whether it serves it (advantage <= 0: always)
+hipError_t launch_smarch_tasks(const Geom& g, const SMarchPlan& sp, const uint32_t* offsets, int64_t np, int cus, double advantage,
+                               uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream);
+
 // ---- deconvolution (deconv.hip) ------------------------------------------------------------------
 struct DeconvArgs {
     int dtype, D, C;

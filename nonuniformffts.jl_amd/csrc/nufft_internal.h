@@ -127,6 +127,10 @@ struct nufft_plan {
     uint32_t* d_patch_choice = nullptr;   // [8]: scratch of patch_split_kernel; [2] = 1: this point set is spread by the patches
     uint32_t* d_patch_cols = nullptr;     // [columns] points per patch column, then [columns + 1] first task of each column
     void* d_patch_tasks = nullptr;        // uint2[ntasks]: {column, end layer << 16 | first layer}, rebuilt by every set_points
+    nufft::SMarchPlan smarch{};           // decomposition of the z-marching spreading ring (smarch_kernels.h); eligible = false: none
+    uint32_t* d_smarch_choice = nullptr;  // [8]: scratch of the task kernels; [2] = 1: this point set is spread by the ring
+    uint32_t* d_smarch_cols = nullptr;    // [columns] points per column, then [columns + 1] first task of each column
+    void* d_smarch_tasks = nullptr;       // uint2[table entries]: {column, end layer << 16 | first layer}, rebuilt by every set_points
     int wave_slots = 2048;             // resident waves of the patch kernel on this device (CUs x 4 SIMDs x its waves per SIMD)
     void* d_vsorted = nullptr;         // C value vectors in sorted order (MFMA-patch spreading)
     int64_t lds_spread = 0, lds_interp = 0;

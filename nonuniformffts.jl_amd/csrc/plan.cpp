@@ -332,7 +332,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     // spreading engine: MFMA patches where they apply (3-D, 4-cell bins, default window evaluation), LDS tiles otherwise
     {
         int req = in->spread_method != NUFFT_SPREAD_AUTO ? in->spread_method : env_int("NUFFT_SPREAD_METHOD", NUFFT_SPREAD_AUTO);
-        if (req < NUFFT_SPREAD_AUTO || req > NUFFT_SPREAD_MFMA_PATCHES) return fail(NUFFT_ERR_INVALID_ARG, "unknown spread_method");
+        if (req < NUFFT_SPREAD_AUTO || req > NUFFT_SPREAD_MARCHING_RING) return fail(NUFFT_ERR_INVALID_ARG, "unknown spread_method");
         p->spread_method_req = req;
         // NUFFT_PATCH_F32ACC=0: ComplexF32 plans keep the Float64-accumulating patch kernel (A/B runs)
         // NUFFT_PATCH_PLANAR=0: the components of a real plan with ntransforms = 2 / 3 are spread one after the other (A/B runs)
@@ -352,6 +352,17 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         const bool prefer_patches = p->is_complex || p->M >= 5 || pp.planar != 0 || env_int("NUFFT_PREFER_PATCHES", 0) != 0;     // (the switch: test runs)
         p->spread_method = (pp.eligible && (req == NUFFT_SPREAD_MFMA_PATCHES || (req == NUFFT_SPREAD_AUTO && prefer_patches)))
                                ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
+        // third engine, the z-marching LDS ring (smarch_kernels.h): same per-point arithmetic as the LDS tiles with 1.4 - 1.5 instead
+        // of 2.1 visits per point and no per-plane control — taken where the LDS tiles were the automatic choice (real data, M <= 4:
+        // measurements in DESIGN.md section 4.9); 256 CUs assumed here, build_device() redoes the decomposition for the device
+        p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C);
+        if (req == NUFFT_SPREAD_MARCHING_RING && !p->smarch.eligible)
+            return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = marching ring needs a 3-D grid of 4-cell bins with every oversampled axis a multiple "
+                                               "of 4 and longer than a column plus a stencil, and the default window evaluation");
+        const bool prefer_ring = env_int("NUFFT_PREFER_RING", 1) != 0 && !p->is_complex && p->M <= 4;
+        if (p->smarch.eligible && (req == NUFFT_SPREAD_MARCHING_RING ||
+                                   (req == NUFFT_SPREAD_AUTO && p->spread_method == NUFFT_SPREAD_LDS_TILES && prefer_ring)))
+            p->spread_method = NUFFT_SPREAD_MARCHING_RING;
     }
     return NUFFT_OK;
 }
@@ -571,7 +582,21 @@ static int build_device(nufft_plan* p) {
         p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
     }
 
-    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->interp_march) NUFFT_HIP(prepare_column_tasks());
+    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
+        hipDeviceProp_t prop;
+        NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
+        p->num_cus = prop.multiProcessorCount;
+        p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C);
+        if (!p->smarch.eligible) return fail(NUFFT_ERR_UNSUPPORTED, "marching-ring spreading: no decomposition for this device");
+        NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M));
+        const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_choice), 8 * sizeof(uint32_t)))) return rc;
+        NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 8 * sizeof(uint32_t)));
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, &p->d_smarch_tasks, (size_t)column_task_table_entries(p->smarch.ct, p->tile.nb[2]) * 8))) return rc;
+    }
+
+    if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->spread_method == NUFFT_SPREAD_MARCHING_RING || p->interp_march) NUFFT_HIP(prepare_column_tasks());
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
         hipEvent_t a, b;
@@ -592,6 +617,7 @@ static void release(nufft_plan* p) {
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
         fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks); fr(p->d_march_choice); fr(p->d_march_cols); fr(p->d_march_tasks);
+        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -951,6 +977,11 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->patch_dims[1] = patches ? p->patch.pby : 0;
     o->patch_f32acc = patches ? p->patch.f32acc : 0;
     o->patch_planar = patches ? p->patch.planar : 0;
+    const bool ring = p->spread_method == NUFFT_SPREAD_MARCHING_RING;
+    o->ring_column[0] = ring ? p->smarch.n1 : 0;
+    o->ring_column[1] = ring ? p->smarch.n2 : 0;
+    o->ring_segments = ring ? p->smarch.ct.nseg : 0;
+    o->reserved_info = 0;
     return NUFFT_OK;
 }
 
@@ -1063,6 +1094,16 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         NUFFT_HIP(launch_patch_tasks(s.g, pp, clo, chi, p->d_offsets, np, slots, advantage, p->d_patch_choice, p->bal.d_slots, p->d_patch_cols,
                                      p->d_patch_cols + ncols, static_cast<uint2*>(p->d_patch_tasks), stream));
     }
+    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
+        // tasks of the spreading ring for this point set, and whether it serves it (balance.hip): while the heaviest task stays
+        // within its measured advantage over the LDS tiles on uniform points (x 0.85 for what the estimate leaves out); an
+        // explicit request always takes the ring
+        double advantage = 0.85 * 1.3;
+        if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING) advantage = 0.0;
+        const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
+        NUFFT_HIP(launch_smarch_tasks(s.g, p->smarch, p->d_offsets, np, p->num_cus, advantage, p->d_smarch_choice, p->bal.d_slots, p->d_smarch_cols,
+                                      p->d_smarch_cols + ncols, static_cast<uint2*>(p->d_smarch_tasks), stream));
+    }
     if (p->interp_march) {
         // tasks of the interpolation ring for this point set, and whether it serves it (balance.hip).  What the ring saves
         // over interp_tile_kernel is grid traffic (halo 1.5x instead of 2.6x at m = 4, 3.75x instead of 12.5x at m = 8), which
@@ -1112,6 +1153,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
             check("patches", ct, p->d_patch_tasks, p->d_patch_choice);
         }
         if (p->interp_march) check("ring", p->march_ct, p->d_march_tasks, p->d_march_choice);
+        if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) check("spreading ring", p->smarch.ct, p->d_smarch_tasks, p->d_smarch_choice);
     }
     p->Np = np;
     p->counts_clean = np > 0;      // the scatter pass has cleared the histogram (no point, no scatter pass: cleared next time)
@@ -1123,13 +1165,14 @@ int nufft_spread_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
     if (rc) return rc;
     if (!engine_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
     *engine_out = NUFFT_SPREAD_LDS_TILES;
-    if (p->spread_method != NUFFT_SPREAD_MFMA_PATCHES) return NUFFT_OK;
+    if (p->spread_method != NUFFT_SPREAD_MFMA_PATCHES && p->spread_method != NUFFT_SPREAD_MARCHING_RING) return NUFFT_OK;
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t flag = 0;
-    NUFFT_HIP(hipMemcpyAsync(&flag, p->d_patch_choice + 2, sizeof(flag), hipMemcpyDeviceToHost, stream));
+    const uint32_t* src = p->spread_method == NUFFT_SPREAD_MFMA_PATCHES ? p->d_patch_choice : p->d_smarch_choice;
+    NUFFT_HIP(hipMemcpyAsync(&flag, src + 2, sizeof(flag), hipMemcpyDeviceToHost, stream));
     NUFFT_HIP(hipStreamSynchronize(stream));
-    *engine_out = flag ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
+    *engine_out = flag ? p->spread_method : NUFFT_SPREAD_LDS_TILES;
     return NUFFT_OK;
 }
 
@@ -1178,6 +1221,8 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
         NUFFT_HIP(launch_zero_split_tiles(p->dtype, a.g, p->D, p->is_complex, p->C, p->bal.d_nslices, p->d_us,
                                           p->grid_elems * (p->is_complex ? 2 : 1), stream));
     NUFFT_HIP(launch_spread(a, stream));
+    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING)
+        NUFFT_HIP(launch_spread_march(a, p->smarch, p->d_smarch_choice + 2, static_cast<const uint2*>(p->d_smarch_tasks), stream));
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         // values gathered into sorted order (per-point weights of the callback menu folded in), then the patches
         const uint32_t* enabled = p->d_patch_choice + 2;

@@ -7,6 +7,7 @@
 #include "tile_kernels.h"
 #include "patch_kernels.h"
 #include <algorithm>
+#include <vector>
 
 #include "march_kernels.h"
 #include "patch32_kernels.h"
@@ -59,6 +60,122 @@ ColumnTasks march_column_tasks(int dtype, int is_complex, int M, const Geom& g) 
     ct.chi = 0;
     ct.maxlen = n[2];           // layers the kernel's run tables hold (MarchCfg::kSegMax)
     return ct;
+}
+
+// ---- spreading on the z-marching LDS ring (smarch_kernels.h) -----------------------------------------------------------
+const void* smarch_kernel_f32r(int M, int* lds_bytes, int* n);
+const void* smarch_kernel_f32c(int M, int* lds_bytes, int* n);
+const void* smarch_kernel_f64r(int M, int* lds_bytes, int* n);
+const void* smarch_kernel_f64c(int M, int* lds_bytes, int* n);
+static const void* smarch_kernel(int dtype, int is_complex, int M, int* lds_bytes, int* n) {
+    if (M < 2 || M > 10) return nullptr;
+    if (dtype == NUFFT_F32) return is_complex ? smarch_kernel_f32c(M, lds_bytes, n) : smarch_kernel_f32r(M, lds_bytes, n);
+    return is_complex ? smarch_kernel_f64c(M, lds_bytes, n) : smarch_kernel_f64r(M, lds_bytes, n);
+}
+
+// Launch model of the ring: blocks go to the 8 XCDs round-robin and to the first free CU there, in launch order (task table
+// order through xcd_remap_chunked, component by component).  Returns the time of the last block in units of work.
+static double smarch_makespan(const std::vector<double>& task_work, int C, int cus, int xcd_chunk) {
+    const int nt = (int)task_work.size(), per = std::max(1, cus / 8);
+    double mk = 0.0;
+    std::vector<double> heap;
+    for (int x = 0; x < 8; ++x) {
+        heap.assign((size_t)per, 0.0);
+        auto cmp = [](double u, double v) { return u > v; };
+        for (int c = 0; c < C; ++c)
+            for (int b = x; b < nt; b += 8) {
+                int t = b;
+                if (xcd_chunk > 0) {
+                    const int group = 8 * xcd_chunk, full = nt / group * group;
+                    if (b < full) { const int k = b >> 3; t = ((k / xcd_chunk) * 8 + (b & 7)) * xcd_chunk + k % xcd_chunk; }
+                } else {
+                    const int q = nt >> 3, r = nt & 7, k = b >> 3, xc = b & 7;
+                    t = ((xc < r) ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + k;
+                }
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                heap.back() += task_work[(size_t)t];
+                std::push_heap(heap.begin(), heap.end(), cmp);
+            }
+        for (double h : heap) mk = std::max(mk, h);
+    }
+    return mk;
+}
+
+// Column and segments for this grid: the compile-time column bounds the LDS ring; within it the plan takes the column
+// (multiples of the bin edge) and the number of segments along z that minimise  point visits / chip utilisation,
+// where visits = prod (n + 2M - 1) / n over x, y (partial last columns counted) x (segl + c_z) / segl for the layers a
+// segment visits beyond its own, and the utilisation comes from the launch model above.
+SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C) {
+    SMarchPlan sp{};
+    int lds = 0, n[5];
+    if (D != 3 || other || !smarch_kernel(dtype, is_complex, M, &lds, n)) return sp;
+    for (int d = 0; d < 3; ++d)
+        if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return sp;
+    const int L = 2 * M, hlo = n[2], hhi = n[3];
+    // columns shorter than the axis (a stencil then never reaches a column from both sides); enough layers for the halo
+    if (8 + L - 1 > g.Nover[0] || 8 + L - 1 > g.Nover[1] || g.nb[2] < 2 * (hlo + hhi) || g.nb[2] > 2048) return sp;
+    static const int xcd_chunk = [] { const char* e = std::getenv("NUFFT_XCD_CHUNK"); return e && *e ? std::atoi(e) : 8; }();
+    static const int force_n1 = [] { const char* e = std::getenv("NUFFT_SMARCH_N1"); return e && *e ? std::atoi(e) : 0; }();
+    static const int force_n2 = [] { const char* e = std::getenv("NUFFT_SMARCH_N2"); return e && *e ? std::atoi(e) : 0; }();
+    static const int force_nseg = [] { const char* e = std::getenv("NUFFT_SMARCH_NSEG"); return e && *e ? std::atoi(e) : 0; }();
+    const double cz = 0.5 * (hlo + hhi);               // a halo layer's points are visited, but add about half their planes
+    const double fixed = 0.15;                         // per task, in layers: ring zero fill, first table, launch
+    double best = 1e300;
+    std::vector<double> work;
+    for (int n2 = n[1]; n2 >= 8; n2 -= 4) {
+        if (force_n2 && n2 != force_n2) continue;
+        if (n2 + L - 1 > g.Nover[1] || (n2 < n[1] / 2 && n2 + 4 + L - 1 <= g.Nover[1] && !force_n2)) continue;
+        for (int n1 = n[0]; n1 >= 8; n1 -= 4) {
+            if (force_n1 && n1 != force_n1) continue;
+            if (n1 + L - 1 > g.Nover[0] || (n1 < n[0] / 2 && n1 + 4 + L - 1 <= g.Nover[0] && !force_n1)) continue;
+            const int ncx = (g.Nover[0] + n1 - 1) / n1, ncy = (g.Nover[1] + n2 - 1) / n2;
+            if ((int64_t)ncx * ncy >= 65536) continue;
+            // relative cost of a layer of each column: the points it visits
+            std::vector<double> colw((size_t)ncx * ncy);
+            double ideal = 0.0;
+            for (int ty = 0; ty < ncy; ++ty)
+                for (int tx = 0; tx < ncx; ++tx) {
+                    const int e1 = std::min(n1, g.Nover[0] - tx * n1), e2 = std::min(n2, g.Nover[1] - ty * n2);
+                    colw[(size_t)ty * ncx + tx] = (double)(e1 + L - 1) * (double)(e2 + L - 1);
+                    ideal += (double)e1 * (double)e2;
+                }
+            ideal *= (double)g.nb[2] * C / cus;         // every point visited once, the chip evenly busy
+            const int max_seg = std::max(1, g.nb[2] / 4);
+            for (int nseg = 1; nseg <= std::min(max_seg, 64); ++nseg) {
+                if (force_nseg && nseg != force_nseg) continue;
+                const int segl = (g.nb[2] + nseg - 1) / nseg, ns = (g.nb[2] + segl - 1) / segl;
+                if (ns != nseg && !force_nseg) continue;
+                work.clear();
+                for (int k = 0; k < ns; ++k) {
+                    const int len = std::min(segl, g.nb[2] - k * segl);
+                    for (double w : colw) work.push_back(w * (len + cz + fixed));
+                }
+                const double cost = smarch_makespan(work, C, cus, xcd_chunk) / ideal;
+                if (cost < best) {
+                    best = cost;
+                    sp.n1 = n1; sp.n2 = n2;
+                    sp.ct = ColumnTasks{ncx, ncy, n1 / 4, n2 / 4, ns, segl, ncx * ncy * ns, 1, -hhi, hlo, 0};
+                    double vis = 0.0;
+                    for (double w : colw) vis += w;
+                    sp.visits = vis / ((double)g.Nover[0] * g.Nover[1]);
+                    sp.efficiency = sp.visits / cost;
+                }
+            }
+        }
+    }
+    if (best >= 1e300) return sp;
+    sp.hlo = hlo; sp.hhi = hhi;
+    sp.lds_bytes = lds;
+    sp.threads = n[4];
+    sp.eligible = true;
+    return sp;
+}
+
+hipError_t prepare_spread_march(int dtype, int is_complex, int M) {
+    int lds = 0, n[5];
+    const void* fn = smarch_kernel(dtype, is_complex, M, &lds, n);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 const void* spread_kernel_f32r(int D, int M, bool flag, bool other);
@@ -423,6 +540,34 @@ hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np
     if (C == 3) return dtype == NUFFT_F32 ? gather_planar_t<float, 3>(D, sorted, np, vin, weights, vout, enabled, stream)
                                           : gather_planar_t<double, 3>(D, sorted, np, vin, weights, vout, enabled, stream);
     return hipErrorInvalidValue;
+}
+
+template <typename T>
+static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
+    int lds = 0, n[5];
+    const void* fn = smarch_kernel(a.dtype, a.is_complex, a.M, &lds, n);
+    if (!fn) return hipErrorInvalidValue;
+    for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
+        const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
+        TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
+        MarchGeom mg{};
+        mg.ntx = sp.ct.ncolx;
+        mg.nty = sp.ct.ncoly;
+        mg.nseg = sp.ct.nseg;
+        mg.segl = sp.ct.segl;
+        mg.ntasks = column_task_table_entries(sp.ct, a.g.nb[2]);
+        mg.flag = flag;
+        mg.tasktab = tasktab;
+        mg.n1 = sp.n1;
+        mg.n2 = sp.n2;
+        void* params[] = {&k, &mg};
+        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)n[4], 1, 1), params, (size_t)lds, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_smarch_t<float>(a, sp, flag, tasktab, stream) : launch_smarch_t<double>(a, sp, flag, tasktab, stream);
 }
 
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream) {

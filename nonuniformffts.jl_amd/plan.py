@@ -33,7 +33,7 @@ class DimensionMismatch(ValueError):
 
 # ---- small value types of the reference's API (src/Kernels/Kernels.jl:8-46) -------------------
 #: spreading engines of the library (include/nufft_mi355x.h NUFFT_SPREAD_*)
-_SPREAD_METHODS = {"auto": 0, "lds_tiles": 1, "mfma_patches": 2}
+_SPREAD_METHODS = {"auto": 0, "lds_tiles": 1, "mfma_patches": 2, "marching_ring": 3}
 
 
 @dataclass(frozen=True)
@@ -318,7 +318,7 @@ class PlanNUFFT:
         patch engine decide per point set on the device; this reads the decision back and synchronises)."""
         out = C.c_int(0)
         _check(lib.nufft_spread_engine_used(self._handle, C.byref(out), self._stream()))
-        return {1: "lds_tiles", 2: "mfma_patches"}[out.value]
+        return {1: "lds_tiles", 2: "mfma_patches", 3: "marching_ring"}[out.value]
 
     def interp_engine_used(self) -> str:
         """Engine that interpolates the point set of the last set_points in exec_type2: "lds_tiles" or "marching_ring"

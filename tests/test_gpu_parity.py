@@ -497,6 +497,74 @@ def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
     assert _rel(out2.cpu().numpy(), ref) < _rtol(Z)
 
 
+def _spread_ring_fits(Z, M):
+    """SMarchCfg::FITS (smarch_kernels.h): a column of at least 4 x 4 cells x (2M + 3) planes of Float64 beside the strips."""
+    nc = 2 if np.dtype(Z).kind == "c" else 1
+    rb = 4 if np.dtype(Z) in (np.dtype(np.float32), np.dtype(np.complex64)) else 8
+    L = 2 * M
+    G = 1
+    while G < nc * L:
+        G *= 2
+    strip = -(-((64 // G) * 3 * L * rb) // 16) * 16
+    fixed = 2 * (64 * 8 + 64 * 4) + 64 * 8 + 64 + 16 * strip
+    rs = nc * 4
+    if nc * L < 16:
+        while rs % 16 != (nc * L) % 16:
+            rs += 1
+    return rs * 4 * (L + 3) * 8 + fixed <= 163840 - 256
+
+
+@pytest.mark.parametrize("M", range(2, 11))
+@pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
+def test_spreading_ring_every_instantiation(Z, M):
+    """Every (element type, M) instantiation of spread_march_kernel against the oracle (type 1, both window evaluations), the
+    ring requested explicitly and nufft_spread_engine_used confirming the device-side flag.  Oversampled grid 96 x 80 x 112:
+    partial columns at the upper ends of dimensions 1 and 2, columns at the periodic boundary (two runs per row of bins),
+    several segments along dimension 3 (first / last layers clip along z, the others take the per-slot code); a point set
+    concentrated in a corner exercises the tasks of equal point count (quantile segments, empty tasks that only store zeros)."""
+    dims, Np = (48, 40, 56), 4000
+    for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
+        if not _spread_ring_fits(Z, M):
+            with pytest.raises(Exception):
+                _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M, spread_method="marching_ring")
+            return
+        nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M, spread_method="marching_ring")
+        assert plan.info().spread_method == 3 and plan.info().ring_column[0] > 0
+        dev = plan.device
+        for name in ("uniform", "corner"):
+            pts = xs if name == "uniform" else tuple((0.3 * x * x / (2 * np.pi)).astype(x.dtype) for x in xs)
+            nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
+            O.set_points(oplan, pts)
+            u = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+            nufft.exec_type1(u, plan, torch.from_numpy(vs[0]).to(dev))
+            assert plan.spread_engine_used() == "marching_ring", (name, evalmode)
+            ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs)[0])
+            assert _rel(u.cpu().numpy(), ref) < _rtol(Z), (name, evalmode)
+
+
+@pytest.mark.parametrize("Z,C", [(np.float64, 1), (np.float64, 3), (np.float32, 2), (np.complex128, 1)])
+def test_spreading_ring_automatic_choice_and_fallback(Z, C):
+    """Automatic engine choice on a grid with enough columns for the chip (256 x 256 x 64 oversampled): real plans at M = 4
+    take the ring for a uniform point set and hand a point set concentrated in one corner to the LDS tiles (device-side
+    decision, read back); both against the oracle.  Complex plans keep their engine."""
+    dims, Np = (128, 128, 32), 60000
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, 4, 2.0, O.FAST_APPROXIMATION, C, Np, seed=77)
+    dev = plan.device
+    is_ring = plan.info().spread_method == 3
+    assert is_ring == (np.dtype(Z).kind != "c")
+    for name in ("uniform", "corner"):
+        pts = xs if name == "uniform" else tuple((0.05 * x).astype(x.dtype) for x in xs)
+        nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
+        O.set_points(oplan, pts)
+        us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+        nufft.exec_type1(us if C > 1 else us[0], plan, tuple(torch.from_numpy(v).to(dev) for v in vs) if C > 1 else torch.from_numpy(vs[0]).to(dev))
+        if is_ring:
+            assert plan.spread_engine_used() == ("marching_ring" if name == "uniform" else "lds_tiles"), name
+        ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs) if C > 1 else _oracle_inputs(oplan, vs)[0])
+        for c in range(C):
+            assert _rel(us[c].cpu().numpy(), ref[c] if C > 1 else ref) < _rtol(Z), (name, c)
+
+
 @pytest.mark.parametrize("Z,M", [(np.float64, 4), (np.complex64, 8), (np.float32, 6), (np.complex128, 5), (np.float64, 8)])
 def test_tasks_of_equal_point_count_on_nonuniform_sets(Z, M, monkeypatch):
     """Patch engine and interpolation ring on point sets far from uniform (set_points cuts their columns into segments of
