@@ -1,22 +1,28 @@
-// Type-1 spreading on a z-marching LDS ring (gfx950, wave64): the third spreading engine.
+// Type-1 spreading on a z-marching LDS window (gfx950, wave64): the third spreading engine.
 //
 // Replaces spread_from_points_shmem_kernel! (reference src/spreading/gpu.jl:237-377, flush :381-434) and the zero fill in
 // front of it (src/NonuniformFFTs.jl:161-167) for 3-D plans, with the same arithmetic per point.  spread_tile_kernel holds
 // the interior of a box in LDS and visits every point within M cells of it: 2.08 visits per point at C2 (24 x 28 x 24),
 // each with its own window evaluation, scalar clipping control per stencil plane and LDS round trips.  Here a workgroup
 // owns a COLUMN of the grid — n1 x n2 cells in x, y, interior only (output-driven as before: no halo in LDS, no global
-// atomics, every cell written once) — and marches along z through a segment of bin layers.  LDS holds a ring of
-// RZ = 2M - 1 + 4 planes: exactly the planes the stencils of one bin layer (4 planes of cells) can touch.  After a layer
-// the 4 oldest planes are complete: they leave with coalesced stores, are zeroed, and become the 4 newest.  Points are
-// clipped in x and y only (C2: 40 x 36 column, 1.42 visits per point); along z a stencil always lies inside the ring, so
-// its 2M planes are added with immediate offsets from per-slot code (switch on the ring slot of the first plane: no
-// per-plane control).  Only the first and last layers of a segment clip along z (planes that belong to the neighbouring
-// segments).
+// atomics, every cell written once) — and marches along z through a segment of bin layers.  LDS holds a window of
+// RZ = 2M - 1 + 4 planes: exactly the planes the stencils of one bin layer (4 planes of cells) can touch, plane k of the
+// window in slot k.  After a layer the 4 lowest planes are complete: they leave with coalesced stores, the other 2M - 1
+// move down four slots and the top four are zeroed (one pass of the workgroup over its LDS, ~3 % of a layer's time).
+// Because the window never rotates, the slot of a stencil's first plane is just (cell_z mod 4): it is folded into the
+// point's LDS offset, and the 2M planes of a point are added with immediate offsets from that one address — no per-plane
+// or per-slot control flow at all.  Points are clipped in x and y only (C2: 32 x 32 column, 1.49 visits per point); only
+// the first and last layers of a segment clip along z (planes that belong to the neighbouring segments).
 //
 // Points: the bins of a layer that can touch the column are runs of the bin-sorted array (one per row of bins, two where
-// the column sits at the periodic boundary in x); a wave pulls chunks of PPW points from an LDS counter, the next chunk's
-// records in flight behind the current one.  Window evaluation (group mapping) and accumulation (face mapping, one point
-// per wave instruction, ds_add_f64 on conflict-free rows) are those of spread_tile_kernel.
+// the column sits at the periodic boundary in x).  Every wave keeps the runs of the current layer in registers (one run
+// per lane, the next layer's bounds in flight) and takes the chunks wave, wave + 16, ... of the layer: no shared counter,
+// no LDS table; the next chunk's records are requested before the current one is processed.  Window evaluation (group
+// mapping) and accumulation (face mapping, one point per wave instruction, ds_add_f64 on conflict-free rows) are those
+// of spread_tile_kernel.  For real data at M = 4 (the 8 x 8 face is exactly one wave) the point's value is folded into its
+// dimension-1 window values, and its clipping mask — an EXEC mask, computed for the eight points of a chunk at once by
+// their group lanes — and LDS offset reach the accumulation as three v_readlane: 22 vector and ~8 scalar instructions
+// per point visit besides the eight atomics.
 //
 // Tasks: column x segment of bin layers from the table set_points builds per point set on the device (balance.hip):
 // equal-length segments for uniform sets, column quantiles otherwise; point sets whose heaviest task would hold the chip
@@ -36,14 +42,14 @@
 namespace nufft {
 
 #ifndef NUFFT_SMARCH_ABL
-#define NUFFT_SMARCH_ABL 0          // ablation builds: 1 = no LDS atomics, 2 = no point visits, 3 = no retire stores
+#define NUFFT_SMARCH_ABL 0          // ablation builds: 1 = no LDS atomics, 2 = no point visits, 3 = no retire stores, 4 = no shift
 #endif
 
 template <typename T, bool CPLX, int M>
 struct SMarchCfg {
     static constexpr int NC = CPLX ? 2 : 1;
     static constexpr int L = 2 * M;
-    static constexpr int RZ = L + 3;                    // ring depth: the planes one bin layer's stencils can touch
+    static constexpr int RZ = L + 3;                    // window depth: the planes one bin layer's stencils can touch
     static constexpr int HLO = (M + 3) / 4;             // layers of points below a segment whose stencils reach into it
     static constexpr int HHI = 1 + (M - 2) / 4;         // ... and above it
     static constexpr int THREADS = 1024;
@@ -51,11 +57,11 @@ struct SMarchCfg {
     using GP = Grp<NC, M>;
     static constexpr int FACE = GP::W1 * L;             // (component, j1, j2) elements of a stencil face
     static constexpr int NPASS = (FACE + kWave - 1) / kWave;
-    static constexpr int kMaxRuns = 64;                 // runs of the sorted array per layer (rows of bins x 2)
+    static constexpr int kMaxRuns = 64;                 // runs of the sorted array per layer (rows of bins x 2): one per lane
+    // real data, M = 4: the face is one wave (8 x 8 lanes); masks and offsets come from the group lanes
+    static constexpr bool FAST = !CPLX && M == 4;
     static constexpr int strip_bytes() { return round_up(GP::PPW * 3 * L * (int)sizeof(T), 16); }
-    // per layer, double-buffered: runs (uint2), cumulative chunk counts (uint32); then counters
-    static constexpr int table_bytes() { return 2 * (kMaxRuns * 8 + kMaxRuns * 4) + kMaxRuns * 8 + 64; }
-    static constexpr int fixed_bytes() { return table_bytes() + NW * strip_bytes(); }
+    static constexpr int fixed_bytes() { return NW * strip_bytes() + 64; }
     static constexpr int row_stride(int n1) { return padded_row_stride(NC * n1, NC * L, 8); }
     struct Dims { int n1, n2; };
     static constexpr int bin_rows(int n) { return tile_bin_rows_bound(true, n, 4, M); }
@@ -87,38 +93,37 @@ struct SMarchCfg {
     static constexpr int PSB = PS * 8;                      // ... in bytes
     static constexpr int RING_BYTES = round_up(RZ * PSB, 16);
     static constexpr int lds_bytes() { return RING_BYTES + fixed_bytes(); }
-    // immediate-offset atomics: KB planes per base address (16-bit offsets), NB bases cover the ring
-    static constexpr int KB = 65535 / PSB + 1;
-    static constexpr int NB = (RZ + KB - 1) / KB;
-    // per-slot code for the 2M planes of a point: RZ cases x NPASS x 2M atomics — only where that stays small
-    static constexpr bool SLOTSW = RZ * NPASS * L <= 400 && NB <= 4;
+    // immediate-offset atomics: PLB planes per base address (16-bit offsets), NBASE bases cover a stencil's 2M planes
+    static constexpr int PLB0 = 65535 / PSB + 1;
+    static constexpr int PLB = PLB0 < 4 ? PLB0 : PLB0 / 4 * 4;
+    static constexpr int NBASE = (L + PLB - 1) / PLB;
 };
 
-// the L planes of a point whose first plane sits in ring slot S: plane J in slot (S + J) % RZ, as an immediate offset
-// from the lane's address in the first slot of that slot's base group
-template <typename C, int S, typename T, int... J>
-__device__ __forceinline__ void smarch_add_planes(const uint32_t (&vb)[C::NB], T w, const T (&w3)[C::L], std::integer_sequence<int, J...>) {
-    (lds_add_imm<(((S + J) % C::RZ) % C::KB) * C::PSB>(vb[((S + J) % C::RZ) / C::KB], (double)(w * w3[J])), ...);
+// the L planes of a point from the lane's address in the point's first slot: plane J at J * PSB — as an immediate offset
+// from the base of its group of PLB planes.  CLIPZ: only the planes of the bit mask (first / last layers of a segment).
+template <typename C, bool CLIPZ, int J, typename T>
+__device__ __forceinline__ void smarch_add_plane(const uint32_t (&vb)[C::NBASE], T w, const T (&w3)[C::L], unsigned planes) {
+#if NUFFT_SMARCH_ABL == 1
+    const double v = (double)(w * w3[J]);
+    asm volatile("" ::"v"(vb[J / C::PLB]), "v"(v));
+#else
+    if (!CLIPZ || (planes & (1u << J))) lds_add_imm<(J % C::PLB) * C::PSB>(vb[J / C::PLB], (double)(w * w3[J]));
+#endif
 }
-// binary dispatch on the (wave-uniform) slot
-template <typename C, int LO, int HI, typename T>
-__device__ __forceinline__ void smarch_slot_dispatch(int slot, const uint32_t (&vb)[C::NB], T w, const T (&w3)[C::L]) {
-    if constexpr (HI - LO == 1) {
-        smarch_add_planes<C, LO>(vb, w, w3, std::make_integer_sequence<int, C::L>{});
-    } else {
-        constexpr int MID = (LO + HI) / 2;
-        if (slot < MID) smarch_slot_dispatch<C, LO, MID>(slot, vb, w, w3);
-        else smarch_slot_dispatch<C, MID, HI>(slot, vb, w, w3);
-    }
+template <typename C, bool CLIPZ, typename T, int... J>
+__device__ __forceinline__ void smarch_add_planes(const uint32_t (&vb)[C::NBASE], T w, const T (&w3)[C::L], unsigned planes,
+                                                  std::integer_sequence<int, J...>) {
+    (smarch_add_plane<C, CLIPZ, J>(vb, w, w3, planes), ...);
 }
 
-template <typename T, bool CPLX, int M>
+template <typename T, bool CPLX, int M, bool POLY>
 __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, MarchGeom mg) {
     using C = SMarchCfg<T, CPLX, M>;
     using GP = typename C::GP;
-    constexpr int NC = C::NC, L = C::L, RZ = C::RZ, RS = C::RS, PS = C::PS, PSB = C::PSB, N1 = C::N1, N2 = C::N2;
-    constexpr int NPASS = C::NPASS, FACE = C::FACE, PPW = GP::PPW, HLO = C::HLO, HHI = C::HHI, THREADS = C::THREADS;
-    constexpr int kMaxRuns = C::kMaxRuns;
+    using WE = WindowEval<T, C::NC, 3, M, GP::G, false>;
+    constexpr int NC = C::NC, L = C::L, RZ = C::RZ, RS = C::RS, PS = C::PS, PSB = C::PSB;
+    constexpr int NPASS = C::NPASS, FACE = C::FACE, PPW = GP::PPW, HLO = C::HLO, HHI = C::HHI, THREADS = C::THREADS, NW = C::NW;
+    constexpr bool FAST = C::FAST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     if (*mg.flag == 0u) return;                         // spread_tile_kernel serves this point set
@@ -140,64 +145,46 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
 
     double* ring = reinterpret_cast<double*>(smem);
     const uint32_t ring_base = (uint32_t)(uintptr_t)ring;
-    uint2* runs_tab = reinterpret_cast<uint2*>(smem + C::RING_BYTES);                               // [2][kMaxRuns]
-    uint32_t* cum_tab = reinterpret_cast<uint32_t*>(smem + C::RING_BYTES + 2 * kMaxRuns * 8);        // [2][kMaxRuns] inclusive chunk counts
-    uint2* run_bins = reinterpret_cast<uint2*>(smem + C::RING_BYTES + 2 * (kMaxRuns * 8 + kMaxRuns * 4));   // [kMaxRuns] {first bin within a layer, bins}
-    int* counter = reinterpret_cast<int*>(smem + C::RING_BYTES + 2 * (kMaxRuns * 8 + kMaxRuns * 4) + kMaxRuns * 8); // [0] chunk counter, [2], [3]: chunks of the layer per buffer
-    T* strip_wave = reinterpret_cast<T*>(smem + C::RING_BYTES + C::table_bytes() + wave * C::strip_bytes());
+    T* strip_wave = reinterpret_cast<T*>(smem + C::RING_BYTES + wave * C::strip_bytes());
 
-    // ---- bins whose points can touch the column: rows of bins along y, one or two runs along x.  Their first bin (within
-    //      a layer of bins) and length go to an LDS table once; wave 0 turns them into runs of the sorted array per layer ----
-    int nruns;
+    // ---- bins whose points can touch the column: rows of bins along y, one or two runs along x; lane i keeps run i:
+    //      its first bin within a layer of bins and its length (lanes >= nruns: an empty run) ----
+    uint32_t rb_bin = 0u, rb_len = 0u;
     {
         const BinSegs seg0 = bin_segments(org1 - M, org1 + neff1 + M - 1, g.Nover[0], 2, g.nb[0]);
         const BinSegs seg1 = bin_segments(org2 - M, org2 + neff2 + M - 1, g.Nover[1], 2, g.nb[1]);
-        nruns = seg1.total() * seg0.n;                  // <= kMaxRuns (SMarchCfg::search)
-        if (tid < kMaxRuns) {
-            uint2 d = make_uint2(0u, 0u);
-            if (tid < nruns) {
-                const int sg = tid % seg0.n, r2 = tid / seg0.n;
-                d = make_uint2((uint32_t)(seg1.bin(r2) * g.nb[0] + (sg ? seg0.lo[1] : seg0.lo[0])), (uint32_t)(sg ? seg0.len[1] : seg0.len[0]));
-            }
-            run_bins[tid] = d;
+        const int nruns = seg1.total() * seg0.n;        // <= kMaxRuns (SMarchCfg::search)
+        if (lane < nruns) {
+            const int sg = lane % seg0.n, r2 = lane / seg0.n;
+            rb_bin = (uint32_t)(seg1.bin(r2) * g.nb[0] + (sg ? seg0.lo[1] : seg0.lo[0]));
+            rb_len = (uint32_t)(sg ? seg0.len[1] : seg0.len[0]);
         }
     }
-    // table of layer `li` into buffer `buf` (wave 0, all 64 lanes): runs, inclusive chunk counts, their total
-    auto write_table = [&](int li, int buf) __attribute__((always_inline)) {
+    // bounds of the lane's run in layer `li` of the task
+    auto load_run = [&](int li, uint32_t& r0, uint32_t& r1) __attribute__((always_inline)) {
         int lay = zb0 - HLO + li;
         if (lay < 0) lay += g.nb[2];
         if (lay >= g.nb[2]) lay -= g.nb[2];
-        const uint2 d = run_bins[lane];
-        const int64_t bin0 = (int64_t)lay * g.nb[1] * g.nb[0] + d.x;
-        const uint2 pr = make_uint2(a.offsets[bin0], a.offsets[bin0 + d.y]);      // (lanes >= nruns: an empty run)
-        const uint32_t ch = (pr.y - pr.x + PPW - 1) / PPW;
-        uint32_t incl = ch;
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += v;
-        }
-        runs_tab[buf * kMaxRuns + lane] = pr;
-        cum_tab[buf * kMaxRuns + lane] = incl;
-        if (lane == kWave - 1) counter[2 + buf] = (int)incl;
+        const uint32_t* o = a.offsets + ((int64_t)lay * g.nb[1] * g.nb[0] + rb_bin);
+        r0 = o[0];
+        r1 = o[rb_len];
     };
 
-    // ---- zero the ring, table of the first layer ----
+    // ---- zero the window ----
     {
         typedef double D2 __attribute__((ext_vector_type(2)));
         D2* r2p = reinterpret_cast<D2*>(ring);
         for (int i = tid; i < RZ * PS / 2; i += THREADS) r2p[i] = D2{0.0, 0.0};
     }
-    __syncthreads();
-    if (wave == 0) {
-        write_table(0, 0);
-        if (lane == 0) counter[0] = 0;
-    }
+    uint32_t nx0, nx1;
+    load_run(0, nx0, nx1);
 
-    // evaluation roles
+    // evaluation roles (the instantiation fixes the evaluation mode)
+    const EvalArgs<T, POLY ? NUFFT_EVAL_FAST_APPROXIMATION : NUFFT_EVAL_DIRECT> am(a);
     const int grp = lane / GP::G, q = lane % GP::G;
     T* strip = strip_wave + grp * (3 * L);
-    WindowEval<T, NC, 3, M, GP::G, false> we;
-    we.init(a, q);
+    WE we;
+    we.init(am, q);
     // accumulation roles
     int j1f[NPASS], j2f[NPASS], cmpf[NPASS];
     bool actf[NPASS];
@@ -217,29 +204,36 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     T* grid = a.grid[comp_id];
     __syncthreads();
 
-    int pm = 0;                                         // ring slot of the first plane of the current layer's window
     for (int li = 0; li < nli; ++li) {
-        const int buf = li & 1;
-        // wave 0: the runs of the next layer (its two loads cost one wave a microsecond per layer)
-        if (wave == 0 && li + 1 < nli) write_table(li + 1, buf ^ 1);
-
-        const int nchunks = counter[2 + buf];
+        // ---- the runs of this layer (requested a layer ago): chunks per run, inclusive scan over the lanes ----
+        const uint32_t p0_l = nx0, p1_l = nx1;
+        uint32_t cum_l = (p1_l - p0_l + PPW - 1) / PPW;
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t v = __shfl_up(cum_l, o, kWave);
+            if (lane >= o) cum_l += v;
+        }
+        if (li + 1 < nli) load_run(li + 1, nx0, nx1);
+        const int nchunks = __builtin_amdgcn_readlane((int)cum_l, kWave - 1);
         const int wq = 4 * (li - HLO) - (M - 1);        // first plane of the layer's window (in owned-plane coordinates)
         const bool clipz = wq < 0 || wq + RZ > nq;      // planes of this window belong to other segments
 
         auto lookup = [&](int item, uint32_t& p0, uint32_t& p1) __attribute__((always_inline)) {
-            const uint32_t cum_l = cum_tab[buf * kMaxRuns + lane];  // inclusive chunk counts (lanes >= nruns: the total)
             const unsigned long long mk = __ballot((uint32_t)item < cum_l);
             const int i = (int)__builtin_ctzll(mk);
             const uint32_t before = i ? (uint32_t)__builtin_amdgcn_readlane((int)cum_l, i - 1) : 0u;
-            const uint2 run = runs_tab[buf * kMaxRuns + i];
-            p0 = run.x + ((uint32_t)item - before) * PPW;
-            p1 = run.y;
+            p0 = (uint32_t)__builtin_amdgcn_readlane((int)p0_l, i) + ((uint32_t)item - before) * PPW;
+            p1 = (uint32_t)__builtin_amdgcn_readlane((int)p1_l, i);
         };
-        auto pull = [&]() __attribute__((always_inline)) -> int {
-            int item = 0;
-            if (lane == 0) item = atomicAdd(counter, 1);
-            return __builtin_amdgcn_readfirstlane(item);
+        auto value_of = [&](const PointRec<T, 3>& r) __attribute__((always_inline)) -> T {
+            T v = T(0);
+            if (FAST || q < NC) {                       // (FAST: every lane of the group holds the point's value)
+#if NUFFT_SMARCH_ABL == 6
+                return T(r.idx);
+#endif
+                v = vin[(int64_t)r.idx * NC + (FAST ? 0 : q)];
+                if (a.weights) v *= a.weights[r.idx];   // callbacks.nonuniform(v, n), src/spreading/gpu.jl:289
+            }
+            return v;
         };
 
         // one chunk of up to PPW points
@@ -261,25 +255,35 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             }
             const int c3 = cell_of(rec.r[2], g.Nover[2]);
             X[2] = rec.r[2] - T(c3);
-            const int dz = c3 & 3;
-            int slot3 = pm + dz;                        // ring slot of the first stencil plane
-            if (slot3 >= RZ) slot3 -= RZ;
+            const int dz = c3 & 3;                      // slot of the first stencil plane
             const int q0 = wq + dz;                     // its plane (owned-plane coordinates)
             if constexpr (CLIPZ) ok = ok && (q0 + L - 1 >= 0) && (q0 < nq);
             const unsigned long long okmask = __ballot(ok);
             if (okmask == 0ull) return;                 // nothing of this chunk touches the column
+            // the point's LDS offset: stencil start in x, y and the slot of its first plane
+            const uint32_t soff = (uint32_t)((s[0] * NC + s[1] * RS + dz * PS) * 8);
+            unsigned long long lmask = 0ull;            // FAST: lanes (j1, j2) of the 8 x 8 face inside the column
+            if constexpr (FAST) {
+                const int lo1 = min(L, max(0, -s[0])), hi1 = max(lo1, min(L, neff1 - s[0]));    // (a point that misses the column: empty ranges)
+                const int lo2 = min(L, max(0, -s[1])), hi2 = max(lo2, min(L, neff2 - s[1]));
+                const uint32_t m1 = ((1u << hi1) - 1u) & ~((1u << lo1) - 1u);
+                const uint32_t col = m1 * 0x01010101u;
+                const unsigned long long rows = hi2 > lo2 ? (~0ull >> (64 - 8 * (hi2 - lo2))) << (8 * lo2) : 0ull;
+                lmask = ok ? (rows & (((unsigned long long)col << 32) | col)) : 0ull;
+            }
+            T wv[WE::NSLOT];
+            we.eval_regs(am, X, wv);
+            if constexpr (FAST) wv[0] *= vmine;         // slot 0 = dimension 1 (G = L = 8): the value rides on w1
             wave_lds_fence();
-            we.template eval_to_strip<0>(a, X, strip, q);
+#pragma unroll
+            for (int sl = 0; sl < WE::NSLOT; ++sl)
+                if (we.has[sl]) strip[q + sl * GP::G] = wv[sl];
             wave_lds_fence();
 #if NUFFT_SMARCH_ABL != 2
             auto do_point = [&](int gi, const T (&w1v)[NPASS], const T (&w2v)[NPASS], T w3a) __attribute__((always_inline)) {
                 const int src = gi * GP::G;             // first lane of the point's group
                 if (!((okmask >> src) & 1ull)) return;
-                const int S1 = __builtin_amdgcn_readlane(s[0], src);
-                const int S2 = __builtin_amdgcn_readlane(s[1], src);
-                const int SL = __builtin_amdgcn_readlane(slot3, src);
-                const T Vre = readlane_t(vmine, src);
-                const T Vim = CPLX ? readlane_t(vmine, src + (CPLX ? 1 : 0)) : T(0);
+                const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)soff, src);
                 const T* sp = strip_wave + gi * (3 * L);
                 T w3[L];
                 {
@@ -292,35 +296,35 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                         for (int j = 0; j < L; ++j) w3[j] = j < 16 ? row_bcast(w3a, j) : row_bcast(w3b, j - 16);
                     }
                 }
-                const uint32_t soff = (uint32_t)((S1 * NC + S2 * RS) * 8);
                 unsigned planes = (1u << L) - 1u;
                 if constexpr (CLIPZ) {
                     const int Q0 = __builtin_amdgcn_readlane(q0, src);
                     const int lo3 = max(0, -Q0), hi3 = min(L, nq - Q0);
                     planes = ((1u << hi3) - 1u) & ~((1u << lo3) - 1u);
                 }
+                if constexpr (FAST) {
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lmask, src);
+                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(lmask >> 32), src);
+                    const T w = w1v[0] * w2v[0];
+                    uint32_t vb[C::NBASE];
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    const int l1 = S1 + j1f[ps], l2 = S2 + j2f[ps];
-                    const bool lane_ok = actf[ps] && (unsigned)l1 < (unsigned)neff1 && (unsigned)l2 < (unsigned)neff2;
-                    const T w = w1v[ps] * (CPLX ? (cmpf[ps] ? Vim : Vre) : Vre) * w2v[ps];
-                    const uint32_t v0 = lane_addr[ps] + soff;       // the lane's element in slot 0
-                    if (lane_ok) {
-                        if constexpr (!CLIPZ && C::SLOTSW) {
-                            uint32_t vb[C::NB];
+                    for (int b = 0; b < C::NBASE; ++b) vb[b] = lane_addr[0] + so + (uint32_t)(b * C::PLB * PSB);
+                    if (__builtin_amdgcn_inverse_ballot_w64(((unsigned long long)mhi << 32) | mlo))
+                        smarch_add_planes<C, CLIPZ>(vb, w, w3, planes, std::make_integer_sequence<int, L>{});
+                } else {
+                    const int S1 = __builtin_amdgcn_readlane(s[0], src);
+                    const int S2 = __builtin_amdgcn_readlane(s[1], src);
+                    const T Vre = readlane_t(vmine, src);
+                    const T Vim = CPLX ? readlane_t(vmine, src + (CPLX ? 1 : 0)) : T(0);
 #pragma unroll
-                            for (int b = 0; b < C::NB; ++b) vb[b] = v0 + (uint32_t)(b * C::KB * PSB);
-                            smarch_slot_dispatch<C, 0, RZ>(SL, vb, w, w3);
-                        } else {
-                            int slot = SL;
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        const int l1 = S1 + j1f[ps], l2 = S2 + j2f[ps];
+                        const bool lane_ok = actf[ps] && (unsigned)l1 < (unsigned)neff1 && (unsigned)l2 < (unsigned)neff2;
+                        const T w = w1v[ps] * (CPLX ? (cmpf[ps] ? Vim : Vre) : Vre) * w2v[ps];
+                        uint32_t vb[C::NBASE];
 #pragma unroll
-                            for (int j3 = 0; j3 < L; ++j3) {
-                                if (!CLIPZ || (planes & (1u << j3))) {
-                                    lds_atomic_add(ring + ((v0 - ring_base) >> 3) + slot * PS, (double)(w * w3[j3]));
-                                }
-                                slot = slot + 1 == RZ ? 0 : slot + 1;
-                            }
-                        }
+                        for (int b = 0; b < C::NBASE; ++b) vb[b] = lane_addr[ps] + so + (uint32_t)(b * C::PLB * PSB);
+                        if (lane_ok) smarch_add_planes<C, CLIPZ>(vb, w, w3, planes, std::make_integer_sequence<int, L>{});
                     }
                 }
             };
@@ -358,14 +362,14 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                 }
             }
 #else
-            asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(slot3), "v"(vmine));
+            asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(soff), "v"(lmask));
 #endif
         };
 
-        // ---- chunks of this layer, pulled from the counter; the next chunk's records are requested before the current one
-        //      is processed, its values right after ----
+        // ---- chunks wave, wave + NW, ... of this layer; the next chunk's records are requested before the current one is
+        //      processed, its values right after ----
         {
-            int item = pull();
+            int item = wave;
             uint32_t p0 = 0, p1 = 0;
             bool valid = item < nchunks;
             PointRec<T, 3> rec{};
@@ -373,64 +377,68 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             if (valid) {
                 lookup(item, p0, p1);
                 rec = sorted[min(p0 + (uint32_t)grp, p1 - 1)];
-                if (q < NC) {
-                    vcur = vin[(int64_t)rec.idx * NC + q];
-                    if (a.weights) vcur *= a.weights[rec.idx];      // callbacks.nonuniform(v, n), src/spreading/gpu.jl:289
-                }
+                vcur = value_of(rec);
             }
             while (valid) {
-                const int itn = pull();
-                const bool validn = itn < nchunks;
+                item += NW;
+                const bool validn = item < nchunks;
                 uint32_t n0 = 0, n1 = 0;
                 PointRec<T, 3> recn = rec;
                 if (validn) {
-                    lookup(itn, n0, n1);
+                    lookup(item, n0, n1);
                     recn = sorted[min(n0 + (uint32_t)grp, n1 - 1)];
                 }
                 const bool have = p0 + (uint32_t)grp < p1;
                 if (clipz) chunk(std::true_type{}, rec, vcur, have);
                 else chunk(std::false_type{}, rec, vcur, have);
-                if (validn && q < NC) {
-                    vcur = vin[(int64_t)recn.idx * NC + q];
-                    if (a.weights) vcur *= a.weights[recn.idx];
-                }
+                // (requesting the next values in the middle of the visits instead — half a chunk more slack — measured slower:
+                // 2.50 against 2.45 ms at C2; the value gather costs 0.1 ms in all, ablation 6)
+                if (validn) vcur = value_of(recn);
                 rec = recn; p0 = n0; p1 = n1; valid = validn;
             }
         }
         // the immediate-offset atomics are inline assembly: the compiler does not know that they are in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if NUFFT_SMARCH_ABL != 5
         __syncthreads();
 
-        // ---- retire: the 4 oldest planes of the window are complete; store the owned ones, zero them, recycle ----
+        // ---- retire + shift: the 4 lowest planes of the window are complete — store the owned ones; the other 2M - 1 move
+        //      down four slots, the top four are zeroed.  One thread per pair of reals of a plane, all RZ planes of that
+        //      position (no thread touches another's positions: no hazard inside the pass) ----
         {
             typedef double D2 __attribute__((ext_vector_type(2)));
             typedef T T2 __attribute__((ext_vector_type(2)));
-            constexpr int RP = NC * N1 / 2;             // pairs per row
-            constexpr int NPAIR = N2 * RP;
-            if (tid == 0) counter[0] = 0;
-            if (wq + 4 > 0 && wq < nq) {
-                for (int e = tid; e < 4 * NPAIR; e += THREADS) {
-                    const int pl = e / NPAIR, er = e % NPAIR, r = er / RP, xp = er % RP;
-                    const int qq = wq + pl;
-                    if (qq < 0 || qq >= nq || r >= neff2 || 2 * xp >= NC * neff1) continue;
-                    int slot = pm + pl;
-                    if (slot >= RZ) slot -= RZ;
-                    D2* src = reinterpret_cast<D2*>(ring + slot * PS + r * RS + 2 * xp);
-                    const D2 v = *src;
-                    *src = D2{0.0, 0.0};
-#if NUFFT_SMARCH_ABL != 3
-                    const int gz = 4 * zb0 + qq;        // < Nover[2]: the task owns these planes
-                    const int64_t row = (int64_t)gz * g.Nover[1] + org2 + r;
-                    *reinterpret_cast<T2*>(grid + (row * g.Nover[0] + org1) * NC + 2 * xp) = T2{(T)v.x, (T)v.y};
+            const int rp = NC * neff1 / 2;              // pairs per row
+            const int npair = neff2 * rp;
+            for (int e = tid; e < npair; e += THREADS) {
+                const int r = e / rp, xp = e - r * rp;
+                D2* pos = reinterpret_cast<D2*>(ring + r * RS + 2 * xp);
+                D2 v[RZ];
+#pragma unroll
+                for (int k = 0; k < RZ; ++k) v[k] = pos[k * (PS / 2)];
+#if NUFFT_SMARCH_ABL != 4
+#pragma unroll
+                for (int k = 0; k < RZ; ++k) pos[k * (PS / 2)] = k + 4 < RZ ? v[k + 4] : D2{0.0, 0.0};
 #else
-                    asm volatile("" ::"v"(v));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pos[k * (PS / 2)] = D2{0.0, 0.0};
 #endif
+#if NUFFT_SMARCH_ABL != 3
+                const int64_t rowb = ((int64_t)(org2 + r) * g.Nover[0] + org1) * NC + 2 * xp;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int qq = wq + k;
+                    if (qq >= 0 && qq < nq)             // (plane 4 zb0 + qq < Nover[2]: the task owns it)
+                        *reinterpret_cast<T2*>(grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb) = T2{(T)v[k].x, (T)v[k].y};
                 }
+#else
+#pragma unroll
+                for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(v[k]));
+#endif
             }
         }
         __syncthreads();
-        pm += 4;
-        if (pm >= RZ) pm -= RZ;
+#endif
     }
 }
 

@@ -72,6 +72,20 @@ struct TileArgs {
     int kernel;                           // NUFFT_KERNEL_*; beta / bop per kernel: see WindowEval
 };
 
+// The window fields of TileArgs with the evaluation mode fixed at compile time (kernels instantiated per mode: the other
+// mode's code and registers disappear).
+template <typename T, int EVALMODE>
+struct EvalArgs {
+    static constexpr int evalmode = EVALMODE;
+    int kernel;
+    const T* coefs;
+    T beta[3], bop[3];
+    __device__ __forceinline__ explicit EvalArgs(const TileArgs<T>& a) : kernel(a.kernel), coefs(a.coefs) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { beta[d] = a.beta[d]; bop[d] = a.bop[d]; }
+    }
+};
+
 template <int NC, int M>
 struct Grp {
     static constexpr int L = 2 * M;
@@ -143,10 +157,12 @@ struct WindowEval {
     bool has[NSLOT];
     T beta_s[NSLOT], bop_s[NSLOT];
 
-    __device__ __forceinline__ void init(const TileArgs<T>& a, int q) { init(a, q, a.coefs); }
+    // A: TileArgs<T> or any struct with its window fields (evalmode, kernel, beta, bop, coefs) — see EvalArgs
+    template <typename A>
+    __device__ __forceinline__ void init(const A& a, int q) { init(a, q, a.coefs); }
     // cf: the coefficient table [D][NP][2M] (a.coefs or a copy of it, e.g. in LDS)
-    template <typename CP>
-    __device__ __forceinline__ void init(const TileArgs<T>& a, int q, CP cf) {
+    template <typename A, typename CP>
+    __device__ __forceinline__ void init(const A& a, int q, CP cf) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const int k = q + s * GS;
@@ -176,8 +192,8 @@ struct WindowEval {
 
     // X[d]: cell fraction of this lane's point; strip: this group's NV slots in LDS.
     // PAD: every dimension's row is [PAD zeros | 2M values | PAD zeros] (the zeros are written once by the caller)
-    template <int PAD = 0>
-    __device__ __forceinline__ void eval_to_strip(const TileArgs<T>& a, const T (&X)[3], T* strip, int q) const {
+    template <int PAD = 0, typename A = TileArgs<T>>
+    __device__ __forceinline__ void eval_to_strip(const A& a, const T (&X)[3], T* strip, int q) const {
         T v[NSLOT];
         eval_regs(a, X, v);
 #pragma unroll
@@ -189,7 +205,8 @@ struct WindowEval {
     }
 
     // the same values left in registers: v[s] is window value k = q + s * GS of the lane's point
-    __device__ __forceinline__ void eval_regs(const TileArgs<T>& a, const T (&X)[3], T (&v)[NSLOT]) const {
+    template <typename A>
+    __device__ __forceinline__ void eval_regs(const A& a, const T (&X)[3], T (&v)[NSLOT]) const {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const T x = dsel[s] == 0 ? X[0] : (dsel[s] == 1 ? X[1] : X[2]);

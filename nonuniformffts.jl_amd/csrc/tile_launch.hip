@@ -63,14 +63,15 @@ ColumnTasks march_column_tasks(int dtype, int is_complex, int M, const Geom& g) 
 }
 
 // ---- spreading on the z-marching LDS ring (smarch_kernels.h) -----------------------------------------------------------
-const void* smarch_kernel_f32r(int M, int* lds_bytes, int* n);
-const void* smarch_kernel_f32c(int M, int* lds_bytes, int* n);
-const void* smarch_kernel_f64r(int M, int* lds_bytes, int* n);
-const void* smarch_kernel_f64c(int M, int* lds_bytes, int* n);
-static const void* smarch_kernel(int dtype, int is_complex, int M, int* lds_bytes, int* n) {
+const void* smarch_kernel_f32r(int M, bool poly, int* lds_bytes, int* n);
+const void* smarch_kernel_f32c(int M, bool poly, int* lds_bytes, int* n);
+const void* smarch_kernel_f64r(int M, bool poly, int* lds_bytes, int* n);
+const void* smarch_kernel_f64c(int M, bool poly, int* lds_bytes, int* n);
+// poly: the instantiation with the piecewise-polynomial window (FastApproximation) or the direct one
+static const void* smarch_kernel(int dtype, int is_complex, int M, bool poly, int* lds_bytes, int* n) {
     if (M < 2 || M > 10) return nullptr;
-    if (dtype == NUFFT_F32) return is_complex ? smarch_kernel_f32c(M, lds_bytes, n) : smarch_kernel_f32r(M, lds_bytes, n);
-    return is_complex ? smarch_kernel_f64c(M, lds_bytes, n) : smarch_kernel_f64r(M, lds_bytes, n);
+    if (dtype == NUFFT_F32) return is_complex ? smarch_kernel_f32c(M, poly, lds_bytes, n) : smarch_kernel_f32r(M, poly, lds_bytes, n);
+    return is_complex ? smarch_kernel_f64c(M, poly, lds_bytes, n) : smarch_kernel_f64r(M, poly, lds_bytes, n);
 }
 
 // Launch model of the ring: blocks go to the 8 XCDs round-robin and to the first free CU there, in launch order (task table
@@ -108,7 +109,7 @@ static double smarch_makespan(const std::vector<double>& task_work, int C, int c
 SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C) {
     SMarchPlan sp{};
     int lds = 0, n[5];
-    if (D != 3 || other || !smarch_kernel(dtype, is_complex, M, &lds, n)) return sp;
+    if (D != 3 || other || !smarch_kernel(dtype, is_complex, M, true, &lds, n)) return sp;
     for (int d = 0; d < 3; ++d)
         if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return sp;
     const int L = 2 * M, hlo = n[2], hhi = n[3];
@@ -172,10 +173,14 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
 }
 
 hipError_t prepare_spread_march(int dtype, int is_complex, int M) {
-    int lds = 0, n[5];
-    const void* fn = smarch_kernel(dtype, is_complex, M, &lds, n);
-    if (!fn) return hipErrorInvalidValue;
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int poly = 0; poly < 2; ++poly) {
+        int lds = 0, n[5];
+        const void* fn = smarch_kernel(dtype, is_complex, M, poly != 0, &lds, n);
+        if (!fn) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 const void* spread_kernel_f32r(int D, int M, bool flag, bool other);
@@ -545,7 +550,7 @@ hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np
 template <typename T>
 static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
     int lds = 0, n[5];
-    const void* fn = smarch_kernel(a.dtype, a.is_complex, a.M, &lds, n);
+    const void* fn = smarch_kernel(a.dtype, a.is_complex, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
     if (!fn) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;

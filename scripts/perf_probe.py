@@ -59,7 +59,8 @@ print(f"plan: Nover={plan.oversampled_dims} bins={[info.bin_dims[d] for d in ran
       f"spread_tile={[info.spread_tile[d] for d in range(a.dim)]} x{[info.spread_ntiles[d] for d in range(a.dim)]} "
       f"interp_tile={[info.interp_tile[d] for d in range(a.dim)]} x{[info.interp_ntiles[d] for d in range(a.dim)]} "
       f"lds={info.lds_bytes_spread}/{info.lds_bytes_interp} "
-      f"threads={info.spread_threads}/{info.interp_threads} workspace={info.workspace_bytes / 1e9:.2f} GB", flush=True)
+      f"threads={info.spread_threads}/{info.interp_threads} workspace={info.workspace_bytes / 1e9:.2f} GB "
+      f"spread_method={info.spread_method} ring_column={list(info.ring_column)} x{info.ring_segments} segments", flush=True)
 
 g = torch.Generator(device="cuda").manual_seed(42)
 if a.dist == "uniform":

@@ -497,23 +497,6 @@ def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
     assert _rel(out2.cpu().numpy(), ref) < _rtol(Z)
 
 
-def _spread_ring_fits(Z, M):
-    """SMarchCfg::FITS (smarch_kernels.h): a column of at least 4 x 4 cells x (2M + 3) planes of Float64 beside the strips."""
-    nc = 2 if np.dtype(Z).kind == "c" else 1
-    rb = 4 if np.dtype(Z) in (np.dtype(np.float32), np.dtype(np.complex64)) else 8
-    L = 2 * M
-    G = 1
-    while G < nc * L:
-        G *= 2
-    strip = -(-((64 // G) * 3 * L * rb) // 16) * 16
-    fixed = 2 * (64 * 8 + 64 * 4) + 64 * 8 + 64 + 16 * strip
-    rs = nc * 4
-    if nc * L < 16:
-        while rs % 16 != (nc * L) % 16:
-            rs += 1
-    return rs * 4 * (L + 3) * 8 + fixed <= 163840 - 256
-
-
 @pytest.mark.parametrize("M", range(2, 11))
 @pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
 def test_spreading_ring_every_instantiation(Z, M):
@@ -524,8 +507,11 @@ def test_spreading_ring_every_instantiation(Z, M):
     concentrated in a corner exercises the tasks of equal point count (quantile segments, empty tasks that only store zeros)."""
     dims, Np = (48, 40, 56), 4000
     for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
-        if not _spread_ring_fits(Z, M):
-            with pytest.raises(Exception):
+        if np.dtype(Z) == np.complex128 and M == 10:
+            # the LDS tiles of this plan need 2-cell bins (plan_math.cpp); the ring, like the patches, sorts by 4-cell bins
+            nufft, plan, *_ = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M)
+            assert plan.info().bin_dims[0] == 2
+            with pytest.raises(ValueError):
                 _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M, spread_method="marching_ring")
             return
         nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M, spread_method="marching_ring")
@@ -551,7 +537,7 @@ def test_spreading_ring_automatic_choice_and_fallback(Z, C):
     nufft, plan, oplan, xs, vs = _make_case(Z, dims, 4, 2.0, O.FAST_APPROXIMATION, C, Np, seed=77)
     dev = plan.device
     is_ring = plan.info().spread_method == 3
-    assert is_ring == (np.dtype(Z).kind != "c")
+    assert is_ring == (np.dtype(Z).kind != "c" and C == 1)      # (real plans with ntransforms = 2, 3: planar patches)
     for name in ("uniform", "corner"):
         pts = xs if name == "uniform" else tuple((0.05 * x).astype(x.dtype) for x in xs)
         nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
