@@ -481,6 +481,30 @@ __device__ __forceinline__ void row_bcast_all(double x, double (&w)[8], int, std
         : "v"(x));
 }
 
+// four values BASE .. BASE + 3 of a row as one block (a single hazard no-op)
+template <int BASE>
+__device__ __forceinline__ void row_bcast4(double x, double (&w)[4]) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b64_dpp %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %1, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+        : "v"(x), "n"(BASE), "n"(BASE + 1), "n"(BASE + 2), "n"(BASE + 3));
+}
+template <int BASE>
+__device__ __forceinline__ void row_bcast4(float x, float (&w)[4]) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+        : "v"(x), "n"(BASE), "n"(BASE + 1), "n"(BASE + 2), "n"(BASE + 3));
+}
+
 // j must be a compile-time constant after unrolling (the switch folds away)
 template <typename T>
 __device__ __forceinline__ T row_bcast(T x, int j) {

@@ -116,6 +116,30 @@ __device__ __forceinline__ void smarch_add_planes(const uint32_t (&vb)[C::NBASE]
     (smarch_add_plane<C, CLIPZ, J>(vb, w, w3, planes), ...);
 }
 
+// FAST path (2M = 8 planes, all from two base addresses): planes J0 .. J0 + 3 with their window values in w3q
+template <typename C, bool CLIPZ, int J0, typename T>
+__device__ __forceinline__ void smarch_add_four(const uint32_t (&vb)[C::NBASE], T w, const T (&w3q)[4], unsigned planes) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int J = J0 + k;
+#if NUFFT_SMARCH_ABL == 1
+        const double v = (double)(w * w3q[k]);
+        asm volatile("" ::"v"(vb[J / C::PLB]), "v"(v));
+#else
+        if (!CLIPZ || (planes & (1u << J))) {
+            const uint32_t addr = vb[J / C::PLB];
+            const double v = (double)(w * w3q[k]);
+            switch (J % C::PLB) {                         // (J is a constant after unrolling)
+                case 0: lds_add_imm<0 * C::PSB>(addr, v); break;
+                case 1: lds_add_imm<1 * C::PSB>(addr, v); break;
+                case 2: lds_add_imm<2 * C::PSB>(addr, v); break;
+                default: lds_add_imm<3 * C::PSB>(addr, v); break;
+            }
+        }
+#endif
+    }
+}
+
 template <typename T, bool CPLX, int M, bool POLY>
 __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, MarchGeom mg) {
     using C = SMarchCfg<T, CPLX, M>;
@@ -309,8 +333,18 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                     uint32_t vb[C::NBASE];
 #pragma unroll
                     for (int b = 0; b < C::NBASE; ++b) vb[b] = lane_addr[0] + so + (uint32_t)(b * C::PLB * PSB);
+#if !defined(NUFFT_SMARCH_W3_SPLIT)
                     if (__builtin_amdgcn_inverse_ballot_w64(((unsigned long long)mhi << 32) | mlo))
                         smarch_add_planes<C, CLIPZ>(vb, w, w3, planes, std::make_integer_sequence<int, L>{});
+#else
+                    // the window values of dimension 3 four planes at a time (8 registers less; measured slower)
+                    static_assert(!FAST || (L == 8 && C::PLB == 4), "FAST: two groups of four planes");
+                    T w3q[4];
+                    row_bcast4<0>(w3a, w3q);
+                    if (__builtin_amdgcn_inverse_ballot_w64(((unsigned long long)mhi << 32) | mlo)) smarch_add_four<C, CLIPZ, 0>(vb, w, w3q, planes);
+                    row_bcast4<4>(w3a, w3q);
+                    if (__builtin_amdgcn_inverse_ballot_w64(((unsigned long long)mhi << 32) | mlo)) smarch_add_four<C, CLIPZ, 4>(vb, w, w3q, planes);
+#endif
                 } else {
                     const int S1 = __builtin_amdgcn_readlane(s[0], src);
                     const int S2 = __builtin_amdgcn_readlane(s[1], src);
@@ -413,27 +447,54 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             for (int e = tid; e < npair; e += THREADS) {
                 const int r = e / rp, xp = e - r * rp;
                 D2* pos = reinterpret_cast<D2*>(ring + r * RS + 2 * xp);
-                D2 v[RZ];
+#if defined(NUFFT_SMARCH_RETIRE_V1)
+                {
+                    D2 v[RZ];
 #pragma unroll
-                for (int k = 0; k < RZ; ++k) v[k] = pos[k * (PS / 2)];
+                    for (int k = 0; k < RZ; ++k) v[k] = pos[k * (PS / 2)];
+#pragma unroll
+                    for (int k = 0; k < RZ; ++k) pos[k * (PS / 2)] = k + 4 < RZ ? v[k + 4] : D2{0.0, 0.0};
+                    const int64_t rowb = ((int64_t)(org2 + r) * g.Nover[0] + org1) * NC + 2 * xp;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int qq = wq + k;
+                        if (qq >= 0 && qq < nq)
+                            *reinterpret_cast<T2*>(grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb) = T2{(T)v[k].x, (T)v[k].y};
+                    }
+                }
+                continue;
+#endif
+                // the four finished planes leave first, then the others move down (fewer values live at a time)
+                {
+                    D2 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = pos[k * (PS / 2)];
+#if NUFFT_SMARCH_ABL != 3
+                    const int64_t rowb = ((int64_t)(org2 + r) * g.Nover[0] + org1) * NC + 2 * xp;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int qq = wq + k;
+                        if (qq >= 0 && qq < nq)         // (plane 4 zb0 + qq < Nover[2]: the task owns it)
+                            *reinterpret_cast<T2*>(grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb) = T2{(T)v[k].x, (T)v[k].y};
+                    }
+#else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(v[k]));
+#endif
+                }
 #if NUFFT_SMARCH_ABL != 4
+                {
+                    D2 v[RZ - 4];
 #pragma unroll
-                for (int k = 0; k < RZ; ++k) pos[k * (PS / 2)] = k + 4 < RZ ? v[k + 4] : D2{0.0, 0.0};
+                    for (int k = 0; k < RZ - 4; ++k) v[k] = pos[(k + 4) * (PS / 2)];
+#pragma unroll
+                    for (int k = 0; k < RZ - 4; ++k) pos[k * (PS / 2)] = v[k];
+                }
+#pragma unroll
+                for (int k = RZ - 4; k < RZ; ++k) pos[k * (PS / 2)] = D2{0.0, 0.0};
 #else
 #pragma unroll
                 for (int k = 0; k < 4; ++k) pos[k * (PS / 2)] = D2{0.0, 0.0};
-#endif
-#if NUFFT_SMARCH_ABL != 3
-                const int64_t rowb = ((int64_t)(org2 + r) * g.Nover[0] + org1) * NC + 2 * xp;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int qq = wq + k;
-                    if (qq >= 0 && qq < nq)             // (plane 4 zb0 + qq < Nover[2]: the task owns it)
-                        *reinterpret_cast<T2*>(grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb) = T2{(T)v[k].x, (T)v[k].y};
-                }
-#else
-#pragma unroll
-                for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(v[k]));
 #endif
             }
         }
