@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector / matrix peak (256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz)
 
 CONFIGS = {
     "c2": dict(Z="float64", n=256, np=1e7, m=4, sigma=2.0, C=1, steps=20,
@@ -336,6 +337,8 @@ def main():
             "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt1},
             "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt2,
                       "ms_per_step": dt2 / steps * 1e3},
+            "workspace_bytes": int(plan.info().workspace_bytes),       # plan-owned device memory with this point set in place
+            "ring_column": [int(info.ring_column[0]), int(info.ring_column[1])], "ring_segments": int(info.ring_segments),
             "spread_engine": engine_used, "patch_f32acc": int(info.patch_f32acc), "patch_dims": [int(info.patch_dims[0]), int(info.patch_dims[1])], "patch_planar": int(info.patch_planar),
             "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
             "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
@@ -363,6 +366,10 @@ def main():
         kname = f"spread_patch_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, false, {head['patch_planar']}>"
         binding = ("issue and latency of the per-visit point set-up at 8 waves per CU (VALU 36 %, LDS 44 %, FP64 matrix pipe 16 % "
                    "busy), not HBM: see DESIGN.md section 4.4")
+    elif head["spread_engine"] == "marching_ring":
+        kname = f"spread_march_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, {'false' if head['evalmode'] == 'Direct' else 'true'}>"
+        binding = ("the LDS atomic pipe (ds_add_f64: 8 array cycles per 64-lane wave instruction, 11.9 of them per point at 1.49 visits; "
+                   "LDS array 73 % busy), then the two barriers per bin layer; not HBM: see DESIGN.md section 4.9")
     else:
         kname = f"spread_tile_kernel<{tname}, {'true' if is_complex else 'false'}, 3, {cfg['m']}"
         binding = ("LDS float atomics (ds_add_f64, 8.5 cycles per wave instruction per CU) and the scalar/vector issue of the "
@@ -386,6 +393,7 @@ def main():
         "own_traffic_bytes_per_stage": ab["spread_kernel_min"],
         "achieved_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9,
         "frac_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9 / HBM_PEAK_GBS,
+        "frac_own": ab["spread_kernel_min"] / spread_s / 1e9 / HBM_PEAK_GBS,      # the kernel's own compulsory traffic (G + P) against the peak
         "kernel_ms": st1["spread"],
         "interp": {"kernel_ms": st2["interp"], "algorithmic_bytes_per_stage": ab["interp_kernel"],
                    "achieved": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9, "frac": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -416,6 +424,7 @@ def main():
                         f"ntransforms={Cn}, {head['evalmode']} window (the other evaluation mode: sibling record)",
             "protocol": "set_points! + exec_type1! per step, inputs resident in HBM (reference benchmark protocol)",
             "spread_engine": head["spread_engine"], "spread_tile": head["spread_tile"], "interp_tile": head["interp_tile"],
+            "ring_column": head["ring_column"], "ring_segments": head["ring_segments"], "workspace_bytes": head["workspace_bytes"],
             "parallelism": f"{world} independent plan(s), one per GPU" + ("" if not distributed or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
         },
         "roofline": roofline,
@@ -453,12 +462,35 @@ def main():
                     "roofline_frac": abo["spread_kernel"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "roofline_frac_own_traffic": abo["spread_kernel_min"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "interp_roofline_frac": abo["interp_kernel"] / (ip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "workspace_bytes": r["workspace_bytes"],
                 }
+                if name == "c3":
+                    # C3 is bound by arithmetic, not HBM: (2M)^3 multiply-adds per point and component on the FP32 pipes
+                    flop = 2.0 * (2 * oc["m"]) ** 3 * (2 if Po["is_complex"] else 1) * Po["Np"] * Po["Cn"]
+                    others[name]["roofline_fp32"] = {"bound": "fp32", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                     "achieved_tflops": flop / (sp_ms * 1e-3) / 1e12, "frac": flop / (sp_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                                     "flop_per_stage": flop, "kernel": "spread_patch32_kernel (v_mfma_f32_16x16x4 + vector FP32)",
+                                                     "interp_achieved_tflops": flop / (ip_ms * 1e-3) / 1e12,
+                                                     "interp_frac": flop / (ip_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+                    others[name]["fp32_achieved_tflops"] = others[name]["roofline_fp32"]["achieved_tflops"]
+                    others[name]["fp32_frac"] = others[name]["roofline_fp32"]["frac"]
+                    others[name]["interp_fp32_achieved_tflops"] = others[name]["roofline_fp32"]["interp_achieved_tflops"]
+                    others[name]["interp_fp32_frac"] = others[name]["roofline_fp32"]["interp_frac"]
                 del Po
                 torch.cuda.empty_cache()
             except Exception as exc:           # informative records: never lose the headline line over them
                 others[name] = {"error": repr(exc)}
         result["config"]["other_configs"] = others
+        # ... and flattened into scalars (the driver's parser keeps scalars of `config`, not nested records)
+        for name, r in others.items():
+            if "error" in r:
+                result["config"][f"{name}_error"] = r["error"]
+                continue
+            for k in ("value", "ms_per_step", "type2_value", "type2_ms_per_step", "spread_ms", "interp_ms", "spread_engine", "roofline_frac",
+                      "roofline_frac_own_traffic", "interp_roofline_frac", "workspace_bytes", "fp32_achieved_tflops", "fp32_frac",
+                      "interp_fp32_achieved_tflops", "interp_fp32_frac"):
+                if k in r:
+                    result["config"][f"{name}_{k}"] = r[k]
     if full and a.config == "c2" and not a.no_reference_protocol:
         result["reference_protocol"] = reference_protocol(cfg, nufft, dev, sweep=not a.no_density_sweep)
     if rank == 0 and full and not a.no_cpu_baseline:

@@ -352,16 +352,19 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         const bool prefer_patches = p->is_complex || p->M >= 5 || pp.planar != 0 || env_int("NUFFT_PREFER_PATCHES", 0) != 0;     // (the switch: test runs)
         p->spread_method = (pp.eligible && (req == NUFFT_SPREAD_MFMA_PATCHES || (req == NUFFT_SPREAD_AUTO && prefer_patches)))
                                ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
-        // third engine, the z-marching LDS ring (smarch_kernels.h): same per-point arithmetic as the LDS tiles with 1.4 - 1.5 instead
-        // of 2.1 visits per point and no per-plane control — taken where the LDS tiles were the automatic choice (real data, M <= 4:
-        // measurements in DESIGN.md section 4.9); 256 CUs assumed here, build_device() redoes the decomposition for the device
+        // third engine, the z-marching LDS window (smarch_kernels.h): the per-point arithmetic of the LDS tiles with 1.5 instead of
+        // 2.1 visits per point and no per-plane control.  Automatic choice from the measured spread stage of the three engines
+        // (256^3 -> 512^3, Np = 1e7): real data up to M = 6 (M = 4: 2.44 ms against 3.07 tiles / 4.05 patches;
+        // M = 6: 10.8 / 15.5 / 13.2; M = 7: 20.1 against 13.4 patches), ntransforms components one after the other (C = 3: 7.3 ms
+        // against 7.5 with the planar patches); ComplexF64 up to M = 4 (5.06 against 5.36 patches), ComplexF32 up to M = 3 (M = 4:
+        // 4.71 against 4.10 patches).  256 CUs assumed here, build_device() redoes the decomposition for the device.
         p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C);
         if (req == NUFFT_SPREAD_MARCHING_RING && !p->smarch.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = marching ring needs a 3-D grid of 4-cell bins with every oversampled axis a multiple "
                                                "of 4 and longer than a column plus a stencil, and the default window evaluation");
-        const bool prefer_ring = env_int("NUFFT_PREFER_RING", 1) != 0 && !p->is_complex && p->M <= 4;
-        if (p->smarch.eligible && (req == NUFFT_SPREAD_MARCHING_RING ||
-                                   (req == NUFFT_SPREAD_AUTO && p->spread_method == NUFFT_SPREAD_LDS_TILES && prefer_ring)))
+        const int ring_max_m = !p->is_complex ? 6 : (p->dtype == NUFFT_F64 ? 4 : 3);
+        const bool prefer_ring = env_int("NUFFT_PREFER_RING", 1) != 0 && p->M <= ring_max_m && env_int("NUFFT_PREFER_PATCHES", 0) == 0;
+        if (p->smarch.eligible && (req == NUFFT_SPREAD_MARCHING_RING || (req == NUFFT_SPREAD_AUTO && prefer_ring)))
             p->spread_method = NUFFT_SPREAD_MARCHING_RING;
     }
     return NUFFT_OK;
@@ -1101,7 +1104,8 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         double advantage = 0.85 * 1.3;
         if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING) advantage = 0.0;
         const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
-        NUFFT_HIP(launch_smarch_tasks(s.g, p->smarch, p->d_offsets, np, p->num_cus, advantage, p->d_smarch_choice, p->bal.d_slots, p->d_smarch_cols,
+        // (the C components are independent workgroups of one launch: each component has num_cus / C compute units' worth of the chip)
+        NUFFT_HIP(launch_smarch_tasks(s.g, p->smarch, p->d_offsets, np, std::max(1, p->num_cus / p->C), advantage, p->d_smarch_choice, p->bal.d_slots, p->d_smarch_cols,
                                       p->d_smarch_cols + ncols, static_cast<uint2*>(p->d_smarch_tasks), stream));
     }
     if (p->interp_march) {

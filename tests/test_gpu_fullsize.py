@@ -270,6 +270,7 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
 @pytest.mark.parametrize("Z,M,engine", [
     (np.complex128, 4, "mfma_patches"), (np.float64, 6, "mfma_patches"), (np.complex64, 8, "mfma_patches"),
     (np.float64, 4, "mfma_patches"), (np.complex64, 8, "lds_tiles"), (np.float32, 4, "mfma_patches"),
+    (np.float64, 4, "marching_ring"), (np.float32, 4, "marching_ring"), (np.complex128, 3, "marching_ring"), (np.float64, 6, "marching_ring"),
 ])
 def test_dense_point_sets_match_c_oracle(Z, M, engine):
     """Dense sets (oversampled 128^3 = 32^3 bins, Np = 2e6: 61 points per bin, every K-batch of the patch engine full and

@@ -531,13 +531,13 @@ def test_spreading_ring_every_instantiation(Z, M):
 @pytest.mark.parametrize("Z,C", [(np.float64, 1), (np.float64, 3), (np.float32, 2), (np.complex128, 1)])
 def test_spreading_ring_automatic_choice_and_fallback(Z, C):
     """Automatic engine choice on a grid with enough columns for the chip (256 x 256 x 64 oversampled): real plans at M = 4
-    take the ring for a uniform point set and hand a point set concentrated in one corner to the LDS tiles (device-side
-    decision, read back); both against the oracle.  Complex plans keep their engine."""
+    and ComplexF64 plans take the ring for a uniform point set and hand a point set concentrated in one corner to the LDS
+    tiles (device-side decision, read back); both against the oracle."""
     dims, Np = (128, 128, 32), 60000
     nufft, plan, oplan, xs, vs = _make_case(Z, dims, 4, 2.0, O.FAST_APPROXIMATION, C, Np, seed=77)
     dev = plan.device
     is_ring = plan.info().spread_method == 3
-    assert is_ring == (np.dtype(Z).kind != "c" and C == 1)      # (real plans with ntransforms = 2, 3: planar patches)
+    assert is_ring
     for name in ("uniform", "corner"):
         pts = xs if name == "uniform" else tuple((0.05 * x).astype(x.dtype) for x in xs)
         nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
@@ -588,16 +588,22 @@ def test_spreading_engine_selection():
         nufft.PlanNUFFT(np.float64, (64, 64), spread_method="mfma_patches", backend=nufft.ROCBackend(0))
     with pytest.raises(ValueError):
         nufft.PlanNUFFT(np.complex128, (35, 64, 40), sigma=1.5, spread_method="mfma_patches", backend=nufft.ROCBackend(0))
-    # automatic choice: patches for complex data or M >= 5 where eligible, LDS tiles otherwise
-    assert nufft.PlanNUFFT(np.float64, (64, 64, 64), backend=nufft.ROCBackend(0)).info().spread_method == 1
-    assert nufft.PlanNUFFT(np.complex128, (64, 64, 64), backend=nufft.ROCBackend(0)).info().spread_method == 2
-    assert nufft.PlanNUFFT(np.float64, (64, 64, 64), m=6, backend=nufft.ROCBackend(0)).info().spread_method == 2
-    assert nufft.PlanNUFFT(np.complex128, (35, 64, 40), sigma=1.5, backend=nufft.ROCBackend(0)).info().spread_method == 1
-    # real plans with ntransforms = 2 / 3: the patches spread the components together
+    # automatic choice where all three engines are eligible: the marching ring for real data up to
+    # M = 6, ComplexF64 up to M = 4 and ComplexF32 up to M = 3; the patches above that; LDS tiles where neither applies
+    def method(Z, dims=(64, 64, 64), **kw):
+        return nufft.PlanNUFFT(Z, dims, backend=nufft.ROCBackend(0), **kw).info().spread_method
+    assert method(np.float64) == 3 and method(np.float64, m=6) == 3 and method(np.float64, m=7) == 2
+    assert method(np.complex128) == 3 and method(np.complex128, m=5) == 2
+    assert method(np.complex64, m=3) == 3 and method(np.complex64) == 2
+    assert method(np.complex128, (35, 64, 40), sigma=1.5) == 1 and method(np.float64, (64, 64)) == 1
+    # real plans with ntransforms = 2 / 3: the ring spreads the components one after the other (7.3 against 7.5 ms at C4); an
+    # explicit request for the patches still spreads them together
     i3 = nufft.PlanNUFFT(np.float64, (64, 64, 64), ntransforms=3, backend=nufft.ROCBackend(0)).info()
-    assert i3.spread_method == 2 and i3.patch_planar == 3
-    i4 = nufft.PlanNUFFT(np.float64, (64, 64, 64), ntransforms=4, backend=nufft.ROCBackend(0)).info()
-    assert i4.spread_method == 1 and i4.patch_planar == 0
+    assert i3.spread_method == 3 and i3.patch_planar == 0 and i3.ring_column[0] > 0
+    i3p = nufft.PlanNUFFT(np.float64, (64, 64, 64), ntransforms=3, spread_method="mfma_patches", backend=nufft.ROCBackend(0)).info()
+    assert i3p.spread_method == 2 and i3p.patch_planar == 3
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.float64, (64, 64), spread_method="marching_ring", backend=nufft.ROCBackend(0))
 
 
 @pytest.mark.parametrize("kw", [dict(gpu_method="global_memory"),
@@ -616,7 +622,7 @@ def _check_type1_type2(Z, dims, M, sigma, evalmode, C, expect_engine=None, **kw)
     Np = 2000
     nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, sigma, evalmode, C, Np, seed=42, **kw)
     if expect_engine is not None:
-        assert plan.info().spread_method == {"lds_tiles": 1, "mfma_patches": 2}[expect_engine]
+        assert plan.info().spread_method == {"lds_tiles": 1, "mfma_patches": 2, "marching_ring": 3}[expect_engine]
     dev = plan.device
     xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
     vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
@@ -809,8 +815,8 @@ def test_automatic_engine_choice_per_point_set(dist):
         "cluster": tuple(torch.randn(Np, dtype=torch.float64, device="cuda", generator=g) * 0.05 + np.pi for _ in range(3)),
     }
     v = torch.randn(Np, dtype=torch.complex128, device="cuda", generator=g)
-    auto = nufft.PlanNUFFT(torch.complex128, (n, n, n), backend=nufft.ROCBackend(0))
-    ref = nufft.PlanNUFFT(torch.complex128, (n, n, n), spread_method="lds_tiles", backend=nufft.ROCBackend(0))
+    auto = nufft.PlanNUFFT(torch.complex128, (n, n, n), m=5, backend=nufft.ROCBackend(0))       # (M = 5: the patches are the automatic choice)
+    ref = nufft.PlanNUFFT(torch.complex128, (n, n, n), m=5, spread_method="lds_tiles", backend=nufft.ROCBackend(0))
     assert auto.info().spread_method == 2 and ref.info().spread_method == 1
     for name in (dist, "uniform" if dist == "cluster" else "cluster", dist):
         nufft.set_points(auto, sets[name])

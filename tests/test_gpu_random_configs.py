@@ -107,7 +107,7 @@ def _draw_large(rng):
     mode = int(rng.integers(0, 2))
     C = int(rng.choice([1, 1, 2, 3]))
     dist = ["uniform", "uniform", "cluster"][int(rng.integers(0, 3))]
-    engine = ["auto", "auto", "lds_tiles", "mfma_patches"][int(rng.integers(0, 4))]
+    engine = ["auto", "auto", "lds_tiles", "mfma_patches", "marching_ring"][int(rng.integers(0, 5))]
     if np.dtype(Z) in (np.dtype(np.float32), np.dtype(np.complex64)):
         # Float32 at small sigma is ill-conditioned whatever the implementation: the deconvolution spans 4-5 decades and amplifies
         # Float32 round-off of windows and sums to 1e-3 (measured at sigma = 1.25, M = 6, clustered points: Float32 oracle vs
@@ -119,7 +119,7 @@ def _draw_large(rng):
 @pytest.mark.parametrize("seed", range(56 + int(os.environ.get("NUFFT_TEST_EXTRA_SEEDS", "0"))))      # (soak runs: more seeds)
 def test_random_configuration_large_3d(seed, monkeypatch):
     """The same differential test on 3-D grids large enough for the engines that need room — register patches (Float64 and
-    Float32 accumulators, planar components), the z-marching interpolation ring — with the default window, both evaluation
+    Float32 accumulators, planar components), the z-marching spreading window and interpolation ring — with the default window, both evaluation
     modes, all element types, ntransforms 1..3, uniform and clustered points (clustered sets switch both stages back to the
     LDS-tile kernels on the device), and the spreading engine automatic or forced (an engine the plan cannot serve must be
     refused, nothing silent)."""
@@ -157,7 +157,7 @@ def test_random_configuration_large_3d(seed, monkeypatch):
                                kernel_evalmode=nufft.Direct() if mode == O.DIRECT else nufft.FastApproximation(),
                                backend=nufft.ROCBackend(0))
     except ValueError as exc:
-        assert engine == "mfma_patches" and "MFMA patches" in str(exc)
+        assert (engine == "mfma_patches" and "MFMA patches" in str(exc)) or (engine == "marching_ring" and "marching ring" in str(exc))
         return
     assert plan.oversampled_dims == oplan.Nover
     O.set_points(oplan, xs)
