@@ -1,4 +1,5 @@
-"""Sharding of independent NUFFT plans over the GPUs of one node (BASELINE configs[4]).
+"""Sharding of independent NUFFT plans — or of the components of one `ntransforms = C` plan — over the GPUs of one node
+(BASELINE configs[4]; north_star: "independent transforms (ntransforms or batched plans) shard embarrassingly").
 
 The reference has no multi-GPU code.  The path shards embarrassingly: independent
 plans (or the components of a batch) share nothing, so plan ``b`` of a batch lives on rank
@@ -47,6 +48,19 @@ class HipExecutor:
         self._p.exec_type2(out, self.plan, uhat)
         return out
 
+    # components of one transform: the points are set once, then one exec per owned component
+    def type1_shared_points(self, points, values_list, outs):
+        self._p.set_points(self.plan, points)
+        for v, o in zip(values_list, outs):
+            self._p.exec_type1(o, self.plan, v)
+        return outs
+
+    def type2_shared_points(self, points, uhats, outs):
+        self._p.set_points(self.plan, points)
+        for u, o in zip(uhats, outs):
+            self._p.exec_type2(o, self.plan, u)
+        return outs
+
 
 class PlanBatch:
     """A batch of ``nplans`` independent transforms of identical shape, sharded one-per-rank.
@@ -65,6 +79,40 @@ class PlanBatch:
         else:
             self.rank, self.world_size = 0, 1
         self.owned = owned_indices(self.nplans, self.rank, self.world_size)
+
+    @classmethod
+    def from_ntransforms(cls, ntransforms: int, executor, group=None) -> "PlanBatch":
+        """The C components of ONE transform (``PlanNUFFT(...; ntransforms = Val(C))``, src/plan.jl:166-176) sharded over the
+        ranks: component c lives on rank c mod world_size, every rank holds the same point set (`exec_components_type1`
+        takes it once).  Components share nothing but the read-only points, so this is the same
+        embarrassingly parallel split as independent plans; ``gather_type1`` returns the C spectra in component order.
+        ``executor`` is a single-component executor (the rank's plan has ntransforms = 1 and is reused per component)."""
+        b = cls(ntransforms, executor, group)
+        b.shared_points = True
+        return b
+
+    shared_points = False
+
+    def exec_components_type1(self, points, values_owned: Sequence) -> List[torch.Tensor]:
+        """`from_ntransforms` batches: the owned components of the transform on the common point set; ``values_owned[i]`` is
+        the value vector of component ``self.owned[i]``."""
+        assert self.shared_points and len(values_owned) == len(self.owned)
+        outs = [torch.empty(self.executor.out_shape(), dtype=self.executor.out_dtype(), device=self.executor.device) for _ in self.owned]
+        if hasattr(self.executor, "type1_shared_points"):
+            self.executor.type1_shared_points(points, list(values_owned), outs)
+        else:
+            for v, o in zip(values_owned, outs):
+                self.executor.type1(points, v, o)
+        return outs
+
+    def exec_components_type2(self, points, uhats_owned: Sequence, outs: Sequence) -> List[torch.Tensor]:
+        assert self.shared_points and len(uhats_owned) == len(outs) == len(self.owned)
+        if hasattr(self.executor, "type2_shared_points"):
+            self.executor.type2_shared_points(points, list(uhats_owned), list(outs))
+        else:
+            for u, o in zip(uhats_owned, outs):
+                self.executor.type2(points, u, o)
+        return list(outs)
 
     def exec_type1(self, points: Sequence, values: Sequence) -> List[torch.Tensor]:
         """Runs every owned problem; ``points[i]`` / ``values[i]`` belong to ``self.owned[i]``."""

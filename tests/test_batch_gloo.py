@@ -63,6 +63,55 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_components(rank, world, port, q):
+    """ntransforms = 3 sharded over two ranks: rank 0 owns components 0 and 2, rank 1 component 1; the same points everywhere."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nufft_pkg import nufft  # noqa: F401
+    batch_mod = __import__("nonuniformffts_jl_amd.batch", fromlist=["PlanBatch"])
+    C = 3
+    batch = batch_mod.PlanBatch.from_ntransforms(C, OracleExecutor())
+    assert batch.owned == list(range(rank, C, world)) and batch.shared_points
+    xs, _ = _problem(0)
+    vals = [_problem(10 + c)[1] for c in batch.owned]            # component c's value vector
+    outs = batch.exec_components_type1(xs, vals)
+    gathered = batch.gather_type1(outs, dst=0)
+    if rank == 0:
+        q.put([g.numpy() for g in gathered])
+    else:
+        assert gathered is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_components_of_one_transform_shard_over_ranks():
+    """`PlanBatch.from_ntransforms` (north_star: "independent transforms (ntransforms or batched plans) shard ... across the
+    GPUs"): C = 3 components on 2 ranks, gathered in component order on rank 0, equal to the oracle's ntransforms = 3 plan."""
+    world, C = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_components, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        gathered = q.get(timeout=120)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    assert len(gathered) == C
+    xs, _ = _problem(0)
+    plan3 = O.OraclePlan(DIMS, is_real=True, M=M, sigma=SIGMA, ntransforms=C)
+    O.set_points(plan3, [x.numpy() for x in xs])
+    ref = O.exec_type1(plan3, [_problem(10 + c)[1].numpy() for c in range(C)])
+    for c in range(C):
+        assert np.allclose(gathered[c], np.asarray(ref[c]), rtol=1e-13, atol=1e-13)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
