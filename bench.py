@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--no-reference-protocol", action="store_true")
     ap.add_argument("--no-density-sweep", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact C3 / C4 records of the default run")
+    ap.add_argument("--shard-components", action="store_true",
+                    help="configurations with ntransforms = C > 1 (c4): the C components of ONE transform are sharded over the ranks "
+                         "(component c on rank c mod N, the same points on every rank; strong scaling) instead of one independent "
+                         "C-component problem per rank")
     ap.add_argument("--force-distributed", action="store_true",
                     help="take the multi-process code path (RCCL init, side-stream gather) even with one rank: "
                          "a single-GPU self-test of the N > 1 path")
@@ -246,9 +250,19 @@ def main():
         T = torch.float32 if Z in (torch.float32, torch.complex64) else torch.float64
         P = dict(Z=Z, T=T, CT=torch.complex64 if T == torch.float32 else torch.complex128, is_complex=Z.is_complex,
                  real_bytes=4 if T == torch.float32 else 8, Np=int(cfg["np"]), Cn=int(cfg["C"]), dims=(cfg["n"],) * 3, cfg=cfg)
-        g = torch.Generator(device=dev).manual_seed(42 + rank)
+        shard = bool(a.shard_components) and P["Cn"] > 1
+        g = torch.Generator(device=dev).manual_seed(42 + (0 if shard else rank))      # (sharded components: one point set for all ranks)
         P["xs"] = tuple(torch.rand(P["Np"], dtype=T, device=dev, generator=g) * (2 * np.pi) for _ in P["dims"])
         P["vps"] = tuple(torch.randn(P["Np"], dtype=Z, device=dev, generator=g) for _ in range(P["Cn"]))
+        P["C_total"], P["sharded"] = P["Cn"], shard
+        if shard:
+            # component c of the transform lives on rank c mod world (nonuniformffts.jl_amd/batch.py: PlanBatch.from_ntransforms)
+            owned = list(range(rank, P["Cn"], world))
+            if not owned:
+                raise SystemExit(f"bench.py --shard-components: {P['Cn']} components cannot occupy {world} ranks")
+            P["vps"] = tuple(P["vps"][c] for c in owned)
+            P["Cn"] = len(owned)
+            P["rounds"] = (P["C_total"] + world - 1) // world       # gathers per step: ranks with fewer components send a placeholder
         return P
 
     def measure(P, evalmode_name, steps, gather):
@@ -261,10 +275,12 @@ def main():
         uhat = [tuple(torch.empty(plan.shape, dtype=CT, device=dev) for _ in range(Cn)) for _ in range(2)]   # double buffer
         vout = tuple(torch.empty(Np, dtype=Z, device=dev) for _ in range(Cn))
         gather_list = None
+        n_gather = P.get("rounds", Cn)                     # collectives per step (sharded components: one per round)
+        pad = tuple(torch.zeros_like(uhat[0][0]) for _ in range(n_gather - Cn))      # placeholders of ranks that own fewer components
         if gather and gather_stream is not None and rank == 0:
             # complex spectra travel as their (re, im) real views (same bytes; every backend supports reals);
             # one receive buffer per (double buffer, component, source rank)
-            gather_list = [[[torch.empty_like(torch.view_as_real(uhat[0][0])) for _ in range(world)] for _ in range(Cn)] for _ in range(2)]
+            gather_list = [[[torch.empty_like(torch.view_as_real(uhat[0][0])) for _ in range(world)] for _ in range(n_gather)] for _ in range(2)]
         gather_done = [None, None]
         use_gather = [gather and gather_stream is not None]
 
@@ -294,7 +310,7 @@ def main():
                 gather_stream.wait_event(done)
                 with torch.cuda.stream(gather_stream):
                     # every component's spectrum (stream-ordered, the host does not block)
-                    gather_components(out, gather_list[k % 2] if rank == 0 else None, rank)
+                    gather_components(tuple(out) + pad, gather_list[k % 2] if rank == 0 else None, rank)
                     e = torch.cuda.Event()
                     e.record()
                     gather_done[k % 2] = e
@@ -330,12 +346,14 @@ def main():
         st2 = stage_ms(ev2, ["set_points", "deconv_pad", "fft", "interp"])
         exec1_ms = st1["spread"] + st1["fft"] + st1["deconv"]
         exec2_ms = st2["deconv_pad"] + st2["fft"] + st2["interp"]
+        jobs = 1 if P.get("sharded") else world
         engine_used = plan.spread_engine_used()          # the per-point-set decision read back from the device (after the timed regions)
         rec = {
             "evalmode": "Direct" if evalmode_name == "direct" else "FastApproximation",
-            "value": world * Np * steps / dt1, "ms_per_step": dt1 / steps * 1e3,
-            "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt1},
-            "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": world * Np * steps / dt2,
+            # independent problems: every rank transforms its own Np points; sharded components: the job is ONE transform of Np points
+            "value": jobs * Np * steps / dt1, "ms_per_step": dt1 / steps * 1e3,
+            "type1": {"stages_ms": st1, "exec_only_pts_per_s": Np / (exec1_ms * 1e-3), "with_set_points_pts_per_s": jobs * Np * steps / dt1},
+            "type2": {"stages_ms": st2, "exec_only_pts_per_s": Np / (exec2_ms * 1e-3), "with_set_points_pts_per_s": jobs * Np * steps / dt2,
                       "ms_per_step": dt2 / steps * 1e3},
             "workspace_bytes": int(plan.info().workspace_bytes),       # plan-owned device memory with this point set in place
             "ring_column": [int(info.ring_column[0]), int(info.ring_column[1])], "ring_segments": int(info.ring_segments),
@@ -349,6 +367,7 @@ def main():
 
     P = prepare(cfg)
     Np, Cn, is_complex, real_bytes = P["Np"], P["Cn"], P["is_complex"], P["real_bytes"]
+    P_sharded, C_total = bool(P.get("sharded")), P["C_total"]
     head = measure(P, a.evalmode, steps, True)
     other = measure(P, "fast" if a.evalmode == "direct" else "direct", steps, True) if full else None
 
@@ -415,7 +434,7 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if P_sharded else "weak",
         "vs_baseline": None,
         "dtype": {"float64": "f64", "float32": "f32", "complex64": "c64 (f32 arithmetic and accumulation, as the reference)", "complex128": "c128"}[cfg["Z"]],
         "data": "synthetic",
@@ -425,7 +444,9 @@ def main():
             "protocol": "set_points! + exec_type1! per step, inputs resident in HBM (reference benchmark protocol)",
             "spread_engine": head["spread_engine"], "spread_tile": head["spread_tile"], "interp_tile": head["interp_tile"],
             "ring_column": head["ring_column"], "ring_segments": head["ring_segments"], "workspace_bytes": head["workspace_bytes"],
-            "parallelism": f"{world} independent plan(s), one per GPU" + ("" if not distributed or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
+            "parallelism": (f"ntransforms = {C_total} components of one transform sharded over {world} GPU(s) (component c on rank c mod N, same points)"
+                            if P_sharded else f"{world} independent plan(s), one per GPU")
+                           + ("" if not distributed or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
         },
         "roofline": roofline,
         "type1": head["type1"], "type2": head["type2"],
