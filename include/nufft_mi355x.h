@@ -260,7 +260,8 @@ int nufft_get_stage_times(nufft_plan* plan, float* ms_out);
 int nufft_spread_engine_used(nufft_plan* plan, int* engine_out, void* stream);
 /* The same for the interpolation stage of nufft_exec_type2: NUFFT_INTERP_LDS_TILES (padded boxes, heavy tiles shared by
  * several workgroups: interp_tile_kernel) or NUFFT_INTERP_MARCHING_RING (3-D plans with the default window evaluation,
- * point sets whose tiles needed no slices: interp_march_kernel).  Replaces nothing in the reference — its
+ * point sets whose heaviest ring task and total work stay within the ring's measured advantage over the tile kernel:
+ * interp_march_kernel).  Replaces nothing in the reference — its
  * interpolate! (src/interpolation/gpu.jl:3-89) has one shared-memory kernel; inspection only. */
 enum { NUFFT_INTERP_LDS_TILES = 1, NUFFT_INTERP_MARCHING_RING = 2 };
 int nufft_interp_engine_used(nufft_plan* plan, int* engine_out, void* stream);

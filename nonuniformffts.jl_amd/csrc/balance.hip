@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx,
     }
     if (lane == 0) {
         colsum[c] = total;
-        atomicMax(&choice[3], heaviest);
+        atomicMax(&choice[6], heaviest);                   // (its own word: choice[3] is the equal-length-mode flag; zeroed by its reader)
     }
 }
 
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void patch_column_sums_kernel(Geom g, int npx,
 // task — uniform point sets keep exactly the partition they always had, whose tasks differ by a per cent, where quantile
 // boundaries on whole layers would make them differ by a layer's worth (9 % at 11 layers per segment) — else
 // S_c = round(T points(c) / Np) segments per column; their exclusive scan (first[c]; first[ncols] = tasks in use; the table
-// holds T + columns entries, enough for any rounding), empty entries behind.  choice[3] = 1: equal-length mode.
+// holds T + columns entries, enough for any rounding), empty entries behind.  choice[3] = 1: equal-length mode;
+// choice[6]: heaviest equal-length task of this point set (patch_column_sums_kernel), read and zeroed here.
 __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int ntasks, int ntab, int nseg, int min_seg, int max_seg, unsigned long long np,
                                                                 unsigned long long limit, unsigned long long slots_eff, int uniform_always,
                                                                 const uint32_t* __restrict__ colsum, uint32_t* __restrict__ first,
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int 
     if (tid == 0) {
         carry = 0;
         const double mean = (double)np / (double)ntasks;
-        const uint32_t heaviest = choice[3];
+        const uint32_t heaviest = choice[6];
+        choice[6] = 0u;                                    // the next set_points starts its maximum from zero
         uniform_mode = (double)heaviest <= 1.1 * mean + 5.0 * sqrt(mean) + 8.0;
         choice[3] = uniform_mode ? 1u : 0u;
         if (uniform_mode) {
@@ -488,11 +490,13 @@ hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int c
 hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, int cus, double advantage,
                               uint32_t* choice, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
     const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(cus, ct.ntasks));
-    const unsigned long long limit = (unsigned long long)(advantage * (double)np / (double)cus) + 64ull;
+    // advantage <= 0: always the ring (a limit that no product with slots_eff can overflow)
+    const bool always = advantage <= 0.0;
+    const unsigned long long limit = always ? ~0ull / (slots_eff + 1ull) : (unsigned long long)(advantage * (double)np / (double)cus) + 64ull;
     // tasks of equal point count: x 0.85 for what the estimate leaves out (per-task window loads, the scheduling tail —
     // folded N(0, 1) points at 0.3 points per cell: the ring takes 1.27x its time for uniform points)
-    const unsigned long long limit_cut = (unsigned long long)(0.85 * advantage * (double)np / (double)cus) + 64ull;
-    return launch_column_tasks(g, ct, offsets, np, limit, limit_cut, slots_eff, false, choice, nullptr, colsum, first, tasktab, stream);
+    const unsigned long long limit_cut = always ? limit : (unsigned long long)(0.85 * advantage * (double)np / (double)cus) + 64ull;
+    return launch_column_tasks(g, ct, offsets, np, limit, limit_cut, slots_eff, always, choice, nullptr, colsum, first, tasktab, stream);
 }
 
 // The same for the z-marching spreading ring (smarch_kernels.h): a task is a workgroup that owns a column for a segment of bin

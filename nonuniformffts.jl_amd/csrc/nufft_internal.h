@@ -110,6 +110,8 @@ struct nufft_plan {
     std::vector<int64_t> index_map[3];
     nufft::TileGeom tile;
     bool interp_march = false;         // the z-marching interpolation kernel may serve point sets of this plan (march_kernels.h)
+    int interp_march_mode = 1;         // NUFFT_INTERP_MARCH latched at plan creation: 0 off, 1 per point set (fitted model), 2 always
+    bool debug_tasks = false;          // NUFFT_DEBUG_TASKS latched at plan creation: host check of the task tables after set_points
     nufft::ColumnTasks march_ct{};     // ... its columns and evenly cut tasks
     int num_cus = 256;                 // compute units of the device (one ring workgroup per CU)
     uint32_t* d_march_choice = nullptr;   // [8]: scratch of the task kernels (balance.hip); [2] = 1: the ring serves this point set

@@ -551,9 +551,13 @@ static int build_device(nufft_plan* p) {
         NUFFT_HIP(prepare_interp(p->dtype, p->is_complex, D, p->M, (int)p->lds_interp, other != 0));
     }
 
-    // second interpolation engine (z-marching ring, march_kernels.h): 3-D plans with the default window evaluation, when
-    // the balance pass exists (its slot count is the per-point-set switch); NUFFT_INTERP_MARCH=0: off (A/B runs)
-    p->interp_march = env_int("NUFFT_INTERP_MARCH", 1) != 0 && p->balance_enabled &&
+    // second interpolation engine (z-marching ring, march_kernels.h): 3-D plans with the default window evaluation.  Which of
+    // the two kernels gathers a point set is decided on the device at set_points (heaviest ring task and total work against the
+    // ring's fitted advantage over the tile kernel: balance.hip, d_march_choice[2]); the mode is latched here —
+    // NUFFT_INTERP_MARCH = 0: never the ring (A/B runs), 2: always (tests of its instantiations on small grids)
+    p->interp_march_mode = env_int("NUFFT_INTERP_MARCH", 1);
+    p->debug_tasks = env_int("NUFFT_DEBUG_TASKS", 0) != 0;
+    p->interp_march = p->interp_march_mode != 0 &&
                       interp_march_available(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
     if (p->interp_march) {
         NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M));
@@ -1119,12 +1123,12 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         // (NUFFT_INTERP_MARCH=2: always the ring — tests of its instantiations on small grids)
         const double rho = (double)np / (double)std::max<int64_t>(p->grid_elems, 1), mr = (double)p->M / 4.0;
         const double fitted = (rho + 0.038 * std::pow(mr, 1.85)) / (1.09 * rho + 0.0086 * std::pow(mr, 1.2));
-        const double advantage = env_int("NUFFT_INTERP_MARCH", 1) == 2 ? 1e12 : fitted;
+        const double advantage = p->interp_march_mode == 2 ? 0.0 : fitted;      // (<= 0: always the ring)
         const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
         NUFFT_HIP(launch_march_tasks(s.g, p->march_ct, p->d_offsets, np, p->num_cus, advantage, p->d_march_choice, p->d_march_cols,
                                      p->d_march_cols + ncols, static_cast<uint2*>(p->d_march_tasks), stream));
     }
-    if (env_int("NUFFT_DEBUG_TASKS", 0) != 0) {
+    if (p->debug_tasks) {
         // development check: every column's tasks tile [0, nb[2]) without gaps or overlaps
         auto check = [&](const char* name, const ColumnTasks& ct, const void* tab, const uint32_t* choice) {
             const size_t ncols = (size_t)ct.ncolx * ct.ncoly, ntab = (size_t)column_task_table_entries(ct, p->tile.nb[2]);

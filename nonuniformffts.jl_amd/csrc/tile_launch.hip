@@ -323,8 +323,8 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         }
     }
     if (!fn) return hipErrorInvalidValue;
-    // z-marching interpolation: launched next to the tile kernel; the slot count set_points left on the device decides
-    // which of the two finds work (no sliced tile: the marching kernel)
+    // z-marching interpolation: launched next to the tile kernel; the flag set_points left on the device (heaviest ring task
+    // and total work against the ring's advantage limit, balance.hip) decides which of the two finds work
     const bool march = interp && a.march != 0 && !other;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;

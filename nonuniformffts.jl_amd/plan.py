@@ -322,7 +322,8 @@ class PlanNUFFT:
 
     def interp_engine_used(self) -> str:
         """Engine that interpolates the point set of the last set_points in exec_type2: "lds_tiles" or "marching_ring"
-        (decided on the device: the ring serves point sets whose tiles needed no slices); synchronises."""
+        (decided on the device at set_points: the ring serves a point set while its heaviest task and its total work stay
+        within the ring's measured advantage over the tile kernel); synchronises."""
         out = C.c_int(0)
         _check(lib.nufft_interp_engine_used(self._handle, C.byref(out), self._stream()))
         return {1: "lds_tiles", 2: "marching_ring"}[out.value]

@@ -14,6 +14,8 @@ def _exe():
     if not os.path.exists(EXE):
         import __graft_entry__ as g
         g.build()
+    if not os.path.exists(EXE):
+        pytest.skip("tests/c_abi_smoke could not be built on this machine (no C compiler / ROCm headers)")
     return EXE
 
 

@@ -47,8 +47,9 @@ def test_random_configuration(seed):
     big_window = kid in (O.KERNEL_BKB, O.KERNEL_KB)
     To = np.float64 if (T == np.float64 or (big_window and D * M >= 18)) else np.float32
     try:
-        oplan64 = O.OraclePlan(dims, is_real=is_real, dtype=To, M=M, sigma=sigma, evalmode=mode, ntransforms=C,
-                               kernel=kid, fftshift=fftshift)
+        # (Float64 oracle for a Float32 plan: the points are located in Float32 exactly as the plan does, coord_dtype)
+        oplan64 = O.OraclePlan(dims, is_real=is_real, dtype=To, coord_dtype=(T if To != T else None), M=M, sigma=sigma, evalmode=mode,
+                               ntransforms=C, kernel=kid, fftshift=fftshift)
     except ValueError:
         pytest.skip("oversampled size below 2M")
     Np = int(rng.integers(1, 3000))
@@ -66,7 +67,7 @@ def test_random_configuration(seed):
                            kernel_evalmode=nufft.Direct() if mode == O.DIRECT else nufft.FastApproximation(),
                            backend=nufft.ROCBackend(0))
     assert plan.oversampled_dims == oplan64.Nover
-    O.set_points(oplan64, [x.astype(To) for x in xs])
+    O.set_points(oplan64, [x.astype(To) for x in xs] if To == T else xs)
     dev = plan.device
     nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
     us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
@@ -76,14 +77,13 @@ def test_random_configuration(seed):
     v64 = [v.astype(cT if not is_real else To) for v in vs]
     ref = O.exec_type1(oplan64, v64 if C > 1 else v64[0])
     ref = ref if C > 1 else [ref]
-    # Float64: 1e-7; Float32 vs Float32 oracle: 1e-5 of test/pseudo_gpu.jl:159-171 times a few (sums of up to 3000
-    # Float32 terms in different orders); Float32 vs Float64 oracle: coordinate rounding enters the phase
-    tol = 1e-7 if T == np.float64 else (5e-5 if To == np.float32 else 3e-4)
-    if dist == "edges" and T == np.float32 and To == np.float64:
-        pytest.skip("boundary points in Float32 against the Float64 oracle: either side of the period is valid")
+    # the reference's own bounds (test/pseudo_gpu.jl:159-171): 1e-7 Float64, 1e-5 Float32 — measured over all seeds (NUFFT_TEST_ERRLOG):
+    # Float32 at most 3.8e-6 (the wide-window case compares with the Float64 oracle that locates the points in Float32)
+    tol = 1e-7 if T == np.float64 else 1e-5
     for c in range(C):
         denom = np.linalg.norm(ref[c].ravel())
         err = np.linalg.norm((us[c].cpu().numpy() - ref[c]).ravel())
+        _log_error("small", seed, T, To, err / max(denom, 1e-30), (dims, M, sigma, kname, mode, str(Zt), dist, "type 1"))
         assert err <= tol * max(denom, 1e-30), (dims, M, sigma, kname, mode, Zt, dist)
     ws = [(rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)).astype(np.complex64 if T == np.float32 else np.complex128)
           for _ in range(C)]
@@ -96,7 +96,16 @@ def test_random_configuration(seed):
     for c in range(C):
         denom = np.linalg.norm(np.asarray(ref2[c]).ravel())
         err = np.linalg.norm((out[c].cpu().numpy() - ref2[c]).ravel())
+        _log_error("small", seed, T, To, err / max(denom, 1e-30), (dims, M, sigma, kname, mode, str(Zt), dist, "type 2"))
         assert err <= tol * max(denom, 1e-30), (dims, M, sigma, kname, mode, Zt, dist)
+
+
+def _log_error(kind, seed, T, To, err, what):
+    """NUFFT_TEST_ERRLOG=<file>: append the measured relative error of every Float32 comparison (soak / tolerance audits)."""
+    path = os.environ.get("NUFFT_TEST_ERRLOG")
+    if path and T == np.float32:
+        with open(path, "a") as fh:
+            fh.write(f"{kind} seed={seed} oracle={'f32' if To == np.float32 else 'f64'} err={err:.3e} {what}\n")
 
 
 def _draw_large(rng):
@@ -172,9 +181,10 @@ def test_random_configuration_large_3d(seed, monkeypatch):
     vo = [v.astype(wide_c if not is_real else (np.float64 if wide else T)) for v in vs]
     ref = O.exec_type1(oplan, vo if C > 1 else vo[0])
     ref = ref if C > 1 else [ref]
-    tol = 1e-7 if T == np.float64 else 5e-5             # (Float32: sums of thousands of Float32 terms in different orders)
+    tol = 1e-7 if T == np.float64 else 1e-5             # the reference's bounds (test/pseudo_gpu.jl:159-171); Float32 measured <= 3.2e-6 over all seeds
     for c in range(C):
         err = np.linalg.norm(us[c].cpu().numpy().astype(np.complex128) - ref[c]) / np.linalg.norm(ref[c])
+        _log_error("large", seed, T, np.float64 if wide else T, err, (dims, M, sigma, mode, str(Zt), C, dist, engine, "type 1"))
         assert err < tol, (seed, M, sigma, dims, Z, mode, C, dist, engine, err)
     ws = [(rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)).astype(np.complex64 if T == np.float32 else np.complex128)
           for _ in range(C)]
@@ -186,4 +196,5 @@ def test_random_configuration_large_3d(seed, monkeypatch):
     ref2 = ref2 if C > 1 else [ref2]
     for c in range(C):
         err = np.linalg.norm(out[c].cpu().numpy() - ref2[c]) / np.linalg.norm(ref2[c])
+        _log_error("large", seed, T, np.float64 if wide else T, err, (dims, M, sigma, mode, str(Zt), C, dist, engine, "type 2"))
         assert err < tol, (seed, M, sigma, dims, Z, mode, C, dist, engine, "type 2", err)
