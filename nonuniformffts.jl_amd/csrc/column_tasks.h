@@ -23,6 +23,7 @@ struct SMarchPlan {
     bool eligible;
     int n1, n2;                 // column interior chosen for this grid (multiples of the bin edge, <= the kernel's compile-time column)
     int hlo, hhi;               // layers of points a segment visits below / above its own
+    int halo;                   // 0: columns clipped in x and y; 1: input-driven in x (halo in LDS, atomics bands); 2: in x and y
     int lds_bytes, threads;
     ColumnTasks ct;             // columns and evenly cut tasks
     double visits, efficiency;  // model: point visits per point, and the share of the chip the launch keeps busy

@@ -141,8 +141,9 @@ hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* so
 
 // ---- spreading on the z-marching LDS ring (smarch_kernels.h, smarch_*.hip) -------------------------------------------
 // 3-D plans with 4-cell bins and the default window evaluation whose axes are long enough; cus: compute units, C: components
-SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C);
-hipError_t prepare_spread_march(int dtype, int is_complex, int M);
+// halo: 0 = output-driven in x and y, 1 = input-driven in x, 2 = input-driven in x and y (smarch_kernels.h)
+SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo);
+hipError_t prepare_spread_march(int dtype, int is_complex, int M, int halo);
 // flag: device flag of set_points (1: the ring serves this point set); tasktab: its task table
 hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream);
 // set_points: tasks of the ring for this point set and whether it serves it (advantage <= 0: always)

@@ -358,7 +358,8 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         // M = 6: 10.8 / 15.5 / 13.2; M = 7: 20.1 against 13.4 patches), ntransforms components one after the other (C = 3: 7.3 ms
         // against 7.5 with the planar patches); ComplexF64 up to M = 4 (5.06 against 5.36 patches), ComplexF32 up to M = 3 (M = 4:
         // 4.71 against 4.10 patches).  256 CUs assumed here, build_device() redoes the decomposition for the device.
-        p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C);
+        p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C,
+                                env_int("NUFFT_SMARCH_HALO", 0));
         if (req == NUFFT_SPREAD_MARCHING_RING && !p->smarch.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = marching ring needs a 3-D grid of 4-cell bins with every oversampled axis a multiple "
                                                "of 4 and longer than a column plus a stencil, and the default window evaluation");
@@ -593,9 +594,9 @@ static int build_device(nufft_plan* p) {
         hipDeviceProp_t prop;
         NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
         p->num_cus = prop.multiProcessorCount;
-        p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C);
+        p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C, p->smarch.halo);
         if (!p->smarch.eligible) return fail(NUFFT_ERR_UNSUPPORTED, "marching-ring spreading: no decomposition for this device");
-        NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M));
+        NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M, p->smarch.halo));
         const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_choice), 8 * sizeof(uint32_t)))) return rc;
         NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 8 * sizeof(uint32_t)));

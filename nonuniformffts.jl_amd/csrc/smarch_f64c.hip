@@ -1,5 +1,7 @@
-// spread_march_kernel instantiations for (double, complex = true): one per half-support M.
+// spread_march_kernel instantiations for (double, complex = true): one per half-support M, halo variant and evaluation mode.
 #define NUFFT_T double
 #define NUFFT_CPLX true
+#define NUFFT_CPLX_IS_TRUE 1
 #define NUFFT_SMARCH_GETTER smarch_kernel_f64c
+#define NUFFT_SMARCH_ZERO smarch_zero_bands_f64
 #include "smarch_inst.h"

@@ -24,6 +24,16 @@
 // their group lanes — and LDS offset reach the accumulation as three v_readlane: 22 vector and ~8 scalar instructions
 // per point visit besides the eight atomics.
 //
+// Halo variants (template flags HX, HY; round 4b).  The column above is OUTPUT-driven in x and y: it holds its own cells only and
+// visits every point whose stencil reaches them (1.49 visits per point at 32 x 32).  With HX (HY) the window also holds the
+// stencil reach beyond the column in x (y) and the column visits only ITS OWN points there — every point is spread exactly
+// once along that dimension, unclipped — and the cells within the stencil's reach of a column boundary (the halo and the
+// band of own cells the neighbours reach) leave with global float atomics onto a band that smarch_zero_bands_kernel has
+// zeroed, the other cells with plain stores as before.  In x the halo is free in LDS (the bank-aligned row stride of a
+// 32-cell column is 40 cells: exactly 32 + 2M); in y it costs 2M - 1 rows.  MEASURED AND NOT BUILT BY DEFAULT: with plain stores in
+// place of the atomics (wrong sums, timing only) the HX + HY kernel takes 1.94 ms at C2 against 2.44 ms, but the 1.2e8 band
+// atomics per launch run at 66 G/s (kernel 3.71 ms) and the banded zero fill costs 0.31 ms: -DNUFFT_SMARCH_HALO_VARIANTS.
+//
 // Tasks: column x segment of bin layers from the table set_points builds per point set on the device (balance.hip):
 // equal-length segments for uniform sets, column quantiles otherwise; point sets whose heaviest task would hold the chip
 // up — and grids with too few columns — go to spread_tile_kernel, which shares heavy tiles between workgroups (device
@@ -45,7 +55,7 @@ namespace nufft {
 #define NUFFT_SMARCH_ABL 0          // ablation builds: 1 = no LDS atomics, 2 = no point visits, 3 = no retire stores, 4 = no shift
 #endif
 
-template <typename T, bool CPLX, int M>
+template <typename T, bool CPLX, int M, bool HX = false, bool HY = false>
 struct SMarchCfg {
     static constexpr int NC = CPLX ? 2 : 1;
     static constexpr int L = 2 * M;
@@ -62,7 +72,11 @@ struct SMarchCfg {
     static constexpr bool FAST = !CPLX && M == 4;
     static constexpr int strip_bytes() { return round_up(GP::PPW * 3 * L * (int)sizeof(T), 16); }
     static constexpr int fixed_bytes() { return NW * strip_bytes() + 64; }
-    static constexpr int row_stride(int n1) { return padded_row_stride(NC * n1, NC * L, 8); }
+    // window = column + the stencil's reach where the dimension is input-driven: XLO cells below (M - 1 rounded up to even, so
+    // that pairs of cells stay 16-byte aligned in the grid) and M above in x; M - 1 rows below and M above in y
+    static constexpr int XLO = HX ? ((M - 1) + ((M - 1) & 1)) : 0, XHI = HX ? M : 0;
+    static constexpr int YLO = HY ? (M - 1) : 0, YHI = HY ? M : 0;
+    static constexpr int row_stride(int n1) { return padded_row_stride(NC * (n1 + XLO + XHI), NC * L, 8); }
     struct Dims { int n1, n2; };
     static constexpr int bin_rows(int n) { return tile_bin_rows_bound(true, n, 4, M); }
     // column interior (n1, n2): multiples of the bin edge, fewest point visits within the LDS budget
@@ -71,15 +85,17 @@ struct SMarchCfg {
         double best_cost = 1e300;
         for (int n2 = 4; n2 <= 64; n2 += 4)
             for (int n1 = 4; n1 <= 64; n1 += 4) {
-                const long bytes = (long)row_stride(n1) * n2 * RZ * 8 + fixed_bytes();
+                const long bytes = (long)row_stride(n1) * (n2 + YLO + YHI) * RZ * 8 + fixed_bytes();
                 if (bytes > 163840 - 256) continue;
                 if (2 * bin_rows(n2) > kMaxRuns) continue;
-                // visits per point on a 512-cell axis (the partial last column counts)
-                auto axis = [](int n) {
+                // visits per point on a 512-cell axis (the partial last column counts); input-driven dimensions: 1, and the
+                // share of cells that leave with atomics instead (weighted as a fifth of a visit)
+                auto axis = [](int n, bool halo) {
                     const int full = 512 / n, rest = 512 - full * n;
+                    if (halo) return 1.0 + 0.2 * (double)((full + (rest ? 1 : 0)) * (L - 1)) / 512.0;
                     return (double)(full * (n + L - 1) + (rest ? rest + L - 1 : 0)) / 512.0;
                 };
-                double cost = axis(n1) * axis(n2);
+                double cost = axis(n1, HX) * axis(n2, HY);
                 cost -= 1e-6 * n1;
                 if (cost < best_cost) { best_cost = cost; best = Dims{n1, n2}; }
             }
@@ -89,7 +105,8 @@ struct SMarchCfg {
     static constexpr int N1 = DIMS.n1, N2 = DIMS.n2;
     static constexpr bool FITS = N1 > 0;
     static constexpr int RS = FITS ? row_stride(N1) : 2;    // row stride in doubles
-    static constexpr int PS = RS * (FITS ? N2 : 2);         // plane stride in doubles
+    static constexpr int WY = (FITS ? N2 : 2) + YLO + YHI;  // rows of the window
+    static constexpr int PS = RS * WY;                      // plane stride in doubles
     static constexpr int PSB = PS * 8;                      // ... in bytes
     static constexpr int RING_BYTES = round_up(RZ * PSB, 16);
     static constexpr int lds_bytes() { return RING_BYTES + fixed_bytes(); }
@@ -140,9 +157,38 @@ __device__ __forceinline__ void smarch_add_four(const uint32_t (&vb)[C::NBASE], 
     }
 }
 
-template <typename T, bool CPLX, int M, bool POLY>
+// Cells of a column that leave with atomics (and must be zero before the launch): the halo and the own cells within the
+// stencil's reach of a neighbour, at the granularity of aligned pairs of cells.  l: index relative to the column's first
+// cell, n: cells of the column (its last one may be shorter), M: half support.
+__device__ __forceinline__ bool smarch_band(int l, int n, int M) {
+    return (l & ~1) < M || (l | 1) >= n - (M - 1);
+}
+
+// Zero fill of the bands (one thread per aligned pair of reals along x; `plane_pairs` pairs per plane of the grid).  Only when
+// the ring serves the point set.
+template <typename T>
+__global__ __launch_bounds__(256) void smarch_zero_bands_kernel(T* grid, int64_t comp_stride, Geom g, int nc, int n1, int n2, int hx, int hy, int M,
+                                                               const uint32_t* flag) {
+    if (*flag == 0u) return;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    const int row_pairs = g.Nover[0] * nc / 2;
+    const int64_t rows = (int64_t)g.Nover[1] * g.Nover[2];
+    T* gr = grid + (int64_t)blockIdx.y * comp_stride;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int y = (int)(row % g.Nover[1]);
+        const int ty = y / n2, ly = y - ty * n2, ny = min(n2, g.Nover[1] - ty * n2);
+        const bool by = hy && (ly < M || ly >= ny - (M - 1));
+        for (int xp = threadIdx.x; xp < row_pairs; xp += blockDim.x) {
+            const int x = 2 * xp / nc;
+            const int tx = x / n1, lx = x - tx * n1, nx = min(n1, g.Nover[0] - tx * n1);
+            if (by || (hx && smarch_band(lx, nx, M))) *reinterpret_cast<T2*>(gr + row * g.Nover[0] * nc + 2 * xp) = T2{T(0), T(0)};
+        }
+    }
+}
+
+template <typename T, bool CPLX, int M, bool POLY, bool HX = false, bool HY = false>
 __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, MarchGeom mg) {
-    using C = SMarchCfg<T, CPLX, M>;
+    using C = SMarchCfg<T, CPLX, M, HX, HY>;
     using GP = typename C::GP;
     using WE = WindowEval<T, C::NC, 3, M, GP::G, false>;
     constexpr int NC = C::NC, L = C::L, RZ = C::RZ, RS = C::RS, PS = C::PS, PSB = C::PSB;
@@ -163,6 +209,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     // the column of this grid: mg.n1 x mg.n2 <= N1 x N2 cells (plan creation picks what fills the chip best)
     const int org1 = tx * mg.n1, org2 = ty * mg.n2;
     const int neff1 = min(mg.n1, g.Nover[0] - org1), neff2 = min(mg.n2, g.Nover[1] - org2);
+    // the window in LDS: the column, plus the stencil's reach in the input-driven dimensions
+    const int wx0 = org1 - C::XLO, wy0 = org2 - C::YLO;         // first cell of the window (may be negative: periodic)
+    const int wnx = neff1 + C::XLO + C::XHI, wny = neff2 + C::YLO + C::YHI;
     const int nlay = zb1 - zb0;
     const int nq = 4 * nlay;                            // planes this task owns: q = 0 .. nq - 1 (plane 4 zb0 + q of the grid)
     const int nli = nlay + HLO + HHI;                   // layers of points it visits
@@ -175,8 +224,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     //      its first bin within a layer of bins and its length (lanes >= nruns: an empty run) ----
     uint32_t rb_bin = 0u, rb_len = 0u;
     {
-        const BinSegs seg0 = bin_segments(org1 - M, org1 + neff1 + M - 1, g.Nover[0], 2, g.nb[0]);
-        const BinSegs seg1 = bin_segments(org2 - M, org2 + neff2 + M - 1, g.Nover[1], 2, g.nb[1]);
+        // (an input-driven dimension visits the column's own bins only: one run, no periodic image)
+        const BinSegs seg0 = HX ? bin_segments(org1, org1 + neff1, g.Nover[0], 2, g.nb[0]) : bin_segments(org1 - M, org1 + neff1 + M - 1, g.Nover[0], 2, g.nb[0]);
+        const BinSegs seg1 = HY ? bin_segments(org2, org2 + neff2, g.Nover[1], 2, g.nb[1]) : bin_segments(org2 - M, org2 + neff2 + M - 1, g.Nover[1], 2, g.nb[1]);
         const int nruns = seg1.total() * seg0.n;        // <= kMaxRuns (SMarchCfg::search)
         if (lane < nruns) {
             const int sg = lane % seg0.n, r2 = lane / seg0.n;
@@ -270,11 +320,13 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             for (int d = 0; d < 2; ++d) {
                 const int c = cell_of(rec.r[d], g.Nover[d]);
                 X[d] = rec.r[d] - T(c);
-                int sd = c - (M - 1) - (d == 0 ? org1 : org2);      // first stencil node in column coordinates
-                const int ne = d == 0 ? neff1 : neff2;
-                if (sd > ne - 1) sd -= g.Nover[d];                  // periodic image next to this column
-                if (sd < -(L - 1)) sd += g.Nover[d];
-                ok = ok && (sd >= -(L - 1)) && (sd <= ne - 1);
+                int sd = c - (M - 1) - (d == 0 ? wx0 : wy0);        // first stencil node in window coordinates
+                if ((d == 0 && !HX) || (d == 1 && !HY)) {           // output-driven: clipped to the column
+                    const int ne = d == 0 ? neff1 : neff2;
+                    if (sd > ne - 1) sd -= g.Nover[d];              // periodic image next to this column
+                    if (sd < -(L - 1)) sd += g.Nover[d];
+                    ok = ok && (sd >= -(L - 1)) && (sd <= ne - 1);
+                }                                                   // (input-driven: the point's own column, 0 <= sd, sd + L <= window)
                 s[d] = sd;
             }
             const int c3 = cell_of(rec.r[2], g.Nover[2]);
@@ -287,9 +339,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             // the point's LDS offset: stencil start in x, y and the slot of its first plane
             const uint32_t soff = (uint32_t)((s[0] * NC + s[1] * RS + dz * PS) * 8);
             unsigned long long lmask = 0ull;            // FAST: lanes (j1, j2) of the 8 x 8 face inside the column
-            if constexpr (FAST) {
-                const int lo1 = min(L, max(0, -s[0])), hi1 = max(lo1, min(L, neff1 - s[0]));    // (a point that misses the column: empty ranges)
-                const int lo2 = min(L, max(0, -s[1])), hi2 = max(lo2, min(L, neff2 - s[1]));
+            if constexpr (FAST && !(HX && HY)) {
+                const int lo1 = HX ? 0 : min(L, max(0, -s[0])), hi1 = HX ? L : max(lo1, min(L, neff1 - s[0]));    // (a point that misses the column: empty ranges)
+                const int lo2 = HY ? 0 : min(L, max(0, -s[1])), hi2 = HY ? L : max(lo2, min(L, neff2 - s[1]));
                 const uint32_t m1 = ((1u << hi1) - 1u) & ~((1u << lo1) - 1u);
                 const uint32_t col = m1 * 0x01010101u;
                 const unsigned long long rows = hi2 > lo2 ? (~0ull >> (64 - 8 * (hi2 - lo2))) << (8 * lo2) : 0ull;
@@ -326,7 +378,16 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                     const int lo3 = max(0, -Q0), hi3 = min(L, nq - Q0);
                     planes = ((1u << hi3) - 1u) & ~((1u << lo3) - 1u);
                 }
-                if constexpr (FAST) {
+                if constexpr (FAST && HX && HY) {
+                    // every lane of the 8 x 8 face lies inside the window: no mask
+                    const T w = w1v[0] * w2v[0];
+                    uint32_t vb[C::NBASE];
+#pragma unroll
+                    for (int b = 0; b < C::NBASE; ++b) vb[b] = lane_addr[0] + so + (uint32_t)(b * C::PLB * PSB);
+                    T w3[L];
+                    row_bcast_all(w3a, w3, 0, std::make_integer_sequence<int, L>{});
+                    smarch_add_planes<C, CLIPZ>(vb, w, w3, planes, std::make_integer_sequence<int, L>{});
+                } else if constexpr (FAST) {
                     const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lmask, src);
                     const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(lmask >> 32), src);
                     const T w = w1v[0] * w2v[0];
@@ -353,7 +414,7 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
 #pragma unroll
                     for (int ps = 0; ps < NPASS; ++ps) {
                         const int l1 = S1 + j1f[ps], l2 = S2 + j2f[ps];
-                        const bool lane_ok = actf[ps] && (unsigned)l1 < (unsigned)neff1 && (unsigned)l2 < (unsigned)neff2;
+                        const bool lane_ok = actf[ps] && (HX || (unsigned)l1 < (unsigned)neff1) && (HY || (unsigned)l2 < (unsigned)neff2);
                         const T w = w1v[ps] * (CPLX ? (cmpf[ps] ? Vim : Vre) : Vre) * w2v[ps];
                         uint32_t vb[C::NBASE];
 #pragma unroll
@@ -442,40 +503,40 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         {
             typedef double D2 __attribute__((ext_vector_type(2)));
             typedef T T2 __attribute__((ext_vector_type(2)));
-            const int rp = NC * neff1 / 2;              // pairs per row
-            const int npair = neff2 * rp;
+            const int rp = NC * wnx / 2;                // pairs per row of the window
+#if NUFFT_SMARCH_ABL == 7
+            const int npair = 0;
+#else
+            const int npair = wny * rp;
+#endif
             for (int e = tid; e < npair; e += THREADS) {
                 const int r = e / rp, xp = e - r * rp;
                 D2* pos = reinterpret_cast<D2*>(ring + r * RS + 2 * xp);
-#if defined(NUFFT_SMARCH_RETIRE_V1)
-                {
-                    D2 v[RZ];
-#pragma unroll
-                    for (int k = 0; k < RZ; ++k) v[k] = pos[k * (PS / 2)];
-#pragma unroll
-                    for (int k = 0; k < RZ; ++k) pos[k * (PS / 2)] = k + 4 < RZ ? v[k + 4] : D2{0.0, 0.0};
-                    const int64_t rowb = ((int64_t)(org2 + r) * g.Nover[0] + org1) * NC + 2 * xp;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int qq = wq + k;
-                        if (qq >= 0 && qq < nq)
-                            *reinterpret_cast<T2*>(grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb) = T2{(T)v[k].x, (T)v[k].y};
-                    }
-                }
-                continue;
-#endif
                 // the four finished planes leave first, then the others move down (fewer values live at a time)
                 {
                     D2 v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = pos[k * (PS / 2)];
 #if NUFFT_SMARCH_ABL != 3
-                    const int64_t rowb = ((int64_t)(org2 + r) * g.Nover[0] + org1) * NC + 2 * xp;
+                    // the cell pair in the grid (the window wraps around the periodic axes), and how it leaves: cells within the
+                    // stencil's reach of a column boundary of an input-driven dimension also receive the neighbours' sums ->
+                    // atomics onto the zeroed band (smarch_zero_bands_kernel), everything else plain stores
+                    const int lx = 2 * xp / NC - C::XLO, ly = r - C::YLO;          // relative to the column's first cell
+                    const int gx = wrap_index(org1 + lx, g.Nover[0]), gy = wrap_index(org2 + ly, g.Nover[1]);
+                    const bool atomic = (HX && smarch_band(lx, neff1, M)) || (HY && (ly < M || ly >= neff2 - (M - 1)));
+                    const int64_t rowb = ((int64_t)gy * g.Nover[0] + gx) * NC + (2 * xp) % NC;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int qq = wq + k;
-                        if (qq >= 0 && qq < nq)         // (plane 4 zb0 + qq < Nover[2]: the task owns it)
-                            *reinterpret_cast<T2*>(grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb) = T2{(T)v[k].x, (T)v[k].y};
+                        if (qq >= 0 && qq < nq) {       // (plane 4 zb0 + qq < Nover[2]: the task owns it)
+                            T* dst = grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb;
+                            if (!(HX || HY) || !atomic || NUFFT_SMARCH_ABL == 8) {
+                                *reinterpret_cast<T2*>(dst) = T2{(T)v[k].x, (T)v[k].y};
+                            } else {
+                                if (v[k].x != 0.0) (void)__hip_atomic_fetch_add(dst, (T)v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (v[k].y != 0.0) (void)__hip_atomic_fetch_add(dst + 1, (T)v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
                     }
 #else
 #pragma unroll

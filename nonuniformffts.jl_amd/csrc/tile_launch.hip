@@ -63,15 +63,20 @@ ColumnTasks march_column_tasks(int dtype, int is_complex, int M, const Geom& g) 
 }
 
 // ---- spreading on the z-marching LDS ring (smarch_kernels.h) -----------------------------------------------------------
-const void* smarch_kernel_f32r(int M, bool poly, int* lds_bytes, int* n);
-const void* smarch_kernel_f32c(int M, bool poly, int* lds_bytes, int* n);
-const void* smarch_kernel_f64r(int M, bool poly, int* lds_bytes, int* n);
-const void* smarch_kernel_f64c(int M, bool poly, int* lds_bytes, int* n);
-// poly: the instantiation with the piecewise-polynomial window (FastApproximation) or the direct one
-static const void* smarch_kernel(int dtype, int is_complex, int M, bool poly, int* lds_bytes, int* n) {
+const void* smarch_kernel_f32r(int M, int halo, bool poly, int* lds_bytes, int* n);
+const void* smarch_kernel_f32c(int M, int halo, bool poly, int* lds_bytes, int* n);
+const void* smarch_kernel_f64r(int M, int halo, bool poly, int* lds_bytes, int* n);
+const void* smarch_kernel_f64c(int M, int halo, bool poly, int* lds_bytes, int* n);
+hipError_t smarch_zero_bands_f32(void* grid, int64_t comp_stride_reals, const Geom& g, int nc, int C, int n1, int n2, int hx, int hy, int M,
+                                 const uint32_t* flag, hipStream_t stream);
+hipError_t smarch_zero_bands_f64(void* grid, int64_t comp_stride_reals, const Geom& g, int nc, int C, int n1, int n2, int hx, int hy, int M,
+                                 const uint32_t* flag, hipStream_t stream);
+// halo: 0 / 1 / 2 = output-driven / input-driven in x / in x and y; poly: the instantiation with the piecewise-polynomial window
+// (FastApproximation) or the direct one
+static const void* smarch_kernel(int dtype, int is_complex, int M, int halo, bool poly, int* lds_bytes, int* n) {
     if (M < 2 || M > 10) return nullptr;
-    if (dtype == NUFFT_F32) return is_complex ? smarch_kernel_f32c(M, poly, lds_bytes, n) : smarch_kernel_f32r(M, poly, lds_bytes, n);
-    return is_complex ? smarch_kernel_f64c(M, poly, lds_bytes, n) : smarch_kernel_f64r(M, poly, lds_bytes, n);
+    if (dtype == NUFFT_F32) return is_complex ? smarch_kernel_f32c(M, halo, poly, lds_bytes, n) : smarch_kernel_f32r(M, halo, poly, lds_bytes, n);
+    return is_complex ? smarch_kernel_f64c(M, halo, poly, lds_bytes, n) : smarch_kernel_f64r(M, halo, poly, lds_bytes, n);
 }
 
 // Launch model of the ring: blocks go to the 8 XCDs round-robin and to the first free CU there, in launch order (task table
@@ -106,15 +111,20 @@ static double smarch_makespan(const std::vector<double>& task_work, int C, int c
 // (multiples of the bin edge) and the number of segments along z that minimise  point visits / chip utilisation,
 // where visits = prod (n + 2M - 1) / n over x, y (partial last columns counted) x (segl + c_z) / segl for the layers a
 // segment visits beyond its own, and the utilisation comes from the launch model above.
-SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C) {
+SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo) {
     SMarchPlan sp{};
     int lds = 0, n[5];
-    if (D != 3 || other || !smarch_kernel(dtype, is_complex, M, true, &lds, n)) return sp;
+    if (halo < 0 || halo > 2) halo = 0;
+    sp.halo = halo;
+    if (D != 3 || other || !smarch_kernel(dtype, is_complex, M, halo, true, &lds, n)) return sp;
+    const bool hx = halo >= 1, hy = halo >= 2;
     for (int d = 0; d < 3; ++d)
         if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return sp;
     const int L = 2 * M, hlo = n[2], hhi = n[3];
     // columns shorter than the axis (a stencil then never reaches a column from both sides); enough layers for the halo
     if (8 + L - 1 > g.Nover[0] || 8 + L - 1 > g.Nover[1] || g.nb[2] < 2 * (hlo + hhi) || g.nb[2] > 2048) return sp;
+    // input-driven dimensions: the window (column + 2M) must not wrap onto itself
+    if ((hx && 8 + 2 * L > g.Nover[0]) || (hy && 8 + 2 * L > g.Nover[1])) return sp;
     static const int xcd_chunk = [] { const char* e = std::getenv("NUFFT_XCD_CHUNK"); return e && *e ? std::atoi(e) : 8; }();
     static const int force_n1 = [] { const char* e = std::getenv("NUFFT_SMARCH_N1"); return e && *e ? std::atoi(e) : 0; }();
     static const int force_n2 = [] { const char* e = std::getenv("NUFFT_SMARCH_N2"); return e && *e ? std::atoi(e) : 0; }();
@@ -129,6 +139,7 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
         for (int n1 = n[0]; n1 >= 8; n1 -= 4) {
             if (force_n1 && n1 != force_n1) continue;
             if (n1 + L - 1 > g.Nover[0] || (n1 < n[0] / 2 && n1 + 4 + L - 1 <= g.Nover[0] && !force_n1)) continue;
+            if ((hx && n1 + 2 * L > g.Nover[0]) || (hy && n2 + 2 * L > g.Nover[1])) continue;
             const int ncx = (g.Nover[0] + n1 - 1) / n1, ncy = (g.Nover[1] + n2 - 1) / n2;
             if ((int64_t)ncx * ncy >= 65536) continue;
             // relative cost of a layer of each column: the points it visits
@@ -137,7 +148,8 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
             for (int ty = 0; ty < ncy; ++ty)
                 for (int tx = 0; tx < ncx; ++tx) {
                     const int e1 = std::min(n1, g.Nover[0] - tx * n1), e2 = std::min(n2, g.Nover[1] - ty * n2);
-                    colw[(size_t)ty * ncx + tx] = (double)(e1 + L - 1) * (double)(e2 + L - 1);
+                    // (an input-driven dimension visits only the column's own points)
+                    colw[(size_t)ty * ncx + tx] = (double)(hx ? e1 : e1 + L - 1) * (double)(hy ? e2 : e2 + L - 1);
                     ideal += (double)e1 * (double)e2;
                 }
             ideal *= (double)g.nb[2] * C / cus;         // every point visited once, the chip evenly busy
@@ -172,10 +184,10 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
     return sp;
 }
 
-hipError_t prepare_spread_march(int dtype, int is_complex, int M) {
+hipError_t prepare_spread_march(int dtype, int is_complex, int M, int halo) {
     for (int poly = 0; poly < 2; ++poly) {
         int lds = 0, n[5];
-        const void* fn = smarch_kernel(dtype, is_complex, M, poly != 0, &lds, n);
+        const void* fn = smarch_kernel(dtype, is_complex, M, halo, poly != 0, &lds, n);
         if (!fn) return hipErrorInvalidValue;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -550,8 +562,16 @@ hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np
 template <typename T>
 static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
     int lds = 0, n[5];
-    const void* fn = smarch_kernel(a.dtype, a.is_complex, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
+    const void* fn = smarch_kernel(a.dtype, a.is_complex, a.M, sp.halo, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
     if (!fn) return hipErrorInvalidValue;
+    if (sp.halo > 0) {
+        // halo variants: the cells near column boundaries are accumulated with global atomics onto zeroed bands
+        const int ncr = a.is_complex ? 2 : 1;
+        hipError_t e = a.dtype == NUFFT_F32
+            ? smarch_zero_bands_f32(a.grid, a.grid_stride * ncr, a.g, ncr, a.C, sp.n1, sp.n2, sp.halo >= 1, sp.halo >= 2, a.M, flag, stream)
+            : smarch_zero_bands_f64(a.grid, a.grid_stride * ncr, a.g, ncr, a.C, sp.n1, sp.n2, sp.halo >= 1, sp.halo >= 2, a.M, flag, stream);
+        if (e != hipSuccess) return e;
+    }
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
