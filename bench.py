@@ -386,7 +386,7 @@ def main():
         binding = ("issue and latency of the per-visit point set-up at 8 waves per CU (VALU 36 %, LDS 44 %, FP64 matrix pipe 16 % "
                    "busy), not HBM: see DESIGN.md section 4.4")
     elif head["spread_engine"] == "marching_ring":
-        kname = f"spread_march_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, {'false' if head['evalmode'] == 'Direct' else 'true'}>"
+        kname = f"spread_march_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, {'false' if head['evalmode'] == 'Direct' else 'true'},"
         binding = ("the LDS atomic pipe (ds_add_f64: 8 array cycles per 64-lane wave instruction, 11.9 of them per point at 1.49 visits; "
                    "LDS array 73 % busy), then the two barriers per bin layer; not HBM: see DESIGN.md section 4.9")
     else:
