@@ -178,20 +178,6 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
     const int zbase = 4 * zb0 - (M - 1);                // first plane of the segment's first window (may be negative)
     const int o1 = org1 - (M - 1), o2 = org2 - (M - 1);
 
-    // global address of real e of plane `gz` (unwrapped) of the padded column
-    auto src_of = [&](int gz, int e) __attribute__((always_inline)) -> const T* {
-        const int r = e / RS, xx = e % RS;
-        const int64_t row = (int64_t)wrap_index(gz, g.Nover[2]) * g.Nover[1] + wrap_index(o2 + r, g.Nover[1]);
-        return grid + (row * g.Nover[0] + wrap_index(o1 + xx / NC, g.Nover[0])) * NC + xx % NC;
-    };
-    // ---- first window: RZ planes straight into the ring (plane zbase + k in slot k) ----
-    for (int e = tid; e < RZ * PS; e += kMarchThreads) {
-        const int k = e / PS;
-        int gz = zbase + k;
-        if (gz < 0) gz += g.Nover[2];
-        ring[k * PSP + e % PS] = *src_of(gz, e % PS);
-    }
-
     // lane roles: G lanes per point, lane q = (j1, component) — or j1 alone with both components per lane (PAIR)
     constexpr bool PAIR = C::PAIR;
     constexpr int NCL = PAIR ? 1 : NC;                  // components that have lanes of their own
@@ -226,6 +212,33 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
     T* vout = a.vout[comp_id];
     __syncthreads();
 
+    // Layer-invariant part of the plane prefetch: element e = tid + u * THREADS of the BZ new planes is real `el` of plane k; its
+    // offset inside a plane of the grid (periodic in x, y) and its place in an LDS plane never change from phase to phase — only
+    // the plane index does.  (Recomputing them per phase — two divisions and two periodic wraps per element — was 50 of the 184
+    // vector instructions per point at C3, where a layer of a 16 x 16 column holds only ~95 points, and 13 of 43 at C2.)
+    int pf_off[NPF], pf_el[NPF];                        // grid offset within a plane; k << 24 | el  (-1: no element)
+    const int64_t plane_reals = (int64_t)g.Nover[1] * g.Nover[0] * NC;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int e = tid + u * kMarchThreads;
+        pf_off[u] = 0;
+        pf_el[u] = -1;
+        if (e < BZ * PS) {
+            const int k = e / PS, el = e % PS, r = el / RS, xx = el % RS;
+            pf_off[u] = (wrap_index(o2 + r, g.Nover[1]) * g.Nover[0] + wrap_index(o1 + xx / NC, g.Nover[0])) * NC + xx % NC;
+            pf_el[u] = (k << 24) | el;
+        }
+    }
+    // ---- first window: RZ planes straight into the ring (plane zbase + k in slot k), BZ planes at a time with the same tables ----
+    for (int b0 = 0; b0 < RZ; b0 += BZ) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int pl = b0 + (pf_el[u] >> 24);
+            if (pf_el[u] >= 0 && pl < RZ)
+                ring[pl * PSP + (pf_el[u] & 0xffffff)] = grid[(int64_t)wrap_index(zbase + pl, g.Nover[2]) * plane_reals + pf_off[u]];
+        }
+    }
+    __syncthreads();
     constexpr int KL = C::KL;
     int pm = 0;                                         // (BZ * phase) mod RZ: slot of the first plane of the window
     const int nphase = (nlay + KL - 1) / KL;
@@ -236,12 +249,11 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
         if (more) {
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
-                const int e = tid + u * kMarchThreads;
                 pf[u] = T(0);
-                if (e < BZ * PS) {
-                    int gz = zbase + RZ + BZ * ph + e / PS;
+                if (pf_el[u] >= 0) {
+                    int gz = zbase + RZ + BZ * ph + (pf_el[u] >> 24);
                     if (gz >= g.Nover[2]) gz -= g.Nover[2];
-                    pf[u] = *src_of(gz, e % PS);
+                    pf[u] = grid[(int64_t)gz * plane_reals + pf_off[u]];
                 }
             }
         }
@@ -393,11 +405,10 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
             // the BZ new planes take the slots of the BZ oldest: slots pm .. pm + BZ - 1 (mod RZ)
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
-                const int e = tid + u * kMarchThreads;
-                if (e < BZ * PS) {
-                    int slot = pm + e / PS;
+                if (pf_el[u] >= 0) {
+                    int slot = pm + (pf_el[u] >> 24);
                     if (slot >= RZ) slot -= RZ;
-                    ring[slot * PSP + e % PS] = pf[u];
+                    ring[slot * PSP + (pf_el[u] & 0xffffff)] = pf[u];
                 }
             }
             pm += BZ;
