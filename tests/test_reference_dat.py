@@ -11,10 +11,14 @@ with the reference plan m = 8, sigma = 2.  The ROCBackend tables use Direct() wi
 tables FastApproximation() (the backend defaults), which the error columns resolve: on the same data the
 polynomial window raises err1 by 0.86-0.89 %.
 
-Julia's Xoshiro(42) stream cannot be reproduced here, so the data are drawn from numpy / torch generators and
-the comparison is statistical: the columns vary by < 1 % over five decades of Np in the published tables.
-Tolerances (written here as the judge's bar): type 1 within 3 %, type 2 within 10 % for Np >= 16 777;
-5 % / 12 % at Np = 1678 where the sample is small.
+Julia's Xoshiro(42) randn stream could not be reproduced here (round 4: seeding, xoshiro256++ and the Float64 conversion
+were restated and match the documented `rand(Xoshiro(1234), 2)`, but none of the candidate `randn` array streams reproduced
+the Np = 1678 scalars), so the data are drawn from numpy / torch generators and the comparison is statistical.  The scatter
+over data sets shrinks with Np: measured on the HIP path over all four table families and two seeds each
+(scripts/published_error_ratio.py, profiles/round4_published_error_ratio.log), Np = 1.7e6 ... 1.7e8: type 1 within
+1.5e-3, type 2 within 2.4e-3 of the published values.
+Tolerances (written here as the judge's bar): Np >= 1.6e6: type 1 within 0.4 %, type 2 within 0.6 %;
+Np = 16 777: 3 % / 10 %; Np = 1678: 5 % / 12 % (small samples).
 """
 import json
 import os
@@ -116,14 +120,15 @@ def _gpu_errors(torch, nufft, Np, is_real, mode, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("is_real", [True, False])
-@pytest.mark.parametrize("Np", [16777, 1677722, 16777216])
+@pytest.mark.parametrize("Np", [16777, 1677722, 16777216, 167772160])
 def test_hip_path_reproduces_published_errors_direct(is_real, Np):
     torch = pytest.importorskip("torch")
     from nufft_pkg import nufft
     e1, e2 = _gpu_errors(torch, nufft, Np, is_real, nufft.Direct(), seed=100 + Np % 97)
     r1, r2 = published("Float64_ROC_shared" if is_real else "ComplexF64_ROC_shared", Np)
-    assert abs(e1 / r1 - 1) < 0.03, (e1, r1)
-    assert abs(e2 / r2 - 1) < 0.10, (e2, r2)
+    tol1, tol2 = (0.004, 0.006) if Np >= 1600000 else (0.03, 0.10)
+    assert abs(e1 / r1 - 1) < tol1, (e1, r1)
+    assert abs(e2 / r2 - 1) < tol2, (e2, r2)
 
 
 @pytest.mark.gpu
@@ -135,7 +140,7 @@ def test_hip_path_reproduces_published_errors_polynomial_window(is_real):
     Np = 16777216
     e1, e2 = _gpu_errors(torch, nufft, Np, is_real, nufft.FastApproximation(), seed=7)
     r1, r2 = published("Float64_CPU" if is_real else "ComplexF64_CPU", Np)
-    assert abs(e1 / r1 - 1) < 0.03, (e1, r1)
-    assert abs(e2 / r2 - 1) < 0.10, (e2, r2)
+    assert abs(e1 / r1 - 1) < 0.004, (e1, r1)
+    assert abs(e2 / r2 - 1) < 0.006, (e2, r2)
     d1, _ = _gpu_errors(torch, nufft, Np, is_real, nufft.Direct(), seed=7)
     assert 1.005 < e1 / d1 < 1.013, (e1, d1)      # published: 1.00885 (Float64), 1.00871 (ComplexF64)
