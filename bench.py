@@ -47,6 +47,11 @@ CONFIGS = {
 }
 
 
+# NUFFT_BENCH_SHARE_GPU=1: run the N ranks of `--gpus N` on ONE device with the gloo backend (no gather).  A builder's self-test of
+# the launcher, the barriers and the MAX-over-ranks timing on a one-GPU box; the JSON line carries "shared_gpu_self_test": true.
+SHARE_GPU_SELF_TEST = os.environ.get("NUFFT_BENCH_SHARE_GPU", "0") == "1"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +131,7 @@ def launch_ranks(a):
     import socket
     import subprocess
     n_visible = torch.cuda.device_count()          # does not initialise the GPU on this image
-    if n_visible < a.gpus:
+    if n_visible < a.gpus and not SHARE_GPU_SELF_TEST:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_visible} GPU(s) visible on this node; refusing to run "
                          f"a smaller job under that name")
     with socket.socket() as s:
@@ -219,12 +224,18 @@ def main():
     distributed = world > 1 or a.force_distributed
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if SHARE_GPU_SELF_TEST:
+        local_rank = 0                  # every rank on device 0: a self-test of the N > 1 process logic, never a scaling number
+        a.no_gather = True              # gloo has no device gather; RCCL refuses two ranks on one device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if SHARE_GPU_SELF_TEST:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from nufft_pkg import nufft
     import ctypes as C
@@ -430,6 +441,7 @@ def main():
         "value": head["value"],
         "unit": "NU-points/s",
         "n_gpus": world,
+        **({"shared_gpu_self_test": True} if SHARE_GPU_SELF_TEST else {}),
         "steps": steps,
         "warmup": a.warmup,
         "ms_per_step": head["ms_per_step"],
