@@ -306,7 +306,9 @@ def main():
             if ev: ev[0].record()
             nufft.set_points(plan, xs)
             if ev: ev[1].record()
-            _check(lib.nufft_spread(plan._handle, _ptr_table(vps), s))      # writes every grid cell: no fill_with_zeros stage
+            # writes every grid cell: no fill_with_zeros stage.  The stage as exec_type1 enqueues it: on the ring's halo variant the FFT
+            # stage that follows completes the grid (its first pass adds the side buffer of the stencil reach), and is timed as such
+            _check(lib.nufft_spread_deferred(plan._handle, _ptr_table(vps), s))
             if ev: ev[2].record()
             _check(lib.nufft_fft_forward(plan._handle, s))
             if ev: ev[3].record()
@@ -359,6 +361,21 @@ def main():
         exec2_ms = st2["deconv_pad"] + st2["fft"] + st2["interp"]
         jobs = 1 if P.get("sharded") else world
         engine_used = plan.spread_engine_used()          # the per-point-set decision read back from the device (after the timed regions)
+        # Halo variant of the spreading ring: the FFT stage's first pass adds the side buffer of the stencil reach, i.e. part of the
+        # "spread" work is timed under "fft".  How much: the same FFT stage behind the self-contained nufft_spread (plain first pass).
+        fft_plain_ms = None
+        if int(info.ring_halo) and engine_used == "marching_ring":
+            s = stream_ptr()
+            ts = []
+            for _ in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                _check(lib.nufft_spread(plan._handle, _ptr_table(vps), s))
+                e0.record()
+                _check(lib.nufft_fft_forward(plan._handle, s))
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            fft_plain_ms = float(np.mean(ts[1:]))
         rec = {
             "evalmode": "Direct" if evalmode_name == "direct" else "FastApproximation",
             # independent problems: every rank transforms its own Np points; sharded components: the job is ONE transform of Np points
@@ -368,6 +385,7 @@ def main():
                       "ms_per_step": dt2 / steps * 1e3},
             "workspace_bytes": int(plan.info().workspace_bytes),       # plan-owned device memory with this point set in place
             "ring_column": [int(info.ring_column[0]), int(info.ring_column[1])], "ring_segments": int(info.ring_segments),
+            "ring_halo": int(info.ring_halo), "fft_plain_ms": fft_plain_ms,
             "spread_engine": engine_used, "patch_f32acc": int(info.patch_f32acc), "patch_dims": [int(info.patch_dims[0]), int(info.patch_dims[1])], "patch_planar": int(info.patch_planar),
             "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
             "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
@@ -400,11 +418,23 @@ def main():
         kname = f"spread_march_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, {'false' if head['evalmode'] == 'Direct' else 'true'},"
         binding = ("the LDS atomic pipe (ds_add_f64: 8 array cycles per 64-lane wave instruction, 11.9 of them per point at 1.49 visits; "
                    "LDS array 73 % busy), then the two barriers per bin layer; not HBM: see DESIGN.md section 4.9")
+        if head.get("ring_halo"):
+            binding = ("the LDS atomic pipe (ds_add_f64: 8 array cycles per 64-lane wave instruction, 8 per point: halo variant, every point "
+                       "spread once by its own column), then the two barriers per bin layer; the stencil reach leaves through a side buffer "
+                       "that the FFT stage's first pass adds (frac_incl_consumer charges that pass's extra time to this stage); not HBM: "
+                       "see DESIGN.md section 4.9")
     else:
         kname = f"spread_tile_kernel<{tname}, {'true' if is_complex else 'false'}, 3, {cfg['m']}"
         binding = ("LDS float atomics (ds_add_f64, 8.5 cycles per wave instruction per CU) and the scalar/vector issue of the "
                    "clipped stencil loop, not HBM: see DESIGN.md section 4.2")
     spread_s = st1["spread"] * 1e-3
+    # halo variant: the side buffer (0.49 G at 32 x 32 columns, m = 4) is written by the kernel on top of G + P, and the time its
+    # consumer adds to the FFT stage belongs to the zero + spread stage of SURVEY 8(d)
+    halo_extra_s = max(0.0, (st1["fft"] - head["fft_plain_ms"]) * 1e-3) if head.get("fft_plain_ms") else 0.0
+    if head.get("ring_halo"):
+        n1c, n2c, mm = head["ring_column"][0], head["ring_column"][1], cfg["m"]
+        xr, yr = (mm - 1) + ((mm - 1) & 1) + mm, 2 * mm - 1
+        ab["spread_kernel_min"] += Cn * ab["G"] * ((n1c + xr) * (n2c + yr) / float(n1c * n2c) - 1.0)
     traffic_b, traffic_src = pmc_traffic(kname, a.config)
     probe = hbm_probe(dev) if full else None
     peak_m = probe["peak_measured_GBs"] if probe else None
@@ -423,8 +453,11 @@ def main():
         "own_traffic_bytes_per_stage": ab["spread_kernel_min"],
         "achieved_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9,
         "frac_own_traffic": ab["spread_kernel_min"] / spread_s / 1e9 / HBM_PEAK_GBS,
-        "frac_own": ab["spread_kernel_min"] / spread_s / 1e9 / HBM_PEAK_GBS,      # the kernel's own compulsory traffic (G + P) against the peak
+        "frac_own": ab["spread_kernel_min"] / spread_s / 1e9 / HBM_PEAK_GBS,      # the kernel's own compulsory traffic (G + P [+ side buffer]) against the peak
         "kernel_ms": st1["spread"],
+        # halo variant only: the stage charged with the extra time of the FFT pass that adds the side buffer (else = frac)
+        "consumer_extra_ms": halo_extra_s * 1e3,
+        "frac_incl_consumer": ab["spread_kernel"] / (spread_s + halo_extra_s) / 1e9 / HBM_PEAK_GBS,
         "interp": {"kernel_ms": st2["interp"], "algorithmic_bytes_per_stage": ab["interp_kernel"],
                    "achieved": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9, "frac": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "traffic": (lambda t: t[0] / 1e9 if t[0] is not None else None)(pmc_traffic("interp_march_kernel", a.config)),
@@ -455,7 +488,7 @@ def main():
                         f"ntransforms={Cn}, {head['evalmode']} window (the other evaluation mode: sibling record)",
             "protocol": "set_points! + exec_type1! per step, inputs resident in HBM (reference benchmark protocol)",
             "spread_engine": head["spread_engine"], "spread_tile": head["spread_tile"], "interp_tile": head["interp_tile"],
-            "ring_column": head["ring_column"], "ring_segments": head["ring_segments"], "workspace_bytes": head["workspace_bytes"],
+            "ring_column": head["ring_column"], "ring_segments": head["ring_segments"], "ring_halo": head["ring_halo"], "workspace_bytes": head["workspace_bytes"],
             "parallelism": (f"ntransforms = {C_total} components of one transform sharded over {world} GPU(s) (component c on rank c mod N, same points)"
                             if P_sharded else f"{world} independent plan(s), one per GPU")
                            + ("" if not distributed or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
@@ -491,7 +524,8 @@ def main():
                     "workload": oc["label"] + f", m={oc['m']}, sigma={oc['sigma']}, {r['evalmode']} window",
                     "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": 3,
                     "type2_value": r["type2"]["with_set_points_pts_per_s"], "type2_ms_per_step": r["type2"]["ms_per_step"],
-                    "spread_ms": sp_ms, "interp_ms": ip_ms, "spread_engine": r["spread_engine"],
+                    "spread_ms": sp_ms, "interp_ms": ip_ms, "spread_engine": r["spread_engine"], "ring_halo": r["ring_halo"],
+                    "fft_ms": r["type1"]["stages_ms"]["fft"], "fft_plain_ms": r["fft_plain_ms"],
                     "roofline_frac": abo["spread_kernel"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "roofline_frac_own_traffic": abo["spread_kernel_min"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "interp_roofline_frac": abo["interp_kernel"] / (ip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -520,6 +554,7 @@ def main():
                 result["config"][f"{name}_error"] = r["error"]
                 continue
             for k in ("value", "ms_per_step", "type2_value", "type2_ms_per_step", "spread_ms", "interp_ms", "spread_engine", "roofline_frac",
+                      "ring_halo", "fft_ms", "fft_plain_ms",
                       "roofline_frac_own_traffic", "interp_roofline_frac", "workspace_bytes", "fp32_achieved_tflops", "fp32_frac",
                       "interp_fp32_achieved_tflops", "interp_fp32_frac"):
                 if k in r:

@@ -149,7 +149,8 @@ typedef struct nufft_info {
                                 evaluation and operands — the reference's TODO at src/spreading/gpu.jl:293); 0 = one at a time    */
     int32_t ring_column[2];  /* marching ring: cells of a workgroup's column along dimensions 1, 2; 0 otherwise         */
     int32_t ring_segments;   /* marching ring: segments a column is cut into along dimension 3 for uniform point sets  */
-    int32_t reserved_info;
+    int32_t ring_halo;       /* marching ring: 1 = halo variant (every point spread once by its own column; the stencil reach
+                                travels through a side buffer that the first FFT pass adds), 0 = clipped columns          */
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */
@@ -219,6 +220,12 @@ int nufft_exec_type2_cb(nufft_plan* plan, void* const* values_out, const void* c
 int nufft_fill_zeros(nufft_plan* plan, void* stream);
 /* spread_from_points!(::GPU, ...), src/spreading/gpu.jl:134-214 (adds onto the plan's grids). */
 int nufft_spread(nufft_plan* plan, const void* const* values_in, void* stream);
+/* The same stage as exec_type1 enqueues it: on plans whose spreading engine is the marching ring's halo variant (nufft_info.ring_halo)
+ * the stencil reach beyond each workgroup's column is left in a side buffer and the oversampled grid is completed by the next
+ * nufft_fft_forward (its dimension-1 pass adds the buffer while it loads the lines), nufft_interpolate or nufft_copy_grid on this
+ * plan — nufft_spread completes it itself with one more pass.  Identical to nufft_spread on every other plan.
+ * (No reference counterpart: src/NonuniformFFTs.jl:169-177 calls spread_from_points! and _type1_fft! back to back.) */
+int nufft_spread_deferred(nufft_plan* plan, const void* const* values_in, void* stream);
 /* _type1_fft!, src/NonuniformFFTs.jl:197-211. */
 int nufft_fft_forward(nufft_plan* plan, void* stream);
 /* copy_deconvolve_to_non_oversampled!(::GPU, ...), src/NonuniformFFTs.jl:387-414. */

@@ -67,7 +67,7 @@ class NufftInfo(C.Structure):
         ("npoly", C.c_int32), ("window_scale_log2", C.c_int32 * 3), ("kernel", C.c_int32),
         ("spread_max_items", C.c_int32), ("interp_max_items", C.c_int32), ("spread_method", C.c_int32),
         ("patch_dims", C.c_int32 * 2), ("patch_f32acc", C.c_int32), ("patch_planar", C.c_int32),
-        ("ring_column", C.c_int32 * 2), ("ring_segments", C.c_int32), ("reserved_info", C.c_int32),
+        ("ring_column", C.c_int32 * 2), ("ring_segments", C.c_int32), ("ring_halo", C.c_int32),
     ]
 
 
@@ -90,6 +90,7 @@ SYMBOLS = {
     "nufft_exec_type2_cb": (C.c_int, [_P, _PP, _PP, _P, _P]),
     "nufft_fill_zeros": (C.c_int, [_P, _P]),
     "nufft_spread": (C.c_int, [_P, _PP, _P]),
+    "nufft_spread_deferred": (C.c_int, [_P, _PP, _P]),
     "nufft_fft_forward": (C.c_int, [_P, _P]),
     "nufft_deconvolve_truncate": (C.c_int, [_P, _PP, _P]),
     "nufft_deconvolve_pad": (C.c_int, [_P, _PP, _P]),

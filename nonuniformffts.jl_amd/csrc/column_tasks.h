@@ -2,6 +2,14 @@
 // spreading engine (patch columns) and of the z-marching interpolation ring (grid columns); built by balance.hip.
 #pragma once
 
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define NUFFT_HD __host__ __device__
+#else
+#define NUFFT_HD
+#endif
+
 namespace nufft {
 
 // ncolx x ncoly columns of bxw x byw bins, nseg segments of segl layers when cut evenly (ntasks = columns x
@@ -23,10 +31,41 @@ struct SMarchPlan {
     bool eligible;
     int n1, n2;                 // column interior chosen for this grid (multiples of the bin edge, <= the kernel's compile-time column)
     int hlo, hhi;               // layers of points a segment visits below / above its own
-    int halo;                   // 0: columns clipped in x and y; 1: input-driven in x (halo in LDS, atomics bands); 2: in x and y
+    int halo;                   // 0: columns clipped in x and y; 2: halo variant (every point spread once by its own column, the stencil reach
+                                // into a side buffer that the consumer of the grid adds: smarch_kernels.h)
+    int64_t halo_reals;         // halo = 2: reals of the side buffer per component
     int lds_bytes, threads;
     ColumnTasks ct;             // columns and evenly cut tasks
     double visits, efficiency;  // model: point visits per point, and the share of the chip the launch keeps busy
 };
+
+// Side buffer of the halo variant: one record of reals per (plane z, column ty, tx) —
+//   [n2 strips of SW reals: the x reach of the column's own rows, XLO cells below then XHI above]
+//   [YLO + YHI rows of RW reals: the y reach (rows below, then above), each the full width of the window]
+// SW and RW rounded up to even so that aligned pairs of reals stay 2-real aligned.  (XLO = M - 1 rounded up to even: the first
+// cell of the window row is padding for odd M - 1; it is stored as the zero it holds.)
+struct HaloLayout {
+    int n1, n2, xlo, xhi, ylo, yhi, nc;     // column, reach in cells, components per cell
+    int ntx, nty;
+    int sw, rw, rec;                        // strip width, row width, record size (reals)
+    int64_t plane;                          // reals per plane of the grid's side buffer
+};
+NUFFT_HD inline HaloLayout make_halo_layout(int n1, int n2, int M, int nc, int ntx, int nty) {
+    HaloLayout h;
+    h.n1 = n1; h.n2 = n2; h.nc = nc; h.ntx = ntx; h.nty = nty;
+    h.xlo = (M - 1) + ((M - 1) & 1); h.xhi = M; h.ylo = M - 1; h.yhi = M;
+    h.sw = ((h.xlo + h.xhi) * nc + 1) & ~1;
+    h.rw = ((n1 + h.xlo + h.xhi) * nc + 1) & ~1;
+    h.rec = n2 * h.sw + (h.ylo + h.yhi) * h.rw;
+    h.plane = (int64_t)h.rec * ntx * nty;
+    return h;
+}
+// offset (reals) inside a record of window element (real index lxw of the window row, row ly relative to the column's first row);
+// the element must lie outside the column
+NUFFT_HD inline int halo_record_offset(const HaloLayout& h, int lxw, int ly) {
+    if (ly < 0) return h.n2 * h.sw + (ly + h.ylo) * h.rw + lxw;
+    if (ly >= h.n2) return h.n2 * h.sw + (h.ylo + ly - h.n2) * h.rw + lxw;
+    return ly * h.sw + (lxw < h.xlo * h.nc ? lxw : lxw - h.n1 * h.nc);
+}
 
 }  // namespace nufft

@@ -299,9 +299,64 @@ struct RealLineArgs {
     int k1;                 // kept modes per line
     int row;                // row stride of the compact spectrum in complex elements (>= k1: rows padded to 128 bytes)
     const void* twiddle;    // complex<T>[N]: exp(SIGN 2πi m / N), N = 2M
+    // forward pass behind the halo variant of the spreading ring (smarch_kernels.h): the stencil reach of every column sits in
+    // a side buffer and is added to the line while it is loaded (halo != null; the flag says whether the ring served the point set)
+    const void* halo;       // T[planes][nty][ntx][record] of this component
+    const uint32_t* hflag;
+    int ny;                 // lines per plane of the grid (line = z * ny + y)
+    HaloLayout hl;
 };
 
-template <typename T, int M, bool FWD, int TL>
+// line += the stencil reach that the neighbouring columns left in the side buffer (real data: nc = 1; pairs of reals = the
+// complex elements of the line).  Strips of the x reach: one aligned pair per lane and step, distinct cells for distinct columns
+// (columns are wider than the reach).  Rows of the y reach (lines within the reach of a column boundary only): the rows of
+// neighbouring columns overlap, so even and odd columns take turns (and the last column of an odd count goes alone).
+template <typename T, typename C>
+__device__ __forceinline__ void add_halo_to_line(const RealLineArgs& a, C* line, int64_t line_id, int lane, int n) {
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    const HaloLayout& h = a.hl;
+    const int y = (int)(line_id % a.ny), z = (int)(line_id / a.ny);
+    const int ty = y / h.n2, ly = y - ty * h.n2;
+    const T* hz = static_cast<const T*>(a.halo) + (int64_t)z * h.plane;
+    auto add_pair = [&](int x0, T2 v) __attribute__((always_inline)) {
+        if (x0 < 0) x0 += n;
+        if (x0 >= n) x0 -= n;
+        C c = line[lpad(x0 >> 1)];
+        c.x += v.x;
+        c.y += v.y;
+        line[lpad(x0 >> 1)] = c;
+    };
+    {
+        const int sp = h.sw / 2;
+        const T* row = hz + (int64_t)ty * h.ntx * h.rec + ly * h.sw;
+        for (int idx = lane; idx < h.ntx * sp; idx += kWave) {
+            const int tx = idx / sp, i = 2 * (idx - tx * sp);
+            const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + i);
+            add_pair(i < h.xlo ? tx * h.n1 - h.xlo + i : tx * h.n1 + h.n1 + (i - h.xlo), v);
+        }
+        wave_lds_fence();
+    }
+    int sy = -1, rr = 0;
+    if (ly < h.yhi) { sy = ty == 0 ? h.nty - 1 : ty - 1; rr = h.ylo + ly; }
+    else if (ly >= h.n2 - h.ylo) { sy = ty + 1 == h.nty ? 0 : ty + 1; rr = ly - (h.n2 - h.ylo); }
+    if (sy >= 0) {
+        const int rp = h.rw / 2;
+        const T* row = hz + (int64_t)sy * h.ntx * h.rec + h.n2 * h.sw + rr * h.rw;
+        const int neven = h.ntx & ~1;
+        for (int par = 0; par < 3; ++par) {
+            const int ncol = par == 2 ? (h.ntx & 1) : neven / 2;
+            for (int idx = lane; idx < ncol * rp; idx += kWave) {
+                const int k = idx / rp, i = 2 * (idx - k * rp);
+                const int tx = par == 2 ? h.ntx - 1 : 2 * k + par;
+                const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + i);
+                add_pair(tx * h.n1 - h.xlo + i, v);
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+template <typename T, int M, bool FWD, int TL, bool HALO = false>
 __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) {
     using C = typename Cplx2<T>::type;
     constexpr int N = 2 * M;
@@ -322,6 +377,9 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         const C* zin = reinterpret_cast<const C*>(static_cast<const T*>(a.in) + line_id * N);
         for (int n = lane; n < M; n += kWave) line[lpad(n)] = zin[n];
         wave_lds_fence();
+        if constexpr (HALO) {
+            if (*a.hflag != 0u) add_halo_to_line<T, C>(a, line, line_id, lane, N);
+        }
         fft_line<T, M, -1, 2>(line, tw, lane);
         C* xout = static_cast<C*>(a.out) + line_id * a.row;
         for (int k = lane; k < a.k1; k += kWave) {
@@ -442,18 +500,20 @@ static hipError_t launch_real_m(const RealLineArgs& a, hipStream_t stream) {
     constexpr int TL = real_lines_per_group<T, M>();
     static_assert(TL >= 4 && sizeof(C) * (size_t)(TL * LINE + 2 * M) <= kFftLdsLimit, "line buffers exceed the 160 KiB of LDS");
     const size_t lds = sizeof(C) * (size_t)(TL * LINE + 2 * M);
-    auto fn = real_lines_kernel<T, M, FWD, TL>;
     // the attribute is per device: remember which devices of this process have it (plans may live on several)
     static std::atomic<unsigned long long> prepared{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
+    auto fn = real_lines_kernel<T, M, FWD, TL, false>;
+    auto fnh = real_lines_kernel<T, M, FWD, TL, FWD>;      // forward: the variant that adds the spreading ring's side buffer
     if (!(prepared.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && FWD) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fnh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         prepared.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)((a.nlines + TL - 1) / TL)), dim3(TL * kWave), lds, stream, a);
+    hipLaunchKernelGGL((FWD && a.halo) ? fnh : fn, dim3((unsigned)((a.nlines + TL - 1) / TL)), dim3(TL * kWave), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -484,9 +544,13 @@ bool real_lines_supported(int dtype, int64_t n) {
 }
 
 hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1, int row,
-                             const void* twiddle, hipStream_t stream) {
-    RealLineArgs a;
+                             const void* twiddle, hipStream_t stream, const RealLineHalo* halo) {
+    RealLineArgs a{};
     a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.row = row; a.twiddle = twiddle;
+    if (halo && halo->buffer && forward) {
+        if (halo->layout.nc != 1 || halo->ny <= 0) return hipErrorInvalidValue;
+        a.halo = halo->buffer; a.hflag = halo->flag; a.ny = halo->ny; a.hl = halo->layout;
+    }
     const int m = (int)(n / 2);
     if (dtype == NUFFT_F32) return forward ? launch_real_t<float, true>(m, a, stream) : launch_real_t<float, false>(m, a, stream);
     return forward ? launch_real_t<double, true>(m, a, stream) : launch_real_t<double, false>(m, a, stream);

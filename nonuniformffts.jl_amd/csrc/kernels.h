@@ -84,6 +84,7 @@ struct TileKernelArgs {
     const uint2* march_tasks;     // and the task table
     int fixed_tile;            // the tile (g.ip / g.sp) equals the compile-time one (kernel variant with constant strides)
     int cubes;                 // spreading with the compile-time tile: accumulate cube by cube with the FP64 matrix instruction
+    void* halo;                // marching ring, halo variant: side buffer of the stencil reach (C components, SMarchPlan::halo_reals each)
 };
 // Compile-time interpolation tile of an instantiation: n[0..2] cells (n[0] == 0: none), n[3] = LDS row
 // stride in reals; see fixed_interp_tile().
@@ -141,11 +142,13 @@ hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* so
 
 // ---- spreading on the z-marching LDS ring (smarch_kernels.h, smarch_*.hip) -------------------------------------------
 // 3-D plans with 4-cell bins and the default window evaluation whose axes are long enough; cus: compute units, C: components
-// halo: 0 = output-driven in x and y, 1 = input-driven in x, 2 = input-driven in x and y (smarch_kernels.h)
+// halo: 0 = output-driven in x and y; 2 = the halo variant (real data, grids the column divides; falls back to 0 where it cannot run)
 SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo);
 hipError_t prepare_spread_march(int dtype, int is_complex, int M, int halo);
 // flag: device flag of set_points (1: the ring serves this point set); tasktab: its task table
 hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream);
+// halo variant: grid += side buffer (a.halo); the dimension-1 FFT pass of real plans does the same while it loads its lines (launch_real_lines)
+hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, hipStream_t stream);
 // set_points: tasks of the ring for this point set and whether it serves it (advantage <= 0: always)
 hipError_t launch_smarch_tasks(const Geom& g, const SMarchPlan& sp, const uint32_t* offsets, int64_t np, int cus, double advantage,
                                uint32_t* choice, uint32_t* slots_in_use, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream);
@@ -186,8 +189,16 @@ bool fft_lines_supported(int dtype, int64_t n);
 bool real_lines_supported(int dtype, int64_t n);
 // r2c (forward) / c2r of `nlines` contiguous real lines of length n with a compact spectrum of k1 modes per line
 // (row: row stride of the compact spectrum in complex elements, >= k1)
+// halo (forward only, or null): the side buffer of the spreading ring's halo variant for these lines (one component; lines of
+// planes of ny rows), added to every line while it is loaded — when *flag != 0 (the ring served the point set)
+struct RealLineHalo {
+    const void* buffer;
+    const uint32_t* flag;
+    int ny;
+    HaloLayout layout;
+};
 hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1, int row,
-                             const void* twiddle, hipStream_t stream);
+                             const void* twiddle, hipStream_t stream, const RealLineHalo* halo = nullptr);
 hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePass& p, hipStream_t stream);
 // c2c of `nlines` contiguous complex lines of length n with a compact spectrum of k1 kept modes (map: kept -> FFT index)
 hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,

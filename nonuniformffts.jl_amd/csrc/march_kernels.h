@@ -38,6 +38,8 @@ struct MarchGeom {
     const uint32_t* flag;           // per point set (set_points, balance.hip): 1 = the ring serves it, 0 = interp_tile_kernel
     const uint2* tasktab;           // per point set: {column, end layer << 16 | first layer} per task
     int n1, n2;                     // spreading ring (smarch_kernels.h): the column chosen for this grid (<= its compile-time one)
+    void* halo;                     // ... its halo variant: side buffer of the stencil reach (reals), component stride in reals
+    int64_t halo_comp;
 };
 
 constexpr int kMarchMaxRows = 16;   // rows of bins of a column (n2 <= 64)

@@ -133,6 +133,9 @@ struct nufft_plan {
     uint32_t* d_smarch_choice = nullptr;  // [8]: scratch of the task kernels; [2] = 1: this point set is spread by the ring
     uint32_t* d_smarch_cols = nullptr;    // [columns] points per column, then [columns + 1] first task of each column
     void* d_smarch_tasks = nullptr;       // uint2[table entries]: {column, end layer << 16 | first layer}, rebuilt by every set_points
+    void* d_smarch_halo = nullptr;        // halo variant: side buffer of the stencil reach, C x smarch.halo_reals reals
+    bool halo_pending = false;            // inside exec_type1: the side buffer has not been added yet, the first FFT pass does it
+    bool halo_fuse = true;                // NUFFT_SMARCH_HALO_FUSE (latched at creation): 0 = always the separate add pass
     int wave_slots = 2048;             // resident waves of the patch kernel on this device (CUs x 4 SIMDs x its waves per SIMD)
     void* d_vsorted = nullptr;         // C value vectors in sorted order (MFMA-patch spreading)
     int64_t lds_spread = 0, lds_interp = 0;

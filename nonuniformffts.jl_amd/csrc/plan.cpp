@@ -140,6 +140,13 @@ static int env_int(const char* name, int fallback) {
     return (v && *v) ? std::atoi(v) : fallback;
 }
 
+// Default of the spreading ring's halo variant for this plan (0: clipped columns, 2: halo variant); see DESIGN.md section 4.9.
+// Measured (256^3 -> 512^3, Np = 1e7; spread + FFT stages, ms; scripts/r4_halo_matrix.sh): Float64 m = 2 ... 7: 2.08 / 2.57 / 3.03 / 5.72 /
+// 11.4 / 20.7 with clipped columns, 1.88 / 2.22 / 2.62 / 4.68 / 8.35 / 14.8 with the halo variant; Float32 alike (m = 8: 17.3 -> 13.1).
+// Only where the plan's own dimension-1 pass adds the side buffer (real plans on the pruned FFT path); smarch_plan falls back to the
+// clipped columns where the variant cannot run (axes the column does not divide, LDS).
+static int smarch_halo_default(const nufft_plan* p) { return (!p->is_complex && p->D == 3) ? 2 : 0; }   // (build_device: ... and the pruned real FFT path)
+
 static int build_host(nufft_plan* p, const nufft_params* in) {
     p->dtype = in->dtype;
     p->is_complex = in->is_complex != 0;
@@ -358,12 +365,17 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         // M = 6: 10.8 / 15.5 / 13.2; M = 7: 20.1 against 13.4 patches), ntransforms components one after the other (C = 3: 7.3 ms
         // against 7.5 with the planar patches); ComplexF64 up to M = 4 (5.06 against 5.36 patches), ComplexF32 up to M = 3 (M = 4:
         // 4.71 against 4.10 patches).  256 CUs assumed here, build_device() redoes the decomposition for the device.
-        p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C,
-                                env_int("NUFFT_SMARCH_HALO", 0));
+        // halo variant of the ring (every point spread once, the stencil reach through a side buffer that the first FFT pass adds):
+        // real data on grids whose axes the column divides; NUFFT_SMARCH_HALO=0 / 2 forces the choice (A/B runs, tests)
+        const int want_halo = env_int("NUFFT_SMARCH_HALO", smarch_halo_default(p)) == 2 ? 2 : 0;
+        p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, want_halo);
+        if (!p->smarch.eligible && want_halo)
+            p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, 0);
         if (req == NUFFT_SPREAD_MARCHING_RING && !p->smarch.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = marching ring needs a 3-D grid of 4-cell bins with every oversampled axis a multiple "
                                                "of 4 and longer than a column plus a stencil, and the default window evaluation");
-        const int ring_max_m = !p->is_complex ? 6 : (p->dtype == NUFFT_F64 ? 4 : 3);
+        // (with the halo variant the window also beats the patches for Float32 at M = 7: 10.8 against 12.8 ms spread + FFT)
+        const int ring_max_m = !p->is_complex ? ((p->dtype == NUFFT_F32 && p->smarch.halo == 2) ? 7 : 6) : (p->dtype == NUFFT_F64 ? 4 : 3);
         const bool prefer_ring = env_int("NUFFT_PREFER_RING", 1) != 0 && p->M <= ring_max_m && env_int("NUFFT_PREFER_PATCHES", 0) == 0;
         if (p->smarch.eligible && (req == NUFFT_SPREAD_MARCHING_RING || (req == NUFFT_SPREAD_AUTO && prefer_ring)))
             p->spread_method = NUFFT_SPREAD_MARCHING_RING;
@@ -558,6 +570,7 @@ static int build_device(nufft_plan* p) {
     // NUFFT_INTERP_MARCH = 0: never the ring (A/B runs), 2: always (tests of its instantiations on small grids)
     p->interp_march_mode = env_int("NUFFT_INTERP_MARCH", 1);
     p->debug_tasks = env_int("NUFFT_DEBUG_TASKS", 0) != 0;
+    p->halo_fuse = env_int("NUFFT_SMARCH_HALO_FUSE", 1) != 0;
     p->interp_march = p->interp_march_mode != 0 &&
                       interp_march_available(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
     if (p->interp_march) {
@@ -594,7 +607,11 @@ static int build_device(nufft_plan* p) {
         hipDeviceProp_t prop;
         NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
         p->num_cus = prop.multiProcessorCount;
-        p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C, p->smarch.halo);
+        int want_halo = p->smarch.halo;
+        if (want_halo == 2 && !(p->pruned_fft && p->compact_dim1) && env_int("NUFFT_SMARCH_HALO", 0) != 2) want_halo = 0;   // no fused consumer: not worth it
+        p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C, want_halo);
+        if (!p->smarch.eligible && want_halo)
+            p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C, 0);
         if (!p->smarch.eligible) return fail(NUFFT_ERR_UNSUPPORTED, "marching-ring spreading: no decomposition for this device");
         NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M, p->smarch.halo));
         const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
@@ -602,6 +619,7 @@ static int build_device(nufft_plan* p) {
         NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 8 * sizeof(uint32_t)));
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, &p->d_smarch_tasks, (size_t)column_task_table_entries(p->smarch.ct, p->tile.nb[2]) * 8))) return rc;
+        if (p->smarch.halo == 2 && (rc = dev_alloc(p, &p->d_smarch_halo, (size_t)p->smarch.halo_reals * real_bytes(p) * p->C))) return rc;
     }
 
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->spread_method == NUFFT_SPREAD_MARCHING_RING || p->interp_march) NUFFT_HIP(prepare_column_tasks());
@@ -625,7 +643,7 @@ static void release(nufft_plan* p) {
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
         fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks); fr(p->d_march_choice); fr(p->d_march_cols); fr(p->d_march_tasks);
-        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks);
+        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks); fr(p->d_smarch_halo);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -688,6 +706,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.march_flag = p->d_march_choice ? p->d_march_choice + 2 : nullptr;
     a.march_tasks = static_cast<const uint2*>(p->d_march_tasks);
     a.cubes = !interp && p->spread_cubes && !needs_other_eval(p->kernel, p->evalmode) && !p->cb_point_weights;
+    a.halo = p->d_smarch_halo;
     a.lds_bytes = (int)(interp ? p->lds_interp : p->lds_spread);
     const nufft_plan::Balance& b = p->bal;
     const int nt = (int)(interp ? p->tile.ip.ntiles : p->tile.sp.ntiles);
@@ -761,15 +780,27 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
         for (int d = 1; d < p->D; ++d) nlines *= p->Nover[d];
         // components are contiguous both in us (Ñ1 reals per line) and in the compact spectrum (N_out1 per line);
         // the per-component offset of the compact spectrum is nlines_per_component * N_out1 <= spec_elems
+        // behind the halo variant of the spreading ring (exec_type1): the pass adds the side buffer while it loads its lines
+        RealLineHalo hh{};
+        const bool fuse = p->halo_pending && p->D == 3;
+        if (fuse) {
+            hh.flag = p->d_smarch_choice + 2;
+            hh.ny = (int)p->Nover[1];
+            hh.layout = make_halo_layout(p->smarch.n1, p->smarch.n2, p->M, 1, p->smarch.ct.ncolx, p->smarch.ct.ncoly);
+        }
+        const size_t rb = real_bytes(p);
         if (p->C == 1) {
-            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, p->d_us, p->d_uhat, nlines, (int)p->Nout[0], (int)p->spec_row, p->d_tw_fw[0], stream));
+            hh.buffer = p->d_smarch_halo;
+            NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, p->d_us, p->d_uhat, nlines, (int)p->Nout[0], (int)p->spec_row, p->d_tw_fw[0], stream,
+                                        fuse ? &hh : nullptr));
         } else {
             const int64_t per = nlines / p->C;
-            const size_t rb = real_bytes(p);
             for (int c = 0; c < p->C; ++c) {
                 const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
                 void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
-                NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], (int)p->spec_row, p->d_tw_fw[0], stream));
+                hh.buffer = static_cast<char*>(p->d_smarch_halo) + (size_t)c * p->smarch.halo_reals * rb;
+                NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], (int)p->spec_row, p->d_tw_fw[0], stream,
+                                            fuse ? &hh : nullptr));
             }
         }
         return NUFFT_OK;
@@ -989,7 +1020,7 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->ring_column[0] = ring ? p->smarch.n1 : 0;
     o->ring_column[1] = ring ? p->smarch.n2 : 0;
     o->ring_segments = ring ? p->smarch.ct.nseg : 0;
-    o->reserved_info = 0;
+    o->ring_halo = (ring && p->smarch.halo == 2) ? 1 : 0;
     return NUFFT_OK;
 }
 
@@ -1106,7 +1137,12 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         // tasks of the spreading ring for this point set, and whether it serves it (balance.hip): while the heaviest task stays
         // within its measured advantage over the LDS tiles on uniform points (x 0.85 for what the estimate leaves out); an
         // explicit request always takes the ring
-        double advantage = 0.85 * 1.3;
+        // (halo variant: 1.87 instead of 2.44 ms at C2, + 0.15 ms in the FFT pass: 3.67 / 2.62 = 1.4 against the tiles, stage + FFT; the
+        // reference's benchmark distribution — folded N(0, 1), sigma = 1.5, Np = 1.68e7 — sits at the threshold: tiles 6.78 + 0.32 ms
+        // below 1.19, window 6.18 + 0.38 ms from 1.3 on, hence 0.93 instead of 0.85 here)
+        static const double adv_env = [] { const char* e = std::getenv("NUFFT_SMARCH_ADVANTAGE"); return e && *e ? std::atof(e) : 0.0; }();
+        double advantage = p->smarch.halo == 2 ? 0.93 * 1.4 : 0.85 * 1.3;
+        if (adv_env > 0.0) advantage = adv_env;       // (experiments)
         if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING) advantage = 0.0;
         const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
         // (the C components are independent workgroups of one launch: each component has num_cus / C compute units' worth of the chip)
@@ -1213,7 +1249,8 @@ int nufft_fill_zeros(nufft_plan* p, void* stream_) {
     return NUFFT_OK;
 }
 
-int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
+// defer_halo: exec_type1 with the halo variant of the ring on a plan whose first FFT pass adds the side buffer itself
+static int spread_impl(nufft_plan* p, const void* const* values_in, void* stream_, bool defer_halo) {
     int rc = require_points(p);
     if (rc) return rc;
     if (!values_in) return fail(NUFFT_ERR_INVALID_ARG, "null value table");
@@ -1230,8 +1267,14 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
         NUFFT_HIP(launch_zero_split_tiles(p->dtype, a.g, p->D, p->is_complex, p->C, p->bal.d_nslices, p->d_us,
                                           p->grid_elems * (p->is_complex ? 2 : 1), stream));
     NUFFT_HIP(launch_spread(a, stream));
-    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING)
+    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
         NUFFT_HIP(launch_spread_march(a, p->smarch, p->d_smarch_choice + 2, static_cast<const uint2*>(p->d_smarch_tasks), stream));
+        // halo variant: the grid is complete once the side buffer has been added — here, or by the first FFT pass
+        if (p->smarch.halo == 2) {
+            if (!defer_halo) NUFFT_HIP(launch_smarch_halo_add(a, p->smarch, p->d_smarch_choice + 2, stream));
+            p->halo_pending = defer_halo;
+        }
+    }
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         // values gathered into sorted order (per-point weights of the callback menu folded in), then the patches
         const uint32_t* enabled = p->d_patch_choice + 2;
@@ -1251,12 +1294,31 @@ int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) {
     return NUFFT_OK;
 }
 
+int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) { return spread_impl(p, values_in, stream_, false); }
+int nufft_spread_deferred(nufft_plan* p, const void* const* values_in, void* stream_) { return spread_impl(p, values_in, stream_, true); }
+
+// The halo variant's side buffer has not been added to the grid yet (nufft_spread_deferred): do it now, unless the caller is
+// the FFT pass that adds it on the fly.
+static int complete_halo(nufft_plan* p, hipStream_t stream) {
+    if (!p->halo_pending) return NUFFT_OK;
+    p->halo_pending = false;
+    TileKernelArgs a = tile_args(p, false);
+    NUFFT_HIP(launch_smarch_halo_add(a, p->smarch, p->d_smarch_choice + 2, stream));
+    return NUFFT_OK;
+}
+
 int nufft_fft_forward(nufft_plan* p, void* stream_) {
     int rc = require_device(p);
     if (rc) return rc;
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_FFT, stream);
+    // behind nufft_spread_deferred: the dimension-1 pass of a real plan's own FFT adds the side buffer while it loads its lines;
+    // every other FFT path gets the completed grid
+    struct Pending { nufft_plan* p; ~Pending() { p->halo_pending = false; } } pending{p};
+    const bool fuse_halo = p->halo_pending && p->pruned_fft && !p->is_complex && p->compact_dim1 && p->D == 3 && p->halo_fuse;
+    if (p->halo_pending && !fuse_halo && (rc = complete_halo(p, stream))) return rc;
+    p->halo_pending = fuse_halo;
     if (p->pruned_fft) {
         if ((rc = pruned_forward_fft(p, stream))) return rc;
         if (p->D == 3 && p->C == 1) return pruned_forward_pass(p, 0, 1, nullptr, stream);
@@ -1357,6 +1419,7 @@ int nufft_interpolate(nufft_plan* p, void* const* values_out, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_INTERP, stream);
+    if ((rc = complete_halo(p, stream))) return rc;
     if (p->Np == 0) return NUFFT_OK;
     TileKernelArgs a = tile_args(p, true);
     a.values_out = values_out;
@@ -1370,7 +1433,8 @@ int nufft_exec_type1(nufft_plan* p, void* const* uhat_out, const void* const* va
     if (!uhat_out || !values_in) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
     // (0) "Fill with zeros" (src/NonuniformFFTs.jl:161-167) is not needed: the output-driven spreading
     // kernel stores every grid cell exactly once.
-    if ((rc = nufft_spread(p, values_in, stream))) return rc;          // (1) :169-172
+    // (halo variant of the spreading ring: the FFT stage completes the grid — its dimension-1 pass adds the side buffer on the fly)
+    if ((rc = nufft_spread_deferred(p, values_in, stream))) return rc;  // (1) :169-172
     if ((rc = nufft_fft_forward(p, stream))) return rc;                // (2) :174-177
     return nufft_deconvolve_truncate(p, uhat_out, stream);             // (3) :179-185
 }
@@ -1437,6 +1501,7 @@ int nufft_copy_grid(const nufft_plan* p, int which, int component, void* dst, in
     if (!dst) return fail(NUFFT_ERR_INVALID_ARG, "null destination");
     if (capacity_bytes < bytes) return fail(NUFFT_ERR_DIM_MISMATCH, "destination buffer too small");
     DeviceGuard guard(p->device);
+    if (which == 0 && p->halo_pending && (rc = complete_halo(const_cast<nufft_plan*>(p), static_cast<hipStream_t>(stream_)))) return rc;
     NUFFT_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream_)));
     return NUFFT_OK;
 }

@@ -3,5 +3,5 @@
 #define NUFFT_CPLX true
 #define NUFFT_CPLX_IS_TRUE 1
 #define NUFFT_SMARCH_GETTER smarch_kernel_f64c
-#define NUFFT_SMARCH_ZERO smarch_zero_bands_f64
+#define NUFFT_SMARCH_HALO_ADD smarch_halo_add_f64
 #include "smarch_inst.h"

@@ -16,14 +16,13 @@ static void smarch_entry_h(bool poly, const void** fn, int* lds_bytes, int* n) {
         n[0] = C::N1; n[1] = C::N2; n[2] = C::HLO; n[3] = C::HHI; n[4] = C::THREADS;
     }
 }
-// halo: 0 = output-driven in x and y (clipped), 1 = input-driven in x, 2 = input-driven in x and y (smarch_kernels.h)
-// The halo variants lost on hardware (global float atomics for the band cells: 66 G/s — C2 spread 3.7 ms + 0.3 ms zero fill
-// against 2.44 ms) and are built only with -DNUFFT_SMARCH_HALO_VARIANTS (A/B runs: NUFFT_SMARCH_HALO=1|2).
+// halo: 0 = output-driven in x and y (clipped: the column visits every point whose stencil reaches it); 2 = the halo variant
+// (every point spread once by its own column, the reach into a side buffer: smarch_kernels.h).  Real data only: the consumer
+// fused into the first FFT pass exists for real plans.
 template <int M>
 static void smarch_entry(int halo, bool poly, const void** fn, int* lds_bytes, int* n) {
-#if defined(NUFFT_SMARCH_HALO_VARIANTS)
+#if !NUFFT_CPLX_IS_TRUE
     if (halo == 2) { smarch_entry_h<M, true, true>(poly, fn, lds_bytes, n); return; }
-    if (halo == 1) { smarch_entry_h<M, true, false>(poly, fn, lds_bytes, n); return; }
 #endif
     if (halo == 0) smarch_entry_h<M, false, false>(poly, fn, lds_bytes, n);
 }
@@ -52,14 +51,15 @@ const void* NUFFT_SMARCH_GETTER(int M, int halo, bool poly, int* lds_bytes, int*
 }  // namespace nufft
 
 namespace nufft {
-// zero fill of the atomically accumulated bands of the halo variants (instantiated once per real type: with the real units)
+// grid += side buffer of the halo variant (instantiated once per real type: with the real units)
 #if !NUFFT_CPLX_IS_TRUE
-hipError_t NUFFT_SMARCH_ZERO(void* grid, int64_t comp_stride_reals, const Geom& g, int nc, int C, int n1, int n2, int hx, int hy, int M,
-                             const uint32_t* flag, hipStream_t stream) {
+hipError_t NUFFT_SMARCH_HALO_ADD(void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, const Geom& g, int nc, int C,
+                                 int n1, int n2, int M, int ntx, int nty, const uint32_t* flag, hipStream_t stream) {
     const int64_t rows = (int64_t)g.Nover[1] * g.Nover[2];
     const unsigned blocks = (unsigned)std::min<int64_t>(rows, 65535 * 4);
-    hipLaunchKernelGGL(smarch_zero_bands_kernel<NUFFT_T>, dim3(blocks, (unsigned)C, 1), dim3(256), 0, stream, static_cast<NUFFT_T*>(grid),
-                       comp_stride_reals, g, nc, n1, n2, hx, hy, M, flag);
+    const HaloLayout h = make_halo_layout(n1, n2, M, nc, ntx, nty);
+    hipLaunchKernelGGL(smarch_halo_add_kernel<NUFFT_T>, dim3(blocks, (unsigned)C, 1), dim3(256), 0, stream, static_cast<NUFFT_T*>(grid),
+                       static_cast<const NUFFT_T*>(halo), grid_comp_reals, halo_comp_reals, g, h, flag);
     return hipGetLastError();
 }
 #endif

@@ -24,15 +24,16 @@
 // their group lanes — and LDS offset reach the accumulation as three v_readlane: 22 vector and ~8 scalar instructions
 // per point visit besides the eight atomics.
 //
-// Halo variants (template flags HX, HY; round 4b).  The column above is OUTPUT-driven in x and y: it holds its own cells only and
-// visits every point whose stencil reaches them (1.49 visits per point at 32 x 32).  With HX (HY) the window also holds the
-// stencil reach beyond the column in x (y) and the column visits only ITS OWN points there — every point is spread exactly
-// once along that dimension, unclipped — and the cells within the stencil's reach of a column boundary (the halo and the
-// band of own cells the neighbours reach) leave with global float atomics onto a band that smarch_zero_bands_kernel has
-// zeroed, the other cells with plain stores as before.  In x the halo is free in LDS (the bank-aligned row stride of a
-// 32-cell column is 40 cells: exactly 32 + 2M); in y it costs 2M - 1 rows.  MEASURED AND NOT BUILT BY DEFAULT: with plain stores in
-// place of the atomics (wrong sums, timing only) the HX + HY kernel takes 1.94 ms at C2 against 2.44 ms, but the 1.2e8 band
-// atomics per launch run at 66 G/s (kernel 3.71 ms) and the banded zero fill costs 0.31 ms: -DNUFFT_SMARCH_HALO_VARIANTS.
+// Halo variant (template flags HX = HY = true; round 4c).  The column above is OUTPUT-driven in x and y: it holds its own cells only
+// and visits every point whose stencil reaches them (1.49 visits per point at 32 x 32).  The halo variant's window also holds the
+// stencil's reach beyond the column (free in x: the bank-aligned row stride of a 32-cell column is 40 cells = 32 + 2M; 2M - 1 rows
+// in y) and the column visits only ITS OWN points: every point is spread exactly once, unclipped, every atomic with all its lanes.
+// The cells of the reach belong to the neighbouring columns: they leave, with plain coalesced stores like the column's own cells,
+// into a SIDE BUFFER (one record per column and plane: n2 strips of the x reach, then the 2M - 1 rows of the y reach), and the
+// consumer of the grid adds them: the dimension-1 FFT pass of real plans while it loads a line (fft_lines.hip, real_lines_kernel:
+// + 0.5 G of reads), or smarch_halo_add_kernel for the stage-level entry point and the plans whose first pass is not that kernel.
+// (Round 4b accumulated the reach with global float atomics onto zeroed bands of the grid instead: 1.2e8 atomics per launch at
+// 66 G/s — 3.71 + 0.31 ms against 2.44 ms; with plain stores the same kernel took 1.94 ms.)
 //
 // Tasks: column x segment of bin layers from the table set_points builds per point set on the device (balance.hip):
 // equal-length segments for uniform sets, column quantiles otherwise; point sets whose heaviest task would hold the chip
@@ -44,6 +45,7 @@
 
 #include <utility>
 
+#include "column_tasks.h"
 #include "device_common.h"
 #include "march_kernels.h"
 #include "nufft_mi355x.h"
@@ -76,7 +78,7 @@ struct SMarchCfg {
     // that pairs of cells stay 16-byte aligned in the grid) and M above in x; M - 1 rows below and M above in y
     static constexpr int XLO = HX ? ((M - 1) + ((M - 1) & 1)) : 0, XHI = HX ? M : 0;
     static constexpr int YLO = HY ? (M - 1) : 0, YHI = HY ? M : 0;
-    static constexpr int row_stride(int n1) { return padded_row_stride(NC * (n1 + XLO + XHI), NC * L, 8); }
+    static constexpr int row_stride(int n1) { return (padded_row_stride(NC * (n1 + XLO + XHI), NC * L, 8) + 1) & ~1; }   // even: rows of aligned pairs
     struct Dims { int n1, n2; };
     static constexpr int bin_rows(int n) { return tile_bin_rows_bound(true, n, 4, M); }
     // column interior (n1, n2): multiples of the bin edge, fewest point visits within the LDS budget
@@ -157,31 +159,42 @@ __device__ __forceinline__ void smarch_add_four(const uint32_t (&vb)[C::NBASE], 
     }
 }
 
-// Cells of a column that leave with atomics (and must be zero before the launch): the halo and the own cells within the
-// stencil's reach of a neighbour, at the granularity of aligned pairs of cells.  l: index relative to the column's first
-// cell, n: cells of the column (its last one may be shorter), M: half support.
-__device__ __forceinline__ bool smarch_band(int l, int n, int M) {
-    return (l & ~1) < M || (l | 1) >= n - (M - 1);
-}
-
-// Zero fill of the bands (one thread per aligned pair of reals along x; `plane_pairs` pairs per plane of the grid).  Only when
-// the ring serves the point set.
+// grid += side buffer (the general consumer: one thread per real of the grid gathers from the up to eight neighbouring columns).
 template <typename T>
-__global__ __launch_bounds__(256) void smarch_zero_bands_kernel(T* grid, int64_t comp_stride, Geom g, int nc, int n1, int n2, int hx, int hy, int M,
-                                                               const uint32_t* flag) {
+__global__ __launch_bounds__(256) void smarch_halo_add_kernel(T* grid, const T* halo, int64_t grid_comp, int64_t halo_comp, Geom g, HaloLayout h,
+                                                             const uint32_t* flag) {
     if (*flag == 0u) return;
-    typedef T T2 __attribute__((ext_vector_type(2)));
-    const int row_pairs = g.Nover[0] * nc / 2;
+    const int nc = h.nc, row_reals = g.Nover[0] * nc;
     const int64_t rows = (int64_t)g.Nover[1] * g.Nover[2];
-    T* gr = grid + (int64_t)blockIdx.y * comp_stride;
+    T* gr = grid + (int64_t)blockIdx.y * grid_comp;
+    const T* hb = halo + (int64_t)blockIdx.y * halo_comp;
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int y = (int)(row % g.Nover[1]);
-        const int ty = y / n2, ly = y - ty * n2, ny = min(n2, g.Nover[1] - ty * n2);
-        const bool by = hy && (ly < M || ly >= ny - (M - 1));
-        for (int xp = threadIdx.x; xp < row_pairs; xp += blockDim.x) {
-            const int x = 2 * xp / nc;
-            const int tx = x / n1, lx = x - tx * n1, nx = min(n1, g.Nover[0] - tx * n1);
-            if (by || (hx && smarch_band(lx, nx, M))) *reinterpret_cast<T2*>(gr + row * g.Nover[0] * nc + 2 * xp) = T2{T(0), T(0)};
+        const int y = (int)(row % g.Nover[1]), z = (int)(row / g.Nover[1]);
+        const int ty = y / h.n2, ly = y - ty * h.n2;
+        const T* hz = hb + (int64_t)z * h.plane;
+        for (int xr = threadIdx.x; xr < row_reals; xr += blockDim.x) {
+            const int x = xr / nc, comp = xr - x * nc;
+            const int tx = x / h.n1, lx = x - tx * h.n1;
+            T sum = T(0);
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int ry = ly - dy * h.n2;              // row relative to the source column's first row
+                if (ry < -h.ylo || ry >= h.n2 + h.yhi) continue;
+                int sy = ty + dy;
+                if (sy < 0) sy += h.nty;
+                if (sy >= h.nty) sy -= h.nty;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int rx = lx - dx * h.n1;
+                    if (rx < -h.xlo || rx >= h.n1 + h.xhi) continue;
+                    int sx = tx + dx;
+                    if (sx < 0) sx += h.ntx;
+                    if (sx >= h.ntx) sx -= h.ntx;
+                    sum += hz[((int64_t)sy * h.ntx + sx) * h.rec + halo_record_offset(h, (h.xlo + rx) * nc + comp, ry)];
+                }
+            }
+            if (sum != T(0)) gr[row * row_reals + xr] += sum;
         }
     }
 }
@@ -276,6 +289,8 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.sorted);
     const T* vin = a.vin[comp_id];
     T* grid = a.grid[comp_id];
+    // halo variant: the side buffer's records (columns of mg.n1 x mg.n2 cells: the plan takes it only for grids they divide)
+    const HaloLayout hl = make_halo_layout(mg.n1, mg.n2, M, NC, mg.ntx, mg.nty);
     __syncthreads();
 
     for (int li = 0; li < nli; ++li) {
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         {
             typedef double D2 __attribute__((ext_vector_type(2)));
             typedef T T2 __attribute__((ext_vector_type(2)));
-            const int rp = NC * wnx / 2;                // pairs per row of the window
+            const int rp = (NC * wnx + 1) / 2;          // pairs per row of the window (an odd last real pairs with a padding zero)
 #if NUFFT_SMARCH_ABL == 7
             const int npair = 0;
 #else
@@ -518,25 +533,25 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = pos[k * (PS / 2)];
 #if NUFFT_SMARCH_ABL != 3
-                    // the cell pair in the grid (the window wraps around the periodic axes), and how it leaves: cells within the
-                    // stencil's reach of a column boundary of an input-driven dimension also receive the neighbours' sums ->
-                    // atomics onto the zeroed band (smarch_zero_bands_kernel), everything else plain stores
+                    // where the pair goes: the column's own cells into the grid; the halo variant's reach into the column's
+                    // record of the side buffer (the consumer of the grid adds it to the neighbours' cells)
                     const int lx = 2 * xp / NC - C::XLO, ly = r - C::YLO;          // relative to the column's first cell
-                    const int gx = wrap_index(org1 + lx, g.Nover[0]), gy = wrap_index(org2 + ly, g.Nover[1]);
-                    const bool atomic = (HX && smarch_band(lx, neff1, M)) || (HY && (ly < M || ly >= neff2 - (M - 1)));
-                    const int64_t rowb = ((int64_t)gy * g.Nover[0] + gx) * NC + (2 * xp) % NC;
+                    T* dst0;
+                    int64_t pstride;                                               // reals between consecutive planes
+                    if ((HX || HY) && (lx < 0 || lx >= neff1 || ly < 0 || ly >= neff2)) {
+                        dst0 = static_cast<T*>(mg.halo) + (int64_t)comp_id * mg.halo_comp + (int64_t)(4 * zb0) * hl.plane +
+                               ((int64_t)ty * mg.ntx + tx) * hl.rec + halo_record_offset(hl, 2 * xp, ly);
+                        pstride = hl.plane;
+                    } else {
+                        const int gx = wrap_index(org1 + lx, g.Nover[0]), gy = wrap_index(org2 + ly, g.Nover[1]);
+                        pstride = (int64_t)g.Nover[1] * g.Nover[0] * NC;
+                        dst0 = grid + (int64_t)(4 * zb0) * pstride + ((int64_t)gy * g.Nover[0] + gx) * NC + (2 * xp) % NC;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int qq = wq + k;
-                        if (qq >= 0 && qq < nq) {       // (plane 4 zb0 + qq < Nover[2]: the task owns it)
-                            T* dst = grid + (int64_t)(4 * zb0 + qq) * g.Nover[1] * g.Nover[0] * NC + rowb;
-                            if (!(HX || HY) || !atomic || NUFFT_SMARCH_ABL == 8) {
-                                *reinterpret_cast<T2*>(dst) = T2{(T)v[k].x, (T)v[k].y};
-                            } else {
-                                if (v[k].x != 0.0) (void)__hip_atomic_fetch_add(dst, (T)v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (v[k].y != 0.0) (void)__hip_atomic_fetch_add(dst + 1, (T)v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
+                        if (qq >= 0 && qq < nq)         // (plane 4 zb0 + qq < Nover[2]: the task owns it)
+                            *reinterpret_cast<T2*>(dst0 + (int64_t)qq * pstride) = T2{(T)v[k].x, (T)v[k].y};
                     }
 #else
 #pragma unroll

@@ -67,11 +67,11 @@ const void* smarch_kernel_f32r(int M, int halo, bool poly, int* lds_bytes, int* 
 const void* smarch_kernel_f32c(int M, int halo, bool poly, int* lds_bytes, int* n);
 const void* smarch_kernel_f64r(int M, int halo, bool poly, int* lds_bytes, int* n);
 const void* smarch_kernel_f64c(int M, int halo, bool poly, int* lds_bytes, int* n);
-hipError_t smarch_zero_bands_f32(void* grid, int64_t comp_stride_reals, const Geom& g, int nc, int C, int n1, int n2, int hx, int hy, int M,
-                                 const uint32_t* flag, hipStream_t stream);
-hipError_t smarch_zero_bands_f64(void* grid, int64_t comp_stride_reals, const Geom& g, int nc, int C, int n1, int n2, int hx, int hy, int M,
-                                 const uint32_t* flag, hipStream_t stream);
-// halo: 0 / 1 / 2 = output-driven / input-driven in x / in x and y; poly: the instantiation with the piecewise-polynomial window
+hipError_t smarch_halo_add_f32(void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, const Geom& g, int nc, int C,
+                               int n1, int n2, int M, int ntx, int nty, const uint32_t* flag, hipStream_t stream);
+hipError_t smarch_halo_add_f64(void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, const Geom& g, int nc, int C,
+                               int n1, int n2, int M, int ntx, int nty, const uint32_t* flag, hipStream_t stream);
+// halo: 0 / 2 = output-driven columns / the halo variant; poly: the instantiation with the piecewise-polynomial window
 // (FastApproximation) or the direct one
 static const void* smarch_kernel(int dtype, int is_complex, int M, int halo, bool poly, int* lds_bytes, int* n) {
     if (M < 2 || M > 10) return nullptr;
@@ -114,10 +114,11 @@ static double smarch_makespan(const std::vector<double>& task_work, int C, int c
 SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo) {
     SMarchPlan sp{};
     int lds = 0, n[5];
-    if (halo < 0 || halo > 2) halo = 0;
+    if (halo != 2) halo = 0;
     sp.halo = halo;
     if (D != 3 || other || !smarch_kernel(dtype, is_complex, M, halo, true, &lds, n)) return sp;
-    const bool hx = halo >= 1, hy = halo >= 2;
+    const bool hx = halo == 2, hy = halo == 2;
+    const int xreach = hx ? (M - 1) + ((M - 1) & 1) + M : 0, yreach = hy ? 2 * M - 1 : 0;
     for (int d = 0; d < 3; ++d)
         if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return sp;
     const int L = 2 * M, hlo = n[2], hhi = n[3];
@@ -140,6 +141,8 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
             if (force_n1 && n1 != force_n1) continue;
             if (n1 + L - 1 > g.Nover[0] || (n1 < n[0] / 2 && n1 + 4 + L - 1 <= g.Nover[0] && !force_n1)) continue;
             if ((hx && n1 + 2 * L > g.Nover[0]) || (hy && n2 + 2 * L > g.Nover[1])) continue;
+            // halo variant: whole columns only, wider than the reach (a cell then receives from one neighbour per side)
+            if (halo == 2 && (g.Nover[0] % n1 || g.Nover[1] % n2 || n1 < xreach || n2 < yreach)) continue;
             const int ncx = (g.Nover[0] + n1 - 1) / n1, ncy = (g.Nover[1] + n2 - 1) / n2;
             if ((int64_t)ncx * ncy >= 65536) continue;
             // relative cost of a layer of each column: the points it visits
@@ -163,7 +166,11 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
                     const int len = std::min(segl, g.nb[2] - k * segl);
                     for (double w : colw) work.push_back(w * (len + cz + fixed));
                 }
-                const double cost = smarch_makespan(work, C, cus, xcd_chunk) / ideal;
+                double cost = smarch_makespan(work, C, cus, xcd_chunk) / ideal;
+                // halo variant: the reach is retired, stored and read again by the FFT pass — cost in proportion to its share of
+                // the column (C2, 32 x 32: 0.49 of the grid's bytes, + 0.15 ms of FFT pass beside 1.87 ms of spreading; measured
+                // 256^3 / 1e6 points: 16 x 16 x 1 segment 0.48 ms against 0.41 ms for 32 x 32 x 4 without this term)
+                if (halo == 2) cost += 0.25 * ((double)(n1 + xreach) * (n2 + yreach) / ((double)n1 * n2) - 1.0);
                 if (cost < best) {
                     best = cost;
                     sp.n1 = n1; sp.n2 = n2;
@@ -178,6 +185,7 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
     }
     if (best >= 1e300) return sp;
     sp.hlo = hlo; sp.hhi = hhi;
+    if (halo == 2) sp.halo_reals = make_halo_layout(sp.n1, sp.n2, M, is_complex ? 2 : 1, sp.ct.ncolx, sp.ct.ncoly).plane * g.Nover[2];
     sp.lds_bytes = lds;
     sp.threads = n[4];
     sp.eligible = true;
@@ -564,14 +572,7 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
     int lds = 0, n[5];
     const void* fn = smarch_kernel(a.dtype, a.is_complex, a.M, sp.halo, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
     if (!fn) return hipErrorInvalidValue;
-    if (sp.halo > 0) {
-        // halo variants: the cells near column boundaries are accumulated with global atomics onto zeroed bands
-        const int ncr = a.is_complex ? 2 : 1;
-        hipError_t e = a.dtype == NUFFT_F32
-            ? smarch_zero_bands_f32(a.grid, a.grid_stride * ncr, a.g, ncr, a.C, sp.n1, sp.n2, sp.halo >= 1, sp.halo >= 2, a.M, flag, stream)
-            : smarch_zero_bands_f64(a.grid, a.grid_stride * ncr, a.g, ncr, a.C, sp.n1, sp.n2, sp.halo >= 1, sp.halo >= 2, a.M, flag, stream);
-        if (e != hipSuccess) return e;
-    }
+    if (sp.halo == 2 && !a.halo) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
@@ -585,6 +586,8 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
         mg.tasktab = tasktab;
         mg.n1 = sp.n1;
         mg.n2 = sp.n2;
+        mg.halo = sp.halo == 2 ? static_cast<void*>(static_cast<T*>(a.halo) + (int64_t)c0 * sp.halo_reals) : nullptr;
+        mg.halo_comp = sp.halo_reals;
         void* params[] = {&k, &mg};
         hipError_t e = hipLaunchKernel(fn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)n[4], 1, 1), params, (size_t)lds, stream);
         if (e != hipSuccess) return e;
@@ -593,6 +596,14 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
 }
 hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
     return a.dtype == NUFFT_F32 ? launch_smarch_t<float>(a, sp, flag, tasktab, stream) : launch_smarch_t<double>(a, sp, flag, tasktab, stream);
+}
+hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, hipStream_t stream) {
+    if (sp.halo != 2) return hipSuccess;
+    if (!a.halo) return hipErrorInvalidValue;
+    const int ncr = a.is_complex ? 2 : 1;
+    return a.dtype == NUFFT_F32
+        ? smarch_halo_add_f32(a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g, ncr, a.C, sp.n1, sp.n2, a.M, sp.ct.ncolx, sp.ct.ncoly, flag, stream)
+        : smarch_halo_add_f64(a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g, ncr, a.C, sp.n1, sp.n2, a.M, sp.ct.ncolx, sp.ct.ncoly, flag, stream);
 }
 
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream) {

@@ -60,7 +60,7 @@ print(f"plan: Nover={plan.oversampled_dims} bins={[info.bin_dims[d] for d in ran
       f"interp_tile={[info.interp_tile[d] for d in range(a.dim)]} x{[info.interp_ntiles[d] for d in range(a.dim)]} "
       f"lds={info.lds_bytes_spread}/{info.lds_bytes_interp} "
       f"threads={info.spread_threads}/{info.interp_threads} workspace={info.workspace_bytes / 1e9:.2f} GB "
-      f"spread_method={info.spread_method} ring_column={list(info.ring_column)} x{info.ring_segments} segments", flush=True)
+      f"spread_method={info.spread_method} ring_column={list(info.ring_column)} x{info.ring_segments} segments halo={info.ring_halo}", flush=True)
 
 g = torch.Generator(device="cuda").manual_seed(42)
 if a.dist == "uniform":

@@ -439,13 +439,15 @@ def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
 
 @pytest.mark.parametrize("M", range(2, 11))
 @pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
-def test_spreading_ring_every_instantiation(Z, M):
-    """Every (element type, M) instantiation of spread_march_kernel against the oracle (type 1, both window evaluations), the
+def test_spreading_ring_every_instantiation(Z, M, monkeypatch):
+    """Every (element type, M) instantiation of spread_march_kernel (clipped columns: the halo variant has its own test below)
+    against the oracle (type 1, both window evaluations), the
     ring requested explicitly and nufft_spread_engine_used confirming the device-side flag.  Oversampled grid 96 x 80 x 112:
     partial columns at the upper ends of dimensions 1 and 2, columns at the periodic boundary (two runs per row of bins),
     several segments along dimension 3 (first / last layers clip along z, the others take the per-slot code); a point set
     concentrated in a corner exercises the tasks of equal point count (quantile segments, empty tasks that only store zeros)."""
     dims, Np = (48, 40, 56), 4000
+    monkeypatch.setenv("NUFFT_SMARCH_HALO", "0")
     for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
         if np.dtype(Z) == np.complex128 and M == 10:
             # the LDS tiles of this plan need 2-cell bins (plan_math.cpp); the ring, like the patches, sorts by 4-cell bins
@@ -455,7 +457,7 @@ def test_spreading_ring_every_instantiation(Z, M):
                 _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M, spread_method="marching_ring")
             return
         nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M, spread_method="marching_ring")
-        assert plan.info().spread_method == 3 and plan.info().ring_column[0] > 0
+        assert plan.info().spread_method == 3 and plan.info().ring_column[0] > 0 and plan.info().ring_halo == 0
         dev = plan.device
         for name in ("uniform", "corner"):
             pts = xs if name == "uniform" else tuple((0.3 * x * x / (2 * np.pi)).astype(x.dtype) for x in xs)
@@ -466,6 +468,50 @@ def test_spreading_ring_every_instantiation(Z, M):
             assert plan.spread_engine_used() == "marching_ring", (name, evalmode)
             ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs)[0])
             assert _rel(u.cpu().numpy(), ref) < _rtol(Z), (name, evalmode)
+
+
+@pytest.mark.parametrize("M", range(2, 11))
+@pytest.mark.parametrize("Z,C", [(np.float32, 1), (np.float64, 1), (np.float64, 2)])
+def test_spreading_ring_halo_variant_every_instantiation(Z, C, M, monkeypatch):
+    """The halo variant of spread_march_kernel (real data: every point spread once by its own column, the stencil's reach beyond
+    the column through a side buffer) for every M, both window evaluations, against the oracle — three consumers of the side
+    buffer: the plan's own dimension-1 FFT pass (exec_type1), the separate add pass in front of the FFT
+    (NUFFT_SMARCH_HALO_FUSE=0), and the stage-level entry point (spread_from_points: the oversampled grid itself against the
+    oracle's).  Oversampled grid 96 x 96 x 112: whole columns (the variant needs them), columns at the periodic boundary whose
+    reach wraps around, several segments along dimension 3, and a point set concentrated in a corner (tasks of equal point count).
+    Where no halo kernel exists (LDS: Float64 at M >= 8) the plan falls back to the clipped columns — asserted for M <= 7."""
+    dims, Np = (48, 48, 56), 4000
+    monkeypatch.setenv("NUFFT_SMARCH_HALO", "2")
+    for evalmode, fuse in ((O.FAST_APPROXIMATION, "1"), (O.DIRECT, "1"), (O.FAST_APPROXIMATION, "0")):
+        monkeypatch.setenv("NUFFT_SMARCH_HALO_FUSE", fuse)
+        nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, C, Np, seed=500 + M, spread_method="marching_ring")
+        info = plan.info()
+        assert info.spread_method == 3 and info.ring_column[0] > 0
+        assert 96 % info.ring_column[0] == 0 and 96 % info.ring_column[1] == 0 or info.ring_halo == 0
+        if M <= 7:
+            assert info.ring_halo == 1, (M, list(info.ring_column))
+        dev = plan.device
+        for name in ("uniform", "corner"):
+            pts = xs if name == "uniform" else tuple((0.3 * x * x / (2 * np.pi)).astype(x.dtype) for x in xs)
+            nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
+            O.set_points(oplan, pts)
+            us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+            vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
+            nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+            assert plan.spread_engine_used() == "marching_ring", (name, evalmode)
+            ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs) if C > 1 else _oracle_inputs(oplan, vs)[0])
+            for c in range(C):
+                assert _rel(us[c].cpu().numpy(), ref[c] if C > 1 else ref) < _rtol(Z), (name, evalmode, fuse, c)
+        if fuse == "1" and evalmode == O.DIRECT:
+            # stage level: the grid after spread_from_points is complete (the add pass ran) — against the oracle's grid
+            nufft.spread_from_points(plan, vd if C > 1 else vd[0])
+            scale = 2.0 ** sum(info.window_scale_log2[d] for d in range(3))
+            o64 = O.OraclePlan(dims, is_real=True, dtype=np.float64, M=M, sigma=2.0, evalmode=evalmode, ntransforms=C)
+            O.set_points(o64, [x.astype(np.float64) for x in pts])
+            refg = O.spread(o64, [v.astype(np.float64) for v in vs])
+            for c in range(C):
+                grid = nufft.oversampled_grid(plan, c).cpu().numpy().astype(np.float64) / scale
+                assert _rel(grid, refg[c]) < (1e-12 if Z == np.float64 else 1e-5), (M, c)
 
 
 @pytest.mark.parametrize("Z,C", [(np.float64, 1), (np.float64, 3), (np.float32, 2), (np.complex128, 1)])
