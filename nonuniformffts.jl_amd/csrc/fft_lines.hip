@@ -311,27 +311,29 @@ struct RealLineArgs {
 // complex elements of the line).  Strips of the x reach: one aligned pair per lane and step, distinct cells for distinct columns
 // (columns are wider than the reach).  Rows of the y reach (lines within the reach of a column boundary only): the rows of
 // neighbouring columns overlap, so even and odd columns take turns (and the last column of an odd count goes alone).
-template <typename T, typename C>
-__device__ __forceinline__ void add_halo_to_line(const RealLineArgs& a, C* line, int64_t line_id, int lane, int n) {
+// NC = 1: real lines, a pair = two cells = one complex element of the packed line (n = cells per line); NC = 2: complex lines, a pair = one cell.
+template <typename T, typename C, int NC>
+__device__ __forceinline__ void add_halo_to_line(const void* halo, const HaloLayout& h, int ny, C* line, int64_t line_id, int lane, int n) {
     typedef T T2 __attribute__((ext_vector_type(2)));
-    const HaloLayout& h = a.hl;
-    const int y = (int)(line_id % a.ny), z = (int)(line_id / a.ny);
+    const int y = (int)(line_id % ny), z = (int)(line_id / ny);
     const int ty = y / h.n2, ly = y - ty * h.n2;
-    const T* hz = static_cast<const T*>(a.halo) + (int64_t)z * h.plane;
-    auto add_pair = [&](int x0, T2 v) __attribute__((always_inline)) {
+    const T* hz = static_cast<const T*>(halo) + (int64_t)z * h.plane;
+    auto add_pair = [&](int x0, T2 v) __attribute__((always_inline)) {       // x0: first cell of the pair
         if (x0 < 0) x0 += n;
         if (x0 >= n) x0 -= n;
-        C c = line[lpad(x0 >> 1)];
+        const int e = NC == 1 ? x0 >> 1 : x0;
+        C c = line[lpad(e)];
         c.x += v.x;
         c.y += v.y;
-        line[lpad(x0 >> 1)] = c;
+        line[lpad(e)] = c;
     };
+    constexpr int CPP = 2 / NC;                         // cells per pair
     {
         const int sp = h.sw / 2;
         const T* row = hz + (int64_t)ty * h.ntx * h.rec + ly * h.sw;
         for (int idx = lane; idx < h.ntx * sp; idx += kWave) {
-            const int tx = idx / sp, i = 2 * (idx - tx * sp);
-            const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + i);
+            const int tx = idx / sp, pi = idx - tx * sp, i = CPP * pi;       // i: cell index within the strip
+            const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + 2 * pi);
             add_pair(i < h.xlo ? tx * h.n1 - h.xlo + i : tx * h.n1 + h.n1 + (i - h.xlo), v);
         }
         wave_lds_fence();
@@ -346,10 +348,10 @@ __device__ __forceinline__ void add_halo_to_line(const RealLineArgs& a, C* line,
         for (int par = 0; par < 3; ++par) {
             const int ncol = par == 2 ? (h.ntx & 1) : neven / 2;
             for (int idx = lane; idx < ncol * rp; idx += kWave) {
-                const int k = idx / rp, i = 2 * (idx - k * rp);
+                const int k = idx / rp, pi = idx - k * rp;
                 const int tx = par == 2 ? h.ntx - 1 : 2 * k + par;
-                const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + i);
-                add_pair(tx * h.n1 - h.xlo + i, v);
+                const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + 2 * pi);
+                add_pair(tx * h.n1 - h.xlo + CPP * pi, v);
             }
             wave_lds_fence();
         }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         for (int n = lane; n < M; n += kWave) line[lpad(n)] = zin[n];
         wave_lds_fence();
         if constexpr (HALO) {
-            if (*a.hflag != 0u) add_halo_to_line<T, C>(a, line, line_id, lane, N);
+            if (*a.hflag != 0u) add_halo_to_line<T, C, 1>(a.halo, a.hl, a.ny, line, line_id, lane, N);
         }
         fft_line<T, M, -1, 2>(line, tw, lane);
         C* xout = static_cast<C*>(a.out) + line_id * a.row;
@@ -437,9 +439,14 @@ struct CplxLineArgs {
     int k1;                 // kept modes per line
     const int32_t* map;     // [k1]
     const void* twiddle;    // complex<T>[N]
+    // forward pass behind the halo variant of the spreading ring (see RealLineArgs)
+    const void* halo;
+    const uint32_t* hflag;
+    int ny;
+    HaloLayout hl;
 };
 
-template <typename T, int N, bool FWD, int TL>
+template <typename T, int N, bool FWD, int TL, bool HALO = false>
 __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) {
     using C = typename Cplx2<T>::type;
     constexpr int LINE = N + (N >> 4) + 1;
@@ -459,6 +466,9 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
         const C* zin = static_cast<const C*>(a.in) + line_id * N;
         for (int n = lane; n < N; n += kWave) line[lpad(n)] = zin[n];
         wave_lds_fence();
+        if constexpr (HALO) {
+            if (*a.hflag != 0u) add_halo_to_line<T, C, 2>(a.halo, a.hl, a.ny, line, line_id, lane, N);
+        }
         fft_line<T, N, -1>(line, tw, lane);
         C* xout = static_cast<C*>(a.out) + line_id * a.k1;
         for (int k = lane; k < a.k1; k += kWave) xout[k] = line[lpad(a.map[k])];
@@ -563,17 +573,19 @@ static hipError_t launch_cplx_n(const CplxLineArgs& a, hipStream_t stream) {
     constexpr int TL = (sizeof(C) * (16 * LINE + N) <= 80 * 1024) ? 16 : 8;
     static_assert(sizeof(C) * (size_t)(TL * LINE + N) <= kFftLdsLimit, "line buffers exceed the 160 KiB of LDS");
     const size_t lds = sizeof(C) * (size_t)(TL * LINE + N);
-    auto fn = cplx_lines_kernel<T, N, FWD, TL>;
+    auto fn = cplx_lines_kernel<T, N, FWD, TL, false>;
+    auto fnh = cplx_lines_kernel<T, N, FWD, TL, FWD>;
     static std::atomic<unsigned long long> prepared{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(prepared.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && FWD) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fnh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         prepared.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)((a.nlines + TL - 1) / TL)), dim3(TL * kWave), lds, stream, a);
+    hipLaunchKernelGGL((FWD && a.halo) ? fnh : fn, dim3((unsigned)((a.nlines + TL - 1) / TL)), dim3(TL * kWave), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -587,10 +599,68 @@ static hipError_t launch_cplx_t(int n, const CplxLineArgs& a, hipStream_t stream
     }
 }
 
+// grid += side buffer of the spreading window's halo variant, line by line through LDS (the consumer for the stage-level
+// nufft_spread and for plans whose first FFT pass is not real_lines_kernel / cplx_lines_kernel): one wave per line of the grid,
+// the same add_halo_to_line as the fused passes.  ne: complex-sized elements per line (real data: pairs of cells).
+template <typename T, int NC>
+__global__ __launch_bounds__(1024) void halo_add_lines_kernel(T* grid, const T* halo, int64_t nlines, int ny, int ne, HaloLayout h, const uint32_t* flag,
+                                                              int64_t grid_comp, int64_t halo_comp) {
+    using C = typename Cplx2<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (*flag == 0u) return;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nw = blockDim.x / kWave;
+    const int LINE = ne + (ne >> 4) + 1;
+    C* line = reinterpret_cast<C*>(smem) + (size_t)wave * LINE;
+    const int64_t line_id = (int64_t)blockIdx.x * nw + wave;
+    if (line_id >= nlines) return;
+    C* g = reinterpret_cast<C*>(grid + (int64_t)blockIdx.y * grid_comp) + line_id * ne;
+    for (int n = lane; n < ne; n += kWave) line[lpad(n)] = g[n];
+    wave_lds_fence();
+    add_halo_to_line<T, C, NC>(halo + (int64_t)blockIdx.y * halo_comp, h, ny, line, line_id, lane, NC == 1 ? 2 * ne : ne);
+    for (int n = lane; n < ne; n += kWave) g[n] = line[lpad(n)];
+}
+
+template <typename T>
+static hipError_t launch_halo_add_lines_t(void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, int n1cells, int ny, int nz,
+                                          int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream) {
+    using Cx = typename Cplx2<T>::type;
+    const int ne = h.nc == 1 ? n1cells / 2 : n1cells;
+    const int LINE = ne + (ne >> 4) + 1;
+    int nw = 16;
+    while (nw > 1 && (size_t)nw * LINE * sizeof(Cx) > 72 * 1024) nw >>= 1;
+    const size_t lds = (size_t)nw * LINE * sizeof(Cx);
+    if (lds > kFftLdsLimit || (h.nc == 1 && (n1cells & 1))) return hipErrorInvalidValue;
+    const int64_t nlines = (int64_t)ny * nz;
+    auto fn = h.nc == 1 ? halo_add_lines_kernel<T, 1> : halo_add_lines_kernel<T, 2>;
+    static std::atomic<unsigned long long> prepared{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(prepared.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(halo_add_lines_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLdsLimit);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(halo_add_lines_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLdsLimit);
+        if (e != hipSuccess) return e;
+        prepared.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)((nlines + nw - 1) / nw), (unsigned)C, 1), dim3(nw * kWave), lds, stream, static_cast<T*>(grid),
+                       static_cast<const T*>(halo), nlines, ny, ne, h, flag, grid_comp_reals, halo_comp_reals);
+    return hipGetLastError();
+}
+
+hipError_t launch_halo_add_lines(int dtype, void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, int n1cells, int ny, int nz,
+                                 int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream) {
+    return dtype == NUFFT_F32 ? launch_halo_add_lines_t<float>(grid, halo, grid_comp_reals, halo_comp_reals, n1cells, ny, nz, C, h, flag, stream)
+                              : launch_halo_add_lines_t<double>(grid, halo, grid_comp_reals, halo_comp_reals, n1cells, ny, nz, C, h, flag, stream);
+}
+
 hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
-                             const int32_t* map, const void* twiddle, hipStream_t stream) {
-    CplxLineArgs a;
+                             const int32_t* map, const void* twiddle, hipStream_t stream, const RealLineHalo* halo) {
+    CplxLineArgs a{};
     a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.map = map; a.twiddle = twiddle;
+    if (halo && halo->buffer && forward) {
+        if (halo->layout.nc != 2 || halo->ny <= 0) return hipErrorInvalidValue;
+        a.halo = halo->buffer; a.hflag = halo->flag; a.ny = halo->ny; a.hl = halo->layout;
+    }
     if (dtype == NUFFT_F32) return forward ? launch_cplx_t<float, true>((int)n, a, stream) : launch_cplx_t<float, false>((int)n, a, stream);
     return forward ? launch_cplx_t<double, true>((int)n, a, stream) : launch_cplx_t<double, false>((int)n, a, stream);
 }

@@ -200,8 +200,11 @@ struct RealLineHalo {
 hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1, int row,
                              const void* twiddle, hipStream_t stream, const RealLineHalo* halo = nullptr);
 hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePass& p, hipStream_t stream);
+// grid += side buffer of the spreading window's halo variant, line by line (C components; lines of n1cells cells, planes of ny lines)
+hipError_t launch_halo_add_lines(int dtype, void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, int n1cells, int ny, int nz,
+                                 int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream);
 // c2c of `nlines` contiguous complex lines of length n with a compact spectrum of k1 kept modes (map: kept -> FFT index)
 hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
-                             const int32_t* map, const void* twiddle, hipStream_t stream);
+                             const int32_t* map, const void* twiddle, hipStream_t stream, const RealLineHalo* halo = nullptr);
 
 }  // namespace nufft

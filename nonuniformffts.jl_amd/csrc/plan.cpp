@@ -145,7 +145,13 @@ static int env_int(const char* name, int fallback) {
 // 11.4 / 20.7 with clipped columns, 1.88 / 2.22 / 2.62 / 4.68 / 8.35 / 14.8 with the halo variant; Float32 alike (m = 8: 17.3 -> 13.1).
 // Only where the plan's own dimension-1 pass adds the side buffer (real plans on the pruned FFT path); smarch_plan falls back to the
 // clipped columns where the variant cannot run (axes the column does not divide, LDS).
-static int smarch_halo_default(const nufft_plan* p) { return (!p->is_complex && p->D == 3) ? 2 : 0; }   // (build_device: ... and the pruned real FFT path)
+// Complex data (interleaved components double the window): it pays where a 32 x 16 column or larger still fits — ComplexF64 m = 2 (3.29 -> 2.84 ms),
+// ComplexF32 m = 2, 3 (2.55 -> 1.97, 4.03 -> 3.51); with 16 x 16 columns the reach is 1.2 x the grid (ComplexF64 m = 3: 4.70 -> 5.08 ms).
+static int smarch_halo_default(const nufft_plan* p) {      // (build_device: ... and only on the plan's own pruned FFT path)
+    if (p->D != 3) return 0;
+    if (!p->is_complex) return 2;
+    return p->M <= (p->dtype == NUFFT_F32 ? 3 : 2) ? 2 : 0;
+}
 
 static int build_host(nufft_plan* p, const nufft_params* in) {
     p->dtype = in->dtype;
@@ -764,6 +770,14 @@ static int ilog2(int64_t n) {
 // ---- pruned FFT path (see fft_lines.hip) ---------------------------------------------------------
 // type 1, stage "FFT": rocFFT r2c along dim 1 and, for D = 3, the pruned pass along dim 2 into tmp2.
 static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
+    // behind the halo variant of the spreading ring (nufft_spread_deferred): the pass adds the side buffer while it loads its lines
+    RealLineHalo hh{};
+    const bool fuse = p->halo_pending && p->D == 3;
+    if (fuse) {
+        hh.flag = p->d_smarch_choice + 2;
+        hh.ny = (int)p->Nover[1];
+        hh.layout = make_halo_layout(p->smarch.n1, p->smarch.n2, p->M, p->is_complex ? 2 : 1, p->smarch.ct.ncolx, p->smarch.ct.ncoly);
+    }
     if (p->is_complex) {
         int64_t per = 1;
         for (int d = 1; d < p->D; ++d) per *= p->Nover[d];
@@ -771,7 +785,9 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
         for (int c = 0; c < p->C; ++c) {
             const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * cb;
             void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * cb;
-            NUFFT_HIP(launch_cplx_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], p->d_index_map[0], p->d_tw_fw[0], stream));
+            hh.buffer = static_cast<char*>(p->d_smarch_halo) + (size_t)c * p->smarch.halo_reals * real_bytes(p);
+            NUFFT_HIP(launch_cplx_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], p->d_index_map[0], p->d_tw_fw[0], stream,
+                                        fuse ? &hh : nullptr));
         }
         return NUFFT_OK;
     }
@@ -780,14 +796,6 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
         for (int d = 1; d < p->D; ++d) nlines *= p->Nover[d];
         // components are contiguous both in us (Ñ1 reals per line) and in the compact spectrum (N_out1 per line);
         // the per-component offset of the compact spectrum is nlines_per_component * N_out1 <= spec_elems
-        // behind the halo variant of the spreading ring (exec_type1): the pass adds the side buffer while it loads its lines
-        RealLineHalo hh{};
-        const bool fuse = p->halo_pending && p->D == 3;
-        if (fuse) {
-            hh.flag = p->d_smarch_choice + 2;
-            hh.ny = (int)p->Nover[1];
-            hh.layout = make_halo_layout(p->smarch.n1, p->smarch.n2, p->M, 1, p->smarch.ct.ncolx, p->smarch.ct.ncoly);
-        }
         const size_t rb = real_bytes(p);
         if (p->C == 1) {
             hh.buffer = p->d_smarch_halo;
@@ -1316,7 +1324,7 @@ int nufft_fft_forward(nufft_plan* p, void* stream_) {
     // behind nufft_spread_deferred: the dimension-1 pass of a real plan's own FFT adds the side buffer while it loads its lines;
     // every other FFT path gets the completed grid
     struct Pending { nufft_plan* p; ~Pending() { p->halo_pending = false; } } pending{p};
-    const bool fuse_halo = p->halo_pending && p->pruned_fft && !p->is_complex && p->compact_dim1 && p->D == 3 && p->halo_fuse;
+    const bool fuse_halo = p->halo_pending && p->pruned_fft && p->compact_dim1 && p->D == 3 && p->halo_fuse;      // (compact_dim1: true for complex plans)
     if (p->halo_pending && !fuse_halo && (rc = complete_halo(p, stream))) return rc;
     p->halo_pending = fuse_halo;
     if (p->pruned_fft) {

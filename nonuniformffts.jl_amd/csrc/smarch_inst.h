@@ -17,13 +17,10 @@ static void smarch_entry_h(bool poly, const void** fn, int* lds_bytes, int* n) {
     }
 }
 // halo: 0 = output-driven in x and y (clipped: the column visits every point whose stencil reaches it); 2 = the halo variant
-// (every point spread once by its own column, the reach into a side buffer: smarch_kernels.h).  Real data only: the consumer
-// fused into the first FFT pass exists for real plans.
+// (every point spread once by its own column, the reach into a side buffer: smarch_kernels.h).
 template <int M>
 static void smarch_entry(int halo, bool poly, const void** fn, int* lds_bytes, int* n) {
-#if !NUFFT_CPLX_IS_TRUE
     if (halo == 2) { smarch_entry_h<M, true, true>(poly, fn, lds_bytes, n); return; }
-#endif
     if (halo == 0) smarch_entry_h<M, false, false>(poly, fn, lds_bytes, n);
 }
 

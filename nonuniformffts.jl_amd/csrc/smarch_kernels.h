@@ -159,7 +159,8 @@ __device__ __forceinline__ void smarch_add_four(const uint32_t (&vb)[C::NBASE], 
     }
 }
 
-// grid += side buffer (the general consumer: one thread per real of the grid gathers from the up to eight neighbouring columns).
+// grid += side buffer (the general consumer: one thread per real of the grid that receives anything gathers from the up to eight
+// neighbouring columns).
 template <typename T>
 __global__ __launch_bounds__(256) void smarch_halo_add_kernel(T* grid, const T* halo, int64_t grid_comp, int64_t halo_comp, Geom g, HaloLayout h,
                                                              const uint32_t* flag) {
@@ -172,9 +173,15 @@ __global__ __launch_bounds__(256) void smarch_halo_add_kernel(T* grid, const T* 
         const int y = (int)(row % g.Nover[1]), z = (int)(row / g.Nover[1]);
         const int ty = y / h.n2, ly = y - ty * h.n2;
         const T* hz = hb + (int64_t)z * h.plane;
-        for (int xr = threadIdx.x; xr < row_reals; xr += blockDim.x) {
-            const int x = xr / nc, comp = xr - x * nc;
-            const int tx = x / h.n1, lx = x - tx * h.n1;
+        // cells that receive anything: in a row within the y reach of a column boundary all of them, else only the xhi first and
+        // xlo last cells of every column (41 % of the grid at 32 x 32, m = 4)
+        const bool yaff = ly < h.yhi || ly >= h.n2 - h.ylo;
+        const int per = yaff ? h.n1 : h.xlo + h.xhi;
+        for (int t = threadIdx.x; t < h.ntx * per * nc; t += blockDim.x) {
+            const int comp = t % nc, c = t / nc;
+            const int tx = c / per, k = c - tx * per;
+            const int lx = yaff ? k : (k < h.xhi ? k : h.n1 - h.xlo + (k - h.xhi));
+            const int xr = (tx * h.n1 + lx) * nc + comp;
             T sum = T(0);
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy) {

@@ -601,6 +601,14 @@ hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp,
     if (sp.halo != 2) return hipSuccess;
     if (!a.halo) return hipErrorInvalidValue;
     const int ncr = a.is_complex ? 2 : 1;
+    // line by line through LDS (fft_lines.hip: 0.6 ms at C2); the element-wise gather kernel (1.5 ms) where a line does not fit
+    static const bool gather = [] { const char* e = std::getenv("NUFFT_SMARCH_HALO_ADD_GATHER"); return e && *e && std::atoi(e) != 0; }();
+    if (!gather) {
+        const HaloLayout h = make_halo_layout(sp.n1, sp.n2, a.M, ncr, sp.ct.ncolx, sp.ct.ncoly);
+        hipError_t e = launch_halo_add_lines(a.dtype, a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g.Nover[0], a.g.Nover[1], a.g.Nover[2], a.C, h, flag, stream);
+        if (e != hipErrorInvalidValue) return e;
+        (void)hipGetLastError();
+    }
     return a.dtype == NUFFT_F32
         ? smarch_halo_add_f32(a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g, ncr, a.C, sp.n1, sp.n2, a.M, sp.ct.ncolx, sp.ct.ncoly, flag, stream)
         : smarch_halo_add_f64(a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g, ncr, a.C, sp.n1, sp.n2, a.M, sp.ct.ncolx, sp.ct.ncoly, flag, stream);

@@ -12,6 +12,8 @@ CASES = [  # (n, sigma, m, Z, Np, C, mode)
     (64, 2.0, 3, "f64", 100000, 1, "poly"), (64, 2.0, 5, "f32", 100000, 1, "poly"), (64, 2.0, 2, "f32", 100000, 3, "poly"),
     (96, 2.0, 6, "f64", 100000, 1, "poly"), (128, 2.0, 4, "f64", 1000000, 1, "poly"), (64, 2.0, 7, "f64", 50000, 1, "poly"),
     (128, 2.0, 8, "f32", 50000, 1, "direct"),
+    (64, 2.0, 4, "c128", 100000, 1, "poly"), (64, 2.0, 3, "c64", 100000, 2, "direct"), (128, 2.0, 2, "c128", 100000, 1, "poly"),
+    (64, 1.5, 4, "c64", 100000, 1, "poly"), (128, 2.0, 5, "c128", 50000, 1, "poly"),
 ]
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -20,14 +22,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from nufft_pkg import nufft
     out = {}
     for ci, (n, sigma, m, z, Np, C, mode) in enumerate(CASES):
-        Z = {"f64": torch.float64, "f32": torch.float32}[z]
+        Z = {"f64": torch.float64, "f32": torch.float32, "c128": torch.complex128, "c64": torch.complex64}[z]
+        T = torch.float64 if z in ("f64", "c128") else torch.float32
         g = torch.Generator(device="cuda").manual_seed(100 + ci)
-        xs = tuple(torch.rand(Np, dtype=Z, device="cuda", generator=g) * (2 * np.pi) for _ in range(3))
+        xs = tuple(torch.rand(Np, dtype=T, device="cuda", generator=g) * (2 * np.pi) for _ in range(3))
         vs = tuple(torch.randn(Np, dtype=Z, device="cuda", generator=g) for _ in range(C))
         ev = nufft.Direct() if mode == "direct" else nufft.FastApproximation()
         p = nufft.PlanNUFFT(Z, (n,) * 3, m=m, sigma=sigma, ntransforms=C, kernel_evalmode=ev, backend=nufft.ROCBackend(0), spread_method="marching_ring")
         nufft.set_points(p, xs)
-        CZ = torch.complex128 if Z == torch.float64 else torch.complex64
+        CZ = torch.complex128 if T == torch.float64 else torch.complex64
         us = tuple(torch.empty(p.shape, dtype=CZ, device="cuda") for _ in range(C))
         nufft.exec_type1(us if C > 1 else us[0], p, vs if C > 1 else vs[0])
         info = p.info()
