@@ -1059,6 +1059,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     if (np < 0) return fail(NUFFT_ERR_INVALID_ARG, "negative number of points");
     if (np >= ((int64_t)1 << 31) - 1) return fail(NUFFT_ERR_UNSUPPORTED, "number of points exceeds 2^31 - 2");
     if (!coords) return fail(NUFFT_ERR_INVALID_ARG, "null coordinate table");
+    p->halo_pending = false;           // a deferred spread of the previous point set that was never consumed is void
     for (int d = 0; d < p->D; ++d)
         if (np > 0 && !coords[d]) return fail(NUFFT_ERR_INVALID_ARG, "null coordinate vector");
     DeviceGuard guard(p->device);
@@ -1253,6 +1254,7 @@ int nufft_fill_zeros(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_ZERO, stream);
+    p->halo_pending = false;
     NUFFT_HIP(launch_zero_fill(p->d_us, (size_t)p->grid_elems * value_bytes(p) * p->C, stream));
     return NUFFT_OK;
 }
@@ -1386,6 +1388,7 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_FFT, stream);
+    p->halo_pending = false;           // the grids are overwritten: an unconsumed deferred spread is void
     if (p->pruned_fft && p->is_complex) {
         int64_t per = 1;
         for (int d = 1; d < p->D; ++d) per *= p->Nover[d];

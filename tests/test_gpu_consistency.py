@@ -132,3 +132,59 @@ def test_cube_accumulation_variant_of_the_tile_kernel(monkeypatch):
             nufft.exec_type1(u, plans[c], v)
             outs.append(u)
         assert float((outs[0] - outs[1]).norm() / outs[0].norm()) < 1e-13
+
+
+@pytest.mark.parametrize("Z", [np.float64, np.complex64])
+def test_deferred_spread_stage_completes_the_grid_wherever_it_is_consumed(Z, monkeypatch):
+    """nufft_spread_deferred (the spreading stage as exec_type1 enqueues it: on the marching window's halo variant the stencil reach
+    beyond the columns sits in a side buffer until a consumer of the grid adds it).  Every consumer must see the complete grid:
+    nufft_copy_grid, nufft_interpolate, and the FFT stage (stage by stage = exec_type1); an abandoned deferred spread must not leak
+    into a later transform (exec_type2 overwrites the grids; set_points voids it)."""
+    import ctypes as C
+    monkeypatch.setenv("NUFFT_SMARCH_HALO", "2")
+    dims, M, Np = (64, 64, 32), 3, 30000
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, O.FAST_APPROXIMATION, 1, Np, seed=9, spread_method="marching_ring")
+    from nonuniformffts_jl_amd.plan import _check, _ptr_table      # (the package's import name, registered by nufft_pkg)
+    assert plan.info().ring_halo == 1
+    lib, dev = nufft.lib, plan.device
+    tol = 1e-13 if np.dtype(Z) == np.float64 else 2e-6          # (LDS float atomics: the order of the sums differs from launch to launch)
+
+    def same(a, b):
+        return float((a - b).norm() / b.norm()) < tol
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
+    vd = torch.from_numpy(vs[0]).to(dev)
+    nufft.set_points(plan, xd)
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    # the complete grid, from the self-contained stage
+    nufft.spread_from_points(plan, vd)
+    full = nufft.oversampled_grid(plan).clone()
+    # deferred, then read back: the copy completes it
+    _check(lib.nufft_spread_deferred(plan._handle, _ptr_table((vd,)), s))
+    assert same(nufft.oversampled_grid(plan), full)
+    # deferred, then interpolate from the grid: the same values as from the complete grid
+    out_ref = torch.empty(Np, dtype=plan.Z, device=dev)
+    nufft.spread_from_points(plan, vd)
+    nufft.interpolate(plan, out_ref)
+    out = torch.empty_like(out_ref)
+    _check(lib.nufft_spread_deferred(plan._handle, _ptr_table((vd,)), s))
+    nufft.interpolate(plan, out)
+    assert same(out, out_ref)
+    # deferred + FFT + deconvolution, stage by stage = exec_type1
+    u_ref = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    nufft.exec_type1(u_ref, plan, vd)
+    u = torch.empty_like(u_ref)
+    _check(lib.nufft_spread_deferred(plan._handle, _ptr_table((vd,)), s))
+    _check(lib.nufft_fft_forward(plan._handle, s))
+    _check(lib.nufft_deconvolve_truncate(plan._handle, _ptr_table((u,)), s))
+    assert same(u, u_ref)
+    # an abandoned deferred spread does not leak into a type-2 transform, nor survive set_points
+    w = torch.empty(Np, dtype=plan.Z, device=dev)
+    nufft.exec_type2(w, plan, u_ref)
+    _check(lib.nufft_spread_deferred(plan._handle, _ptr_table((vd,)), s))
+    w2 = torch.empty_like(w)
+    nufft.exec_type2(w2, plan, u_ref)
+    assert same(w2, w)
+    _check(lib.nufft_spread_deferred(plan._handle, _ptr_table((vd,)), s))
+    nufft.set_points(plan, xd)
+    nufft.spread_from_points(plan, vd)
+    assert same(nufft.oversampled_grid(plan), full)
