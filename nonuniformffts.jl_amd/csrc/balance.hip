@@ -275,6 +275,7 @@ __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int 
 __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int npy, int pbx, int pby, int clo, int chi, int zq, int segl, int maxlen,
                                                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ first,
                                                          unsigned long long limit, unsigned long long limit_cut, unsigned long long slots_eff, int uniform_always,
+                                                         double rho_eff_max, unsigned long long np,
                                                          uint2* __restrict__ tasktab, uint32_t* __restrict__ choice,
                                                          uint32_t* __restrict__ slots_in_use) {
     __shared__ uint32_t cum_all[256 / kWave][kPatchMaxLayers + 1];
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
         return;
     }
     uint32_t* cum = cum_all[w];
-    unsigned long long wsum = 0;
+    unsigned long long wsum = 0, wsq = 0;                 // wsq: sum of n^2 over the column's layers (the density the points see)
     uint32_t wmax = 0;
     if (c < npx * npy) {
         const int bx0 = (c % npx) * pbx, by0 = (c / npx) * pby;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
                     n += offsets[bin0 + ncx] - offsets[bin0];
                 }
                 run += n;
+                wsq += (unsigned long long)n * n;
                 cum[z + 1] = run;                        // (local to the lane's chunk for now)
             }
         }
@@ -370,11 +372,13 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
         }
         for (int o = kWave / 2; o > 0; o >>= 1) {
             wsum += __shfl_down(wsum, o, kWave);
+            wsq += __shfl_down(wsq, o, kWave);
             wmax = max(wmax, (uint32_t)__shfl_down(wmax, o, kWave));
         }
         if (lane == 0) {
             atomicMax(&choice[0], wmax);
             atomicAdd(reinterpret_cast<unsigned long long*>(choice + 4), wsum);
+            atomicAdd(reinterpret_cast<unsigned long long*>(choice + 8), wsq);
         }
     }
     __syncthreads();
@@ -385,11 +389,17 @@ __global__ __launch_bounds__(256) void patch_split_kernel(Geom g, int npx, int n
             __threadfence();
             const unsigned long long mx = atomicExch(&choice[0], 0u);
             const unsigned long long sum = atomicExch(reinterpret_cast<unsigned long long*>(choice + 4), 0ull);
+            const unsigned long long sumsq = atomicExch(reinterpret_cast<unsigned long long*>(choice + 8), 0ull);
             choice[1] = 0u;
             // the kernel takes about max(heaviest task, all tasks / wave slots) point visits per wave: patches while that
             // stays within `limit` (launch_patch_tasks)
             const unsigned long long lim = choice[3] != 0u ? limit : limit_cut;      // (the estimate is exact for equal-length tasks)
-            const bool patches = (mx <= lim && sum <= lim * slots_eff) || sum == 0ull || (uniform_always && choice[3] != 0u);
+            bool patches = (mx <= lim && sum <= lim * slots_eff) || sum == 0ull || (uniform_always && choice[3] != 0u);
+            // engines whose advantage falls with the density (the interpolation ring): veto by the density the points themselves see
+            if (rho_eff_max > 0.0 && np > 0ull && !uniform_always) {
+                const double rho_eff = (double)sumsq / (double)np / ((double)(pbx * pby) * 64.0);     // bins of 4^3 cells
+                if (rho_eff > rho_eff_max) patches = false;
+            }
             choice[2] = patches ? 1u : 0u;
             if (patches && slots_in_use) slots_in_use[0] = 0u;
         }
@@ -447,7 +457,7 @@ int patch_task_table_entries(const PatchPlan& pp) { return pp.ntasks + 2 * pp.np
 // tasks of equal point count)
 static hipError_t launch_column_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, unsigned long long limit,
                                       unsigned long long limit_cut, unsigned long long slots_eff, bool uniform_always, uint32_t* choice, uint32_t* slots_in_use,
-                                      uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
+                                      uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream, double rho_eff_max = 0.0) {
     const int ncols = ct.ncolx * ct.ncoly, wpb = 256 / kWave;
     const int ntab = column_task_table_entries(ct, g.nb[2]);
     hipLaunchKernelGGL(patch_column_sums_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, ct.ncolx, ct.ncoly, ct.bxw, ct.byw,
@@ -456,7 +466,8 @@ static hipError_t launch_column_tasks(const Geom& g, const ColumnTasks& ct, cons
     hipLaunchKernelGGL(patch_task_counts_kernel, dim3(1), dim3(1024), 0, stream, ncols, ct.ntasks, ntab, ct.nseg, min_seg, g.nb[2] / ct.zq,
                        (unsigned long long)np, limit, slots_eff, uniform_always ? 1 : 0, colsum, first, tasktab, choice, slots_in_use);
     hipLaunchKernelGGL(patch_split_kernel, dim3((unsigned)((ncols + wpb - 1) / wpb)), dim3(256), 0, stream, g, ct.ncolx, ct.ncoly, ct.bxw, ct.byw,
-                       ct.clo, ct.chi, ct.zq, ct.segl, ct.maxlen, offsets, first, limit, limit_cut, slots_eff, uniform_always ? 1 : 0, tasktab, choice, slots_in_use);
+                       ct.clo, ct.chi, ct.zq, ct.segl, ct.maxlen, offsets, first, limit, limit_cut, slots_eff, uniform_always ? 1 : 0, rho_eff_max,
+                       (unsigned long long)np, tasktab, choice, slots_in_use);
     if (ntab <= kPatchSortMax && ncols < 65536) {
         int npad = 2;
         while (npad < ntab) npad <<= 1;
@@ -487,7 +498,7 @@ hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int c
 // short segments duplicates only the (2M - 1)-plane window load, not point work — so the ring keeps a point set while
 // max(heaviest task, all points / workgroups at work) stays within `advantage` x an even share of the whole chip
 // (np / cus): small grids, whose few tasks cannot fill the chip, go to the LDS-tile kernel with its slices.
-hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, int cus, double advantage,
+hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, int cus, double advantage, double rho_eff_max,
                               uint32_t* choice, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream) {
     const unsigned long long slots_eff = (unsigned long long)std::max(1, std::min(cus, ct.ntasks));
     // advantage <= 0: always the ring (a limit that no product with slots_eff can overflow)
@@ -496,7 +507,8 @@ hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32
     // tasks of equal point count: x 0.85 for what the estimate leaves out (per-task window loads, the scheduling tail —
     // folded N(0, 1) points at 0.3 points per cell: the ring takes 1.27x its time for uniform points)
     const unsigned long long limit_cut = always ? limit : (unsigned long long)(0.85 * advantage * (double)np / (double)cus) + 64ull;
-    return launch_column_tasks(g, ct, offsets, np, limit, limit_cut, slots_eff, always, choice, nullptr, colsum, first, tasktab, stream);
+    return launch_column_tasks(g, ct, offsets, np, limit, limit_cut, slots_eff, always, choice, nullptr, colsum, first, tasktab, stream,
+                               always ? 0.0 : rho_eff_max);
 }
 
 // The same for the z-marching spreading ring (smarch_kernels.h): a task is a workgroup that owns a column for a segment of bin

@@ -119,7 +119,7 @@ struct PatchPlan {
 PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, bool allow_f32acc = true, int planar_nc = 0);
 // set_points: cuts the patch columns into tasks of about equal point count and decides on the device which engine serves
 // this point set (balance.hip); choice = uint32[8], zeroed once; colsum[columns], first[columns + 1], tasktab[pp.ntasks]
-hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, int cus, double advantage,
+hipError_t launch_march_tasks(const Geom& g, const ColumnTasks& ct, const uint32_t* offsets, int64_t np, int cus, double advantage, double rho_eff_max,
                               uint32_t* choice, uint32_t* colsum, uint32_t* first, uint2* tasktab, hipStream_t stream);
 // advantage: how much faster than the LDS tiles the patches are on uniform points (<= 0: always the patches)
 hipError_t launch_patch_tasks(const Geom& g, const PatchPlan& pp, int clo, int chi, const uint32_t* offsets, int64_t np,

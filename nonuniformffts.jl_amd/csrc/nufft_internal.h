@@ -114,7 +114,7 @@ struct nufft_plan {
     bool debug_tasks = false;          // NUFFT_DEBUG_TASKS latched at plan creation: host check of the task tables after set_points
     nufft::ColumnTasks march_ct{};     // ... its columns and evenly cut tasks
     int num_cus = 256;                 // compute units of the device (one ring workgroup per CU)
-    uint32_t* d_march_choice = nullptr;   // [8]: scratch of the task kernels (balance.hip); [2] = 1: the ring serves this point set
+    uint32_t* d_march_choice = nullptr;   // [16]: scratch of the task kernels (balance.hip); [2] = 1: the ring serves this point set
     uint32_t* d_march_cols = nullptr;     // [columns] points per column, then [columns + 1] first task of each column
     void* d_march_tasks = nullptr;        // uint2[ntasks + columns]: {column, end layer << 16 | first layer}
     bool interp_fixed = false;         // tile.ip is the compile-time tile of the kernel instantiation
@@ -126,11 +126,11 @@ struct nufft_plan {
         bool eligible = false;
         int npx = 0, npy = 0, nseg = 0, segl = 0, ntasks = 0, lds_bytes = 0, pby = 0, occ = 2, f32acc = 0, planar = 0;
     } patch;
-    uint32_t* d_patch_choice = nullptr;   // [8]: scratch of patch_split_kernel; [2] = 1: this point set is spread by the patches
+    uint32_t* d_patch_choice = nullptr;   // [16]: scratch of patch_split_kernel; [2] = 1: this point set is spread by the patches
     uint32_t* d_patch_cols = nullptr;     // [columns] points per patch column, then [columns + 1] first task of each column
     void* d_patch_tasks = nullptr;        // uint2[ntasks]: {column, end layer << 16 | first layer}, rebuilt by every set_points
     nufft::SMarchPlan smarch{};           // decomposition of the z-marching spreading ring (smarch_kernels.h); eligible = false: none
-    uint32_t* d_smarch_choice = nullptr;  // [8]: scratch of the task kernels; [2] = 1: this point set is spread by the ring
+    uint32_t* d_smarch_choice = nullptr;  // [16]: scratch of the task kernels; [2] = 1: this point set is spread by the ring
     uint32_t* d_smarch_cols = nullptr;    // [columns] points per column, then [columns + 1] first task of each column
     void* d_smarch_tasks = nullptr;       // uint2[table entries]: {column, end layer << 16 | first layer}, rebuilt by every set_points
     void* d_smarch_halo = nullptr;        // halo variant: side buffer of the stencil reach, C x smarch.halo_reals reals

@@ -585,8 +585,8 @@ static int build_device(nufft_plan* p) {
         const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
         if (ncols >= 65536 || p->tile.nb[2] > 2048) p->interp_march = false;      // (beyond the task kernels' table formats)
         else {
-            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_march_choice), 8 * sizeof(uint32_t)))) return rc;
-            NUFFT_HIP(hipMemset(p->d_march_choice, 0, 8 * sizeof(uint32_t)));
+            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_march_choice), 16 * sizeof(uint32_t)))) return rc;
+            NUFFT_HIP(hipMemset(p->d_march_choice, 0, 16 * sizeof(uint32_t)));
             if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_march_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
             if ((rc = dev_alloc(p, &p->d_march_tasks, (size_t)column_task_table_entries(p->march_ct, p->tile.nb[2]) * 8))) return rc;
             hipDeviceProp_t prop;
@@ -597,8 +597,8 @@ static int build_device(nufft_plan* p) {
 
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false, p->patch.planar));
-        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 8 * sizeof(uint32_t)))) return rc;
-        NUFFT_HIP(hipMemset(p->d_patch_choice, 0, 8 * sizeof(uint32_t)));
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 16 * sizeof(uint32_t)))) return rc;
+        NUFFT_HIP(hipMemset(p->d_patch_choice, 0, 16 * sizeof(uint32_t)));
         // task table of the patch engine, rebuilt by every set_points (balance.hip): [columns] points, [columns + 1] first task,
         // [ntasks] {column, layers}
         const size_t ncols = (size_t)p->patch.npx * p->patch.npy;
@@ -621,8 +621,8 @@ static int build_device(nufft_plan* p) {
         if (!p->smarch.eligible) return fail(NUFFT_ERR_UNSUPPORTED, "marching-ring spreading: no decomposition for this device");
         NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M, p->smarch.halo));
         const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
-        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_choice), 8 * sizeof(uint32_t)))) return rc;
-        NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 8 * sizeof(uint32_t)));
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_choice), 16 * sizeof(uint32_t)))) return rc;
+        NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 16 * sizeof(uint32_t)));
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, &p->d_smarch_tasks, (size_t)column_task_table_entries(p->smarch.ct, p->tile.nb[2]) * 8))) return rc;
         if (p->smarch.halo == 2 && (rc = dev_alloc(p, &p->d_smarch_halo, (size_t)p->smarch.halo_reals * real_bytes(p) * p->C))) return rc;
@@ -1170,8 +1170,15 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         const double rho = (double)np / (double)std::max<int64_t>(p->grid_elems, 1), mr = (double)p->M / 4.0;
         const double fitted = (rho + 0.038 * std::pow(mr, 1.85)) / (1.09 * rho + 0.0086 * std::pow(mr, 1.2));
         const double advantage = p->interp_march_mode == 2 ? 0.0 : fitted;      // (<= 0: always the ring)
+        // Point sets far from uniform (tasks of equal point count): the same trade at the density the points themselves see,
+        // rho_eff = sum n^2 / (sum n x cells) over the column layers (balance.hip).  Uniform sets break even at
+        // rho* = (c_t - c_r) / 0.09 (0.33 at m = 4); cut tasks amortise the window loads better — measured at m = 4, Np = 1e7 ... 1.7e7:
+        // rho_eff = 0.42 (folded N(0, 1) on 512^3, Gaussian cluster of 1 rad) ring 1.87 / 1.88 ms against 2.10 / 2.09 tiles;
+        // 1.66 (folded N(0, 1), 1.68e7 points on 384^3) 3.42 against 2.58; 3.3 (cluster of 0.5 rad) 2.01 against 1.43 — so the ring
+        // keeps such sets up to 2.5 rho*.
+        const double rho_star = (0.038 * std::pow(mr, 1.85) - 0.0086 * std::pow(mr, 1.2)) / 0.09;
         const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
-        NUFFT_HIP(launch_march_tasks(s.g, p->march_ct, p->d_offsets, np, p->num_cus, advantage, p->d_march_choice, p->d_march_cols,
+        NUFFT_HIP(launch_march_tasks(s.g, p->march_ct, p->d_offsets, np, p->num_cus, advantage, 2.5 * rho_star, p->d_march_choice, p->d_march_cols,
                                      p->d_march_cols + ncols, static_cast<uint2*>(p->d_march_tasks), stream));
     }
     if (p->debug_tasks) {

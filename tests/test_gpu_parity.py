@@ -540,6 +540,15 @@ def test_spreading_ring_automatic_choice_and_fallback(Z, C):
         ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs) if C > 1 else _oracle_inputs(oplan, vs)[0])
         for c in range(C):
             assert _rel(us[c].cpu().numpy(), ref[c] if C > 1 else ref) < _rtol(Z), (name, c)
+        # type 2 on the same point sets: the interpolation ring's own device-side decision — the corner set is 8000 times denser
+        # than the grid average where its points are (density veto, balance.hip) and goes to the LDS tiles
+        outs = tuple(torch.empty(Np, dtype=plan.Z, device=dev) for _ in range(C))
+        nufft.exec_type2(outs if C > 1 else outs[0], plan, us if C > 1 else us[0])
+        if name == "corner":
+            assert plan.interp_engine_used() == "lds_tiles"
+        ref2 = O.exec_type2(oplan, [u.cpu().numpy() for u in us] if C > 1 else _oracle_inputs(oplan, [us[0].cpu().numpy()])[0])
+        for c in range(C):
+            assert _rel(outs[c].cpu().numpy(), ref2[c] if C > 1 else ref2) < _rtol(Z), (name, c, "type 2")
 
 
 @pytest.mark.parametrize("Z,M", [(np.float64, 4), (np.complex64, 8), (np.float32, 6), (np.complex128, 5), (np.float64, 8)])
