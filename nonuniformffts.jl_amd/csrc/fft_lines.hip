@@ -287,6 +287,36 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     }
 }
 
+// Contiguous line <-> LDS with 16-byte accesses per lane: Float32 lines move two complex elements per lane and step (8-byte accesses
+// reach about half the rate: C3's dimension-1 pass, 12.9 GB, took 4.9 ms).  n elements, n even, the line 16-byte aligned.
+template <typename C>
+__device__ __forceinline__ void load_line_wide(C* line, const C* src, int n, int lane) {
+    if constexpr (sizeof(C) == 8) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int k = lane; k < n / 2; k += kWave) {
+            const float4 v = s4[k];
+            C a, b;
+            a.x = v.x; a.y = v.y; b.x = v.z; b.y = v.w;
+            line[lpad(2 * k)] = a;
+            line[lpad(2 * k + 1)] = b;
+        }
+    } else {
+        for (int k = lane; k < n; k += kWave) line[lpad(k)] = src[k];
+    }
+}
+template <typename C>
+__device__ __forceinline__ void store_line_wide(C* dst, const C* line, int n, int lane) {
+    if constexpr (sizeof(C) == 8) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int k = lane; k < n / 2; k += kWave) {
+            const C a = line[lpad(2 * k)], b = line[lpad(2 * k + 1)];
+            d4[k] = make_float4(a.x, a.y, b.x, b.y);
+        }
+    } else {
+        for (int k = lane; k < n; k += kWave) dst[k] = line[lpad(k)];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Dimension 1 of real plans: r2c / c2r of contiguous lines with a *compact* spectrum (only the K1 = N1/2 + 1
 // kept modes are stored: row length K1 instead of Ñ1/2 + 1).  A real line of N = 2M samples is transformed as
@@ -377,7 +407,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
     C* line = lines + wave * LINE;
     if (FWD) {
         const C* zin = reinterpret_cast<const C*>(static_cast<const T*>(a.in) + line_id * N);
-        for (int n = lane; n < M; n += kWave) line[lpad(n)] = zin[n];
+        load_line_wide(line, zin, M, lane);
         wave_lds_fence();
         if constexpr (HALO) {
             if (*a.hflag != 0u) add_halo_to_line<T, C, 1>(a.halo, a.hl, a.ny, line, line_id, lane, N);
@@ -426,7 +456,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         wave_lds_fence();
         fft_line<T, M, 1, 2>(line, tw, lane);
         C* zout = reinterpret_cast<C*>(static_cast<T*>(a.out) + line_id * N);
-        for (int n = lane; n < M; n += kWave) zout[n] = line[lpad(n)];
+        store_line_wide(zout, line, M, lane);
     }
 }
 
@@ -464,7 +494,7 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
     C* line = lines + wave * LINE;
     if (FWD) {
         const C* zin = static_cast<const C*>(a.in) + line_id * N;
-        for (int n = lane; n < N; n += kWave) line[lpad(n)] = zin[n];
+        load_line_wide(line, zin, N, lane);
         wave_lds_fence();
         if constexpr (HALO) {
             if (*a.hflag != 0u) add_halo_to_line<T, C, 2>(a.halo, a.hl, a.ny, line, line_id, lane, N);
@@ -481,7 +511,7 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
         wave_lds_fence();
         fft_line<T, N, 1>(line, tw, lane);
         C* zout = static_cast<C*>(a.out) + line_id * N;
-        for (int n = lane; n < N; n += kWave) zout[n] = line[lpad(n)];
+        store_line_wide(zout, line, N, lane);
     }
 }
 
@@ -614,10 +644,10 @@ __global__ __launch_bounds__(1024) void halo_add_lines_kernel(T* grid, const T* 
     const int64_t line_id = (int64_t)blockIdx.x * nw + wave;
     if (line_id >= nlines) return;
     C* g = reinterpret_cast<C*>(grid + (int64_t)blockIdx.y * grid_comp) + line_id * ne;
-    for (int n = lane; n < ne; n += kWave) line[lpad(n)] = g[n];
+    load_line_wide(line, g, ne, lane);
     wave_lds_fence();
     add_halo_to_line<T, C, NC>(halo + (int64_t)blockIdx.y * halo_comp, h, ny, line, line_id, lane, NC == 1 ? 2 * ne : ne);
-    for (int n = lane; n < ne; n += kWave) g[n] = line[lpad(n)];
+    store_line_wide(g, line, ne, lane);
 }
 
 template <typename T>
@@ -669,9 +699,11 @@ template <typename T, int N, bool FWD, bool MULT>
 static hipError_t launch_n_m(const FftLineArgs& a, hipStream_t stream) {
     using C = typename Cplx2<T>::type;
     constexpr int LINE = N + (N >> 4) + 1;
-    // TA lines per workgroup: as many as fit in the LDS limit (two workgroups per CU), at most 16
+    // TA lines per workgroup: as many as fit in the LDS limit, at most 16.  Float64: two workgroups per CU (70 KB at N = 512) beat one
+    // with 16 lines (measured).  Float32: 16 lines make the strided accesses 128-byte segments instead of 64-byte ones, which is worth
+    // one workgroup per CU (C3, N = 1024: deconvolution + padding pass 4.47 -> 3.47 ms, last forward pass 1.66 -> 1.40 ms)
 #ifndef NUFFT_FFT_LDS_LIMIT
-#define NUFFT_FFT_LDS_LIMIT (80 * 1024)      // two workgroups per CU (70 KB at N = 512 Float64) beat one with 16 lines: measured
+#define NUFFT_FFT_LDS_LIMIT (sizeof(C) == 8 ? 160 * 1024 - 1024 : 80 * 1024)
 #endif
     constexpr int TA = (sizeof(C) * (16 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 16 : ((sizeof(C) * (8 * LINE + N) <= NUFFT_FFT_LDS_LIMIT) ? 8 : 4);
     static_assert(sizeof(C) * (size_t)(TA * LINE + N) <= kFftLdsLimit, "line buffers exceed the 160 KiB of LDS");
