@@ -93,10 +93,10 @@ void interp_fixed_dims(int dtype, int is_complex, int D, int M, int* n);
 void spread_fixed_dims(int dtype, int is_complex, int D, int M, int* n);
 bool spread_cubes_available(int dtype, int is_complex, int D, int M);
 // z-marching interpolation (march_kernels.h): available for this plan?  (3-D, 4-cell bins, default window evaluation)
-bool interp_march_available(int dtype, int is_complex, int D, int M, const Geom& g, bool other);
-hipError_t prepare_interp_march(int dtype, int is_complex, int M);
+bool interp_march_available(int dtype, int is_complex, int D, int M, bool poly, const Geom& g, bool other);
+hipError_t prepare_interp_march(int dtype, int is_complex, int M, bool poly);
 // columns (the kernel's compile-time column) and evenly cut tasks of the ring for this grid
-ColumnTasks march_column_tasks(int dtype, int is_complex, int M, const Geom& g);
+ColumnTasks march_column_tasks(int dtype, int is_complex, int M, bool poly, const Geom& g);
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
 hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);
 // Sets the dynamic-LDS attribute of every instantiation that may be launched for this configuration.

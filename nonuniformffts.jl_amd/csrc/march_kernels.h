@@ -44,7 +44,7 @@ struct MarchGeom {
 
 constexpr int kMarchMaxRows = 16;   // rows of bins of a column (n2 <= 64)
 
-template <typename T, bool CPLX, int M>
+template <typename T, bool CPLX, int M, bool POLY = true>
 struct MarchCfg {
     static constexpr int NC = CPLX ? 2 : 1;
     static constexpr int L = 2 * M, HALO = L - 1;
@@ -54,14 +54,26 @@ struct MarchCfg {
     static constexpr int KL = NUFFT_MARCH_KL;           // bin layers per phase (one barrier pair and one plane fetch per phase)
     static constexpr int BZ = 4 * KL;                   // planes per phase
     static constexpr int RZ = HALO + BZ;                // ring depth
-    // 16 waves per CU leave 128 registers per lane.  Only Float32 real data at M <= 5 fit them; everything else spilled
-    // its prefetched planes to scratch (measured at C2, Float64: 5.3 GB of memory-side fetches per launch instead of 1.9,
-    // 1.83 ms instead of 1.67), so those run 8 waves with 256 registers each.
-#ifndef NUFFT_MARCH_WIDE_M
-#define NUFFT_MARCH_WIDE_M 6
+    // Workgroup size: 16 waves per CU leave 128 registers per lane, 8 waves 256.  With one instantiation per window evaluation (the other
+    // mode's code and registers gone) almost every kernel fits 128 registers and gains from the second wave per SIMD — interpolation
+    // stage, 256^3 -> 512^3, Np = 1e7, 8 -> 16 waves (profiles/round4_c_interp_threads.log): Float64 m = 4 1.52 -> 1.27 ms (Direct 1.85 ->
+    // 1.56), m = 5 3.80 -> 3.00; Float32 m = 8 4.84 -> 3.67; ComplexF64 m = 4 4.19 -> 2.76; ComplexF32 m = 4 1.70 -> 1.25.  The
+    // exceptions spill (polynomial window, wide stencils: the 2M window values and M + 3 coefficients per slot stay in registers):
+    // Float64 m = 6 (34 registers spilled) 4.01 -> 4.69, m = 8 (68) 5.83 -> 15.1; ComplexF64 m = 8 20.4 -> 30.2; ComplexF32 m = 8 (C3's
+    // kernel, 18 spilled) 6.07 -> 6.06 — those keep 8 waves with 256 registers each.
+    static constexpr int threads_rule() {
+#if defined(NUFFT_MARCH_FORCE_1024)
+        return 1024;
+#elif defined(NUFFT_MARCH_FORCE_512)
+        return 512;
+#else
+        if (!POLY) return 1024;                                 // Direct(): no spills at 128 registers in any instantiation
+        if (sizeof(T) == 8) return M <= (CPLX ? 6 : 5) ? 1024 : 512;
+        if (CPLX) return M <= 7 ? 1024 : 512;
+        return 1024;                                            // Float32
 #endif
-    static constexpr int THREADS = (sizeof(T) == 8 || CPLX || M >= NUFFT_MARCH_WIDE_M) ? 512 : 1024;
-    static constexpr int NW = THREADS / kWave;
+    }
+    static constexpr int THREADS_PREFERRED = threads_rule();
     // Complex data with at most 16 lanes per stencil row: ONE lane per j1 gathers both components (64- / 128-bit LDS reads,
     // v_pk_fma_f32 for ComplexF32) — half the wave instructions per point of the (j1, component) lane mapping, and the
     // window values can stay in registers as for real data.
@@ -91,18 +103,18 @@ struct MarchCfg {
     // [runs of the segment: layer x row][passes of the longest run per layer][pass counter, flag]
     static constexpr int table_bytes(int segl) { return round_up(kMarchMaxRows * segl * 8 + segl * 4 + 64, 16); }
     static constexpr int kSegMax = 64;
-    static constexpr int fixed_bytes() { return table_bytes(kSegMax) + NW * strip_bytes() + 64; }
+    static constexpr int fixed_bytes_for(int threads) { return table_bytes(kSegMax) + threads / kWave * strip_bytes() + 64; }
     // column interior (n1, n2): multiples of the bin edge, minimal halo amplification within the LDS budget
     struct Dims { int n1, n2; };
-    static constexpr Dims search() {
+    static constexpr Dims search(int threads) {
         Dims best{0, 0};
         double best_cost = 1e300;
         for (int n2 = 4; n2 <= 4 * kMarchMaxRows; n2 += 4)
             for (int n1 = 4; n1 <= 64; n1 += 4) {
-                const long bytes = (long)pad_plane(NC * (n1 + HALO) * (n2 + HALO)) * RZ * (long)sizeof(T) + fixed_bytes();
+                const long bytes = (long)pad_plane(NC * (n1 + HALO) * (n2 + HALO)) * RZ * (long)sizeof(T) + fixed_bytes_for(threads);
                 if (bytes > 163840 - 256) continue;
                 // registers of the per-thread plane prefetch (the planes of the next layer are in flight during the gather)
-                if (((long)BZ * NC * (n1 + HALO) * (n2 + HALO) + THREADS - 1) / THREADS * (long)(sizeof(T) / 4) > 32) continue;
+                if (((long)BZ * NC * (n1 + HALO) * (n2 + HALO) + threads - 1) / threads * (long)(sizeof(T) / 4) > 32) continue;
                 double cost = (double)(n1 + HALO) / n1 * (double)(n2 + HALO) / n2;
                 // columns whose edge divides the common power-of-two grid sizes leave no partial column
                 if (512 % n1) cost *= 1.03;
@@ -112,7 +124,11 @@ struct MarchCfg {
             }
         return best;
     }
-    static constexpr Dims DIMS = search();
+    // (16 waves carry twice the strips: where no column fits beside them — ComplexF64, M = 9, Direct — 8 waves it is)
+    static constexpr int THREADS = (THREADS_PREFERRED == 1024 && search(1024).n1 == 0) ? 512 : THREADS_PREFERRED;
+    static constexpr int NW = THREADS / kWave;
+    static constexpr int fixed_bytes() { return fixed_bytes_for(THREADS); }
+    static constexpr Dims DIMS = search(THREADS);
     static constexpr int N1 = DIMS.n1, N2 = DIMS.n2;
     static constexpr int P1 = N1 + HALO, P2 = N2 + HALO;
     static constexpr int RS = NC * P1;                  // row stride in reals
@@ -126,9 +142,9 @@ struct MarchCfg {
 
 // A task is a column and a segment of its bin layers (at most kSegMax) from set_points' table: segments of about equal
 // point count, or of equal length for uniform point sets (balance.hip).
-template <typename T, bool CPLX, int M>
-__global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_kernel(TileArgs<T> a, MarchGeom mg) {
-    using C = MarchCfg<T, CPLX, M>;
+template <typename T, bool CPLX, int M, bool POLY>
+__global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_march_kernel(TileArgs<T> a, MarchGeom mg) {
+    using C = MarchCfg<T, CPLX, M, POLY>;
     constexpr int kMarchThreads = C::THREADS;
     using GP = typename C::GP;
     constexpr int NC = C::NC, L = C::L, RZ = C::RZ, BZ = C::BZ, RS = C::RS, PS = C::PS, P1 = C::P1, P2 = C::P2;
@@ -196,7 +212,8 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
     T* strip = strip_wave + grp * (3 * L);
     using WEv = WindowEval<T, NCL, 3, M, GP::G, false>;
     WEv we;
-    we.init(a, q);
+    const EvalArgs<T, POLY ? NUFFT_EVAL_FAST_APPROXIMATION : NUFFT_EVAL_DIRECT> am(a);       // (the instantiation fixes the evaluation mode)
+    we.init(am, q);
     if constexpr (ZP == 2) {
         // the second row holds the dimension-3 values with neighbouring pairs exchanged: a row broadcast from lane 2 jj
         // then hands row 0 value 2 jj and row 1 value 2 jj + 1 — each row the weight of its own plane
@@ -293,11 +310,11 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M>::THREADS)) void interp_march_
             T wv[WEv::NSLOT];
             T w1;
             if constexpr (C::REGW) {
-                we.eval_regs(a, X, wv);
+                we.eval_regs(am, X, wv);
                 w1 = wv[0];
             } else {
                 wave_lds_fence();
-                we.eval_to_strip(a, X, strip, q);
+                we.eval_to_strip(am, X, strip, q);
                 wave_lds_fence();
                 w1 = strip[j1];
             }

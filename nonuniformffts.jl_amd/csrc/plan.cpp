@@ -578,10 +578,10 @@ static int build_device(nufft_plan* p) {
     p->debug_tasks = env_int("NUFFT_DEBUG_TASKS", 0) != 0;
     p->halo_fuse = env_int("NUFFT_SMARCH_HALO_FUSE", 1) != 0;
     p->interp_march = p->interp_march_mode != 0 &&
-                      interp_march_available(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
+                      interp_march_available(p->dtype, p->is_complex, D, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
     if (p->interp_march) {
-        NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M));
-        p->march_ct = march_column_tasks(p->dtype, p->is_complex, p->M, make_geom(p));
+        NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
+        p->march_ct = march_column_tasks(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p));
         const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
         if (ncols >= 65536 || p->tile.nb[2] > 2048) p->interp_march = false;      // (beyond the task kernels' table formats)
         else {

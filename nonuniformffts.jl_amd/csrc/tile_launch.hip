@@ -14,33 +14,33 @@
 
 namespace nufft {
 
-const void* march_kernel_f32r(int M, int* lds_bytes, int* n);
-const void* march_kernel_f32c(int M, int* lds_bytes, int* n);
-const void* march_kernel_f64r(int M, int* lds_bytes, int* n);
-const void* march_kernel_f64c(int M, int* lds_bytes, int* n);
-static const void* march_kernel(int dtype, int is_complex, int M, int* lds_bytes, int* n) {
-    if (dtype == NUFFT_F32) return is_complex ? march_kernel_f32c(M, lds_bytes, n) : march_kernel_f32r(M, lds_bytes, n);
-    return is_complex ? march_kernel_f64c(M, lds_bytes, n) : march_kernel_f64r(M, lds_bytes, n);
+const void* march_kernel_f32r(int M, bool poly, int* lds_bytes, int* n);
+const void* march_kernel_f32c(int M, bool poly, int* lds_bytes, int* n);
+const void* march_kernel_f64r(int M, bool poly, int* lds_bytes, int* n);
+const void* march_kernel_f64c(int M, bool poly, int* lds_bytes, int* n);
+static const void* march_kernel(int dtype, int is_complex, int M, bool poly, int* lds_bytes, int* n) {
+    if (dtype == NUFFT_F32) return is_complex ? march_kernel_f32c(M, poly, lds_bytes, n) : march_kernel_f32r(M, poly, lds_bytes, n);
+    return is_complex ? march_kernel_f64c(M, poly, lds_bytes, n) : march_kernel_f64r(M, poly, lds_bytes, n);
 }
-bool interp_march_available(int dtype, int is_complex, int D, int M, const Geom& g, bool other) {
+bool interp_march_available(int dtype, int is_complex, int D, int M, bool poly, const Geom& g, bool other) {
     int lds = 0, n[4];
-    if (D != 3 || other || !march_kernel(dtype, is_complex, M, &lds, n)) return false;
+    if (D != 3 || other || !march_kernel(dtype, is_complex, M, poly, &lds, n)) return false;
     for (int d = 0; d < 3; ++d)
         if (g.blog[d] != 2 || g.Nover[d] % 4 != 0) return false;
     // columns shorter than the axis (a point's stencil then never reaches a column from both sides)
     return n[0] + 2 * M - 1 <= g.Nover[0] && n[1] + 2 * M - 1 <= g.Nover[1] && 4 + 2 * M - 1 <= g.Nover[2];
 }
-hipError_t prepare_interp_march(int dtype, int is_complex, int M) {
+hipError_t prepare_interp_march(int dtype, int is_complex, int M, bool poly) {
     int lds = 0, n[4];
-    const void* fn = march_kernel(dtype, is_complex, M, &lds, n);
+    const void* fn = march_kernel(dtype, is_complex, M, poly, &lds, n);
     if (!fn) return hipErrorInvalidValue;
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
-ColumnTasks march_column_tasks(int dtype, int is_complex, int M, const Geom& g) {
+ColumnTasks march_column_tasks(int dtype, int is_complex, int M, bool poly, const Geom& g) {
     int lds = 0, n[4];
     ColumnTasks ct{};
-    if (!march_kernel(dtype, is_complex, M, &lds, n)) return ct;
+    if (!march_kernel(dtype, is_complex, M, poly, &lds, n)) return ct;
     ct.ncolx = (g.Nover[0] + n[0] - 1) / n[0];
     ct.ncoly = (g.Nover[1] + n[1] - 1) / n[1];
     ct.bxw = n[0] / 4;
@@ -356,7 +356,7 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         if (e != hipSuccess) return e;
         if (march) {
             int lds = 0, n[4];
-            const void* mfn = march_kernel(a.dtype, a.is_complex, a.M, &lds, n);
+            const void* mfn = march_kernel(a.dtype, a.is_complex, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
             MarchGeom mg{};
             mg.ntx = a.march_ct.ncolx;
             mg.nty = a.march_ct.ncoly;
