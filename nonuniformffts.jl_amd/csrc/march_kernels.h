@@ -59,8 +59,9 @@ struct MarchCfg {
     // stage, 256^3 -> 512^3, Np = 1e7, 8 -> 16 waves (profiles/round4_c_interp_threads.log): Float64 m = 4 1.52 -> 1.27 ms (Direct 1.85 ->
     // 1.56), m = 5 3.80 -> 3.00; Float32 m = 8 4.84 -> 3.67; ComplexF64 m = 4 4.19 -> 2.76; ComplexF32 m = 4 1.70 -> 1.25.  The
     // exceptions spill (polynomial window, wide stencils: the 2M window values and M + 3 coefficients per slot stay in registers):
-    // Float64 m = 6 (34 registers spilled) 4.01 -> 4.69, m = 8 (68) 5.83 -> 15.1; ComplexF64 m = 8 20.4 -> 30.2; ComplexF32 m = 8 (C3's
-    // kernel, 18 spilled) 6.07 -> 6.06 — those keep 8 waves with 256 registers each.
+    // Float64 m = 6 (34 registers spilled) 4.01 -> 4.69, m = 8 (68) 5.83 -> 15.1; ComplexF64 m = 8 20.4 -> 30.2 — those keep 8 waves with
+    // 256 registers each.  ComplexF32 m = 8 (C3's kernel) spilled 18 registers with its row groups of 8 (6.07 -> 6.06 ms) and none with
+    // groups of 4: C3 interpolation 52.3 -> 45.0 ms.
     static constexpr int threads_rule() {
 #if defined(NUFFT_MARCH_FORCE_1024)
         return 1024;
@@ -69,8 +70,7 @@ struct MarchCfg {
 #else
         if (!POLY) return 1024;                                 // Direct(): no spills at 128 registers in any instantiation
         if (sizeof(T) == 8) return M <= (CPLX ? 6 : 5) ? 1024 : 512;
-        if (CPLX) return M <= 7 ? 1024 : 512;
-        return 1024;                                            // Float32
+        return 1024;                                            // Float32, ComplexF32 (m = 8: with row groups of 4, below)
 #endif
     }
     static constexpr int THREADS_PREFERRED = threads_rule();
@@ -334,7 +334,8 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_
 #pragma unroll
                 for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
                 // rows per group of the hand-scheduled form (0: compiler-scheduled reads): what compiles without spills
-                constexpr int R = L <= 8 ? ((CPLX || C::THREADS != 512 || L % 4 != 0) ? 2 : 4) : (L % 8 == 0 ? 8 : (L % 4 == 0 ? 4 : 0));
+                // (m = 8 at 16 waves: 8 rows in flight twice over spill 18 registers, groups of 4 fit — C3: 49.8 against 45.0 ms; groups of 2: 47.4)
+                constexpr int R = L <= 8 ? ((CPLX || C::THREADS != 512 || L % 4 != 0) ? 2 : 4) : (L % 8 == 0 ? (C::THREADS == 512 ? 8 : 4) : (L % 4 == 0 ? 4 : 0));
                 static_assert(R == 0 || L % R == 0, "row groups must tile the stencil");
                 if constexpr (R > 0) {
                 // hand-scheduled LDS reads (as in interp_tile_kernel): groups of R rows with immediate offsets from the
