@@ -334,6 +334,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_
 #pragma unroll
                 for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
                 // rows per group of the hand-scheduled form (0: compiler-scheduled reads): what compiles without spills
+                // (m = 4 at 16 waves: groups of 4 spill 8 registers for Float64, 1.31 against 1.26 ms; Float32 gains 3 %: left at 2)
                 // (m = 8 at 16 waves: 8 rows in flight twice over spill 18 registers, groups of 4 fit — C3: 49.8 against 45.0 ms; groups of 2: 47.4)
                 constexpr int R = L <= 8 ? ((CPLX || C::THREADS != 512 || L % 4 != 0) ? 2 : 4) : (L % 8 == 0 ? (C::THREADS == 512 ? 8 : 4) : (L % 4 == 0 ? 4 : 0));
                 static_assert(R == 0 || L % R == 0, "row groups must tile the stencil");
