@@ -520,11 +520,13 @@ def test_spreading_ring_halo_variant_every_instantiation(Z, C, M, monkeypatch):
 
 
 @pytest.mark.parametrize("Z,C", [(np.float64, 1), (np.float64, 3), (np.float32, 2), (np.complex128, 1)])
-def test_spreading_ring_automatic_choice_and_fallback(Z, C):
+def test_spreading_ring_automatic_choice_and_fallback(Z, C, monkeypatch):
     """Automatic engine choice on a grid with enough columns for the chip (256 x 256 x 64 oversampled): real plans at M = 4
     and ComplexF64 plans take the ring for a uniform point set and hand a point set concentrated in one corner to the LDS
     tiles (device-side decision, read back); both against the oracle."""
     dims, Np = (128, 128, 32), 60000
+    for var in ("NUFFT_INTERP_MARCH", "NUFFT_SPREAD_METHOD", "NUFFT_PREFER_RING", "NUFFT_PREFER_PATCHES", "NUFFT_SMARCH_ADVANTAGE"):
+        monkeypatch.delenv(var, raising=False)      # the test is about the automatic choices
     nufft, plan, oplan, xs, vs = _make_case(Z, dims, 4, 2.0, O.FAST_APPROXIMATION, C, Np, seed=77)
     dev = plan.device
     is_ring = plan.info().spread_method == 3
