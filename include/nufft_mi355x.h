@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define NUFFT_MI355X_VERSION 101 /* 0.1.1: nufft_info grew (patch_dims .. ring_segments) since 100 — a caller built against an older
+#define NUFFT_MI355X_VERSION 102 /* 0.1.2: nufft_spread_deferred added, nufft_info.reserved_info became ring_halo (same layout) since 101;
+                                    0.1.1: nufft_info grew (patch_dims .. ring_segments) since 100 — a caller built against an older
                                     header must compare nufft_sizeof_info() / nufft_version() with its own before nufft_plan_info() */
 
 /* ---- return codes ------------------------------------------------------------------- */

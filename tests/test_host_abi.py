@@ -28,7 +28,7 @@ def test_library_exports_every_symbol_in_the_header(nufft):
     raw = C.CDLL(nufft.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert nufft.lib.nufft_version() == 101
+    assert nufft.lib.nufft_version() == 102
     assert b"success" in nufft.lib.nufft_strerror(0)
 
 
