@@ -182,6 +182,12 @@ def test_random_configuration_large_3d(seed, monkeypatch):
     ref = O.exec_type1(oplan, vo if C > 1 else vo[0])
     ref = ref if C > 1 else [ref]
     tol = 1e-7 if T == np.float64 else 1e-5             # the reference's bounds (test/pseudo_gpu.jl:159-171); Float32 measured <= 3.2e-6 over all seeds
+    # Float64 at the ill-conditioned corner of the draw (M = 10 at sigma = 1.25: the deconvolution spans prod_d max / min |phi_hat_d|
+    # = 6.8e11, so two summation orders of the same sums differ by 1e-7 — measured: the LDS tiles against themselves 1.1e-7, every
+    # engine 3-4e-7 against the oracle, soak seed 375): the bound follows the conditioning there, 1e-7 everywhere else (cond <= 5e10)
+    if T == np.float64:
+        cond = float(np.prod([np.abs(ph).max() / np.abs(ph).min() for ph in oplan.phihat]))
+        tol = max(tol, 2e-18 * cond)
     for c in range(C):
         err = np.linalg.norm(us[c].cpu().numpy().astype(np.complex128) - ref[c]) / np.linalg.norm(ref[c])
         _log_error("large", seed, T, np.float64 if wide else T, err, (dims, M, sigma, mode, str(Zt), C, dist, engine, "type 1"))
