@@ -501,13 +501,32 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
         }
         fft_line<T, N, -1>(line, tw, lane);
         C* xout = static_cast<C*>(a.out) + line_id * a.k1;
-        for (int k = lane; k < a.k1; k += kWave) xout[k] = line[lpad(a.map[k])];
+        if (sizeof(C) == 8 && (a.k1 & 1) == 0) {        // Float32: two kept modes (16 bytes) per lane and step
+            float4* x4 = reinterpret_cast<float4*>(xout);
+            for (int k = lane; k < a.k1 / 2; k += kWave) {
+                const C u = line[lpad(a.map[2 * k])], v = line[lpad(a.map[2 * k + 1])];
+                x4[k] = make_float4((float)u.x, (float)u.y, (float)v.x, (float)v.y);
+            }
+        } else {
+            for (int k = lane; k < a.k1; k += kWave) xout[k] = line[lpad(a.map[k])];
+        }
     } else {
         C z; z.x = T(0); z.y = T(0);
         for (int n = lane; n < N; n += kWave) line[lpad(n)] = z;
         wave_lds_fence();
         const C* xin = static_cast<const C*>(a.in) + line_id * a.k1;
-        for (int k = lane; k < a.k1; k += kWave) line[lpad(a.map[k])] = xin[k];
+        if (sizeof(C) == 8 && (a.k1 & 1) == 0) {
+            const float4* x4 = reinterpret_cast<const float4*>(xin);
+            for (int k = lane; k < a.k1 / 2; k += kWave) {
+                const float4 w = x4[k];
+                C u, v;
+                u.x = w.x; u.y = w.y; v.x = w.z; v.y = w.w;
+                line[lpad(a.map[2 * k])] = u;
+                line[lpad(a.map[2 * k + 1])] = v;
+            }
+        } else {
+            for (int k = lane; k < a.k1; k += kWave) line[lpad(a.map[k])] = xin[k];
+        }
         wave_lds_fence();
         fft_line<T, N, 1>(line, tw, lane);
         C* zout = static_cast<C*>(a.out) + line_id * N;
