@@ -25,6 +25,7 @@ def _rel(a, b):
     (np.float64, (48, 40), 1.5, O.FAST_APPROXIMATION),       # general path (rocFFT + deconvolution kernels)
     (np.float64, (32, 32, 32), 2.0, O.FAST_APPROXIMATION),   # pruned FFT passes
     (np.complex64, (32, 64, 32), 2.0, O.DIRECT),
+    (np.float64, (64, 64, 32), 2.0, O.FAST_APPROXIMATION),   # spreading window in its halo variant: the captured FFT pass adds the side buffer
 ])
 def test_graph_replay_matches_oracle_on_new_data(Z, dims, sigma, evalmode):
     from nufft_pkg import nufft
@@ -36,6 +37,8 @@ def test_graph_replay_matches_oracle_on_new_data(Z, dims, sigma, evalmode):
     plan = nufft.PlanNUFFT(Zt, dims, m=4, sigma=sigma, kernel_evalmode=mode, backend=nufft.ROCBackend(0))
     oplan = O.OraclePlan(dims, is_real=is_real, dtype=T, M=4, sigma=sigma, evalmode=evalmode)
     dev = plan.device
+    if dims == (64, 64, 32):
+        assert plan.info().spread_method == 3 and plan.info().ring_halo == 1
 
     def inputs(seed):
         rng = np.random.default_rng(seed)
