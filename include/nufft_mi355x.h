@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define NUFFT_MI355X_VERSION 102 /* 0.1.2: nufft_spread_deferred added, nufft_info.reserved_info became ring_halo (same layout) since 101;
+#define NUFFT_MI355X_VERSION 103 /* 0.1.3: nufft_params grew (kernel_param_dim, N_over: what a binding that already holds the reference's
+                                    per-dimension kernel data forwards verbatim), NUFFT_METHOD_GLOBAL_MEMORY accepted, nufft_copy_grid
+                                    takes a non-const plan since 102;
+                                    0.1.2: nufft_spread_deferred added, nufft_info.reserved_info became ring_halo (same layout) since 101;
                                     0.1.1: nufft_info grew (patch_dims .. ring_segments) since 100 — a caller built against an older
                                     header must compare nufft_sizeof_info() / nufft_version() with its own before nufft_plan_info() */
 
@@ -57,7 +60,10 @@ enum {                                                          /* the four kern
     NUFFT_KERNEL_BSPLINE                 = 3   /* BSplineKernel, bspline.jl                                */
 };
 enum { NUFFT_EVAL_DIRECT = 0, NUFFT_EVAL_FAST_APPROXIMATION = 1 }; /* Kernels.EvaluationMode     */
-enum { NUFFT_METHOD_SHARED_MEMORY = 0 };                       /* gpu_method = :shared_memory    */
+enum {                                                          /* gpu_method (src/blocking/gpu.jl:26): scheduling-only in the   */
+    NUFFT_METHOD_SHARED_MEMORY = 0,                             /* reference (same sums, src/spreading/gpu.jl:168-214); every    */
+    NUFFT_METHOD_GLOBAL_MEMORY = 1                              /* plan here runs the LDS engines, both values are accepted      */
+};
 enum {
     NUFFT_POINT_TRANSFORM_IDENTITY = 0, /* point_transform = identity (src/plan.jl:476)                    */
     NUFFT_POINT_TRANSFORM_NFFT     = 1  /* _transform_point_convention, src/abstractNFFTs.jl:147-155:
@@ -108,6 +114,13 @@ typedef struct nufft_params {
     double  kernel_param;    /* KaiserBesselKernel(β) / BackwardsKaiserBesselKernel(β) / GaussianKernel(ℓ):
                                 explicit shape parameter; 0 -> the optimal one for (M, σ)              */
     int32_t reserved[2];
+    double  kernel_param_dim[3]; /* per-dimension shape parameter, as the reference's kernel data holds it (the field β of
+                                    BackwardsKaiserBesselKernelData / KaiserBesselKernelData, kaiser_bessel_backwards.jl:84,
+                                    kaiser_bessel.jl:112; σ / Δx of GaussianKernelData, gaussian.jl:67,76-78): an entry > 0 overrides
+                                    kernel_param and the optimal value for that dimension, so a binding forwards p.kernels[d] verbatim */
+    int64_t N_over[3];       /* oversampled grid size Ñ_d (gridsize(p.kernels[d]), src/Kernels/Kernels.jl:87): an entry > 0 replaces the
+                                size rule of src/plan.jl:485-498 for that dimension (it must be even in dimension 1 of a real plan
+                                and >= N_d); sigma is then only reported */
 } nufft_params;
 
 /* What show(::PlanNUFFT) prints (src/plan.jl:362-392) plus sizes a caller needs. */
@@ -222,9 +235,13 @@ int nufft_fill_zeros(nufft_plan* plan, void* stream);
 /* spread_from_points!(::GPU, ...), src/spreading/gpu.jl:134-214 (adds onto the plan's grids). */
 int nufft_spread(nufft_plan* plan, const void* const* values_in, void* stream);
 /* The same stage as exec_type1 enqueues it: on plans whose spreading engine is the marching ring's halo variant (nufft_info.ring_halo)
- * the stencil reach beyond each workgroup's column is left in a side buffer and the oversampled grid is completed by the next
- * nufft_fft_forward (its dimension-1 pass adds the buffer while it loads the lines), nufft_interpolate or nufft_copy_grid on this
- * plan — nufft_spread completes it itself with one more pass.  Identical to nufft_spread on every other plan.
+ * the stencil reach beyond each workgroup's column is left in a side buffer.  nufft_fft_forward consumes it on the fly (its
+ * dimension-1 pass adds the buffer to the lines it loads — the spectrum is that of the complete grid, `us` itself stays without
+ * the reach); nufft_complete_grid, nufft_copy_grid(which = 0) and nufft_interpolate add it to `us` (once), before or after that FFT.
+ * The pending state ends with the next nufft_set_points, nufft_spread[_deferred], nufft_fill_zeros or nufft_fft_backward.
+ * nufft_spread completes the grid itself with one more pass.  Identical to nufft_spread on every other plan.
+ * The state is host-side: a deferred spread and its consumer must be enqueued on the same stream, and captured in the same hipGraph
+ * (tests/test_gpu_graph.py), since a replayed spread does not set it again.
  * (No reference counterpart: src/NonuniformFFTs.jl:169-177 calls spread_from_points! and _type1_fft! back to back.) */
 int nufft_spread_deferred(nufft_plan* plan, const void* const* values_in, void* stream);
 /* _type1_fft!, src/NonuniformFFTs.jl:197-211. */
@@ -238,13 +255,18 @@ int nufft_fft_backward(nufft_plan* plan, void* stream);
 /* interpolate!(::GPU, ...), src/interpolation/gpu.jl:40-118. */
 int nufft_interpolate(nufft_plan* plan, void* const* values_out, void* stream);
 
+/* Adds the side buffer of a deferred spread to `us` if that has not happened yet (no-op otherwise): after it, `us` holds the full
+ * spread field as after the reference's spread_from_points! (src/NonuniformFFTs.jl:169-172), also behind nufft_exec_type1. */
+int nufft_complete_grid(nufft_plan* plan, void* stream);
+
 /* Device pointer of plan-owned oversampled arrays (p.data.us / p.data.ûs, src/plan.jl:3-29):
- * which = 0 -> us[c] (real T[N_over] or complex), which = 1 -> ûs[c] (real plans only). */
+ * which = 0 -> us[c] (real T[N_over] or complex), which = 1 -> ûs[c] (real plans only).
+ * which = 0 is refused (NUFFT_ERR_INVALID_ARG) while a deferred spread is pending: call nufft_complete_grid first. */
 int nufft_grid_ptr(const nufft_plan* plan, int which, int component, void** out_ptr, int64_t* out_bytes);
 
 /* Device-to-device copy of one plan-owned oversampled array (same `which` as nufft_grid_ptr) into
  * a caller buffer of at least `capacity_bytes`; enqueued on `stream`. */
-int nufft_copy_grid(const nufft_plan* plan, int which, int component, void* dst, int64_t capacity_bytes, void* stream);
+int nufft_copy_grid(nufft_plan* plan, int which, int component, void* dst, int64_t capacity_bytes, void* stream);
 
 /* Sorted-point inspection: copies the bin-sort permutation (sorted position -> original index,
  * 0-based; BlockDataGPU.pointperm, src/blocking/gpu.jl:15) and the per-tile offsets

@@ -1,81 +1,133 @@
 # NonuniformFFTsMI355XExt.jl — package extension that routes a NonuniformFFTs.jl plan to libnufft_mi355x.so.
 #
 # Copy to NonuniformFFTs.jl/ext/ and declare it in Project.toml ([weakdeps] AMDGPU, [extensions]
-# NonuniformFFTsMI355XExt = "AMDGPU"); see INTEGRATION.md for the dispatch points it uses and why nothing inside src/
-# is edited.  NEVER EXECUTED in the build image (no Julia runtime): tests/test_julia_shim_static.py checks every ccall
-# (symbol, return type, argument types) and the mirrored structs against include/nufft_mi355x.h, and every
-# NonuniformFFTs function it overloads against the reference source (name and positional arity).
+# NonuniformFFTsMI355XExt = "AMDGPU"); INTEGRATION.md walks _PlanNUFFT (src/plan.jl:467-541) line by line and names the method
+# every call hits for this backend.  Nothing inside src/ is edited.
+# NEVER EXECUTED in the build image (no Julia runtime).  tests/test_julia_shim_static.py checks, against include/nufft_mi355x.h and
+# the reference source: every ccall (symbol, return and argument types), the mirrored structs, every NUFFT_* constant, that the
+# enum slots of CParams are filled from those constants only, every NonuniformFFTs.* / Kernels.* / AbstractNFFTs.* name the file
+# *calls* (exists, with that positional arity), every field it reads from a reference struct, every constructor call of its own
+# structs (as many arguments as fields), and that each overload repeats a reference signature in every slot but the backend's
+# (so it is strictly more specific: no ambiguity).
 module NonuniformFFTsMI355XExt
 
 using NonuniformFFTs
-using NonuniformFFTs: PlanNUFFT, NUFFTCallbacks, default_callback, Kernels, AbstractBlockData, AbstractNUFFTData,
-                      HalfSupport, StaticBool, Direct, get_timer_nowarn, maybe_synchronise
+using NonuniformFFTs: PlanNUFFT, NUFFTCallbacks, default_callback, Kernels, AbstractBlockData, AbstractNUFFTData, AbstractNFFTs,
+                      HalfSupport, StaticBool, True, False, Direct, AbstractKernel
+using NonuniformFFTs.Kernels: AbstractKernelData
 using TimerOutputs: @timeit
+using Adapt: adapt
 using AMDGPU
 using KernelAbstractions: KernelAbstractions as KA
 
 const libnufft = "libnufft_mi355x.so"      # nonuniformffts.jl_amd/libnufft_mi355x.so
 
+# ---- constants of include/nufft_mi355x.h (checked one by one against the header) --------------------------------------
+const NUFFT_F32 = Int32(0)
+const NUFFT_F64 = Int32(1)
+const NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL = Int32(0)
+const NUFFT_KERNEL_KAISER_BESSEL = Int32(1)
+const NUFFT_KERNEL_GAUSSIAN = Int32(2)
+const NUFFT_KERNEL_BSPLINE = Int32(3)
+const NUFFT_EVAL_DIRECT = Int32(0)
+const NUFFT_EVAL_FAST_APPROXIMATION = Int32(1)
+const NUFFT_METHOD_SHARED_MEMORY = Int32(0)
+const NUFFT_METHOD_GLOBAL_MEMORY = Int32(1)
+const NUFFT_POINT_TRANSFORM_IDENTITY = Int32(0)
+const NUFFT_POINT_TRANSFORM_NFFT = Int32(1)
+const NUFFT_SPREAD_AUTO = Int32(0)
+const NUFFT_ERR_INVALID_ARG = Int32(1)
+const NUFFT_ERR_SIZE_TOO_SMALL = Int32(2)
+const NUFFT_ERR_DIM_MISMATCH = Int32(3)
+const NUFFT_ERR_LDS_TOO_SMALL = Int32(4)
+const NUFFT_ERR_UNSUPPORTED = Int32(5)
+const NUFFT_ERR_NO_POINTS = Int32(6)
+const NUFFT_ERR_NO_DEVICE = Int32(10)
+
 # ---- backend value: a KA.GPU of its own, forwarding allocation to ROCBackend ----------------------------------------
 struct MI355XBackend <: KA.GPU
     roc::ROCBackend
-    last_Ns::Base.RefValue{Any}            # written by default_block_size, read by BlockDataGPU (same _PlanNUFFT call)
 end
-MI355XBackend() = MI355XBackend(ROCBackend(), Ref{Any}(nothing))
-KA.allocate(b::MI355XBackend, args...) = KA.allocate(b.roc, args...)
-KA.zeros(b::MI355XBackend, args...) = KA.zeros(b.roc, args...)
+MI355XBackend() = MI355XBackend(ROCBackend())
+# (KA.allocate(backend, T, dims...) and KA.zeros(backend, T, dims...) of KernelAbstractions forward to this tuple form)
+KA.allocate(b::MI355XBackend, ::Type{T}, dims::Tuple; kws...) where {T} = KA.allocate(b.roc, T, dims; kws...)
 KA.synchronize(b::MI355XBackend) = KA.synchronize(b.roc)
 
 NonuniformFFTs.default_kernel(::MI355XBackend) = BackwardsKaiserBesselKernel()   # ext/NonuniformFFTsAMDGPUExt.jl:54
 NonuniformFFTs.default_kernel_evalmode(::MI355XBackend) = Direct()               # ext/NonuniformFFTsAMDGPUExt.jl:56
-function NonuniformFFTs.default_block_size(Ns::Dims, b::MI355XBackend)
-    b.last_Ns[] = Ns
-    NonuniformFFTs.default_block_size(Ns, b.roc)                                 # src/NonuniformFFTs.jl:59-63
-end
+# default_block_size(Ns, ::GPU), default_gpu_batch_size(::KA.Backend), to_unit_cell(::GPU, x): the reference's generic methods apply
+# (src/NonuniformFFTs.jl:58-63, src/gpu_common.jl:7, src/blocking/blocking.jl:7)
 
 lasterr() = unsafe_string(ccall((:nufft_last_error_message, libnufft), Cstring, ()))
 check(rc::Cint) = rc == 0 ? nothing :
-    rc in (1, 2, 4, 5, 6, 10) ? throw(ArgumentError(lasterr())) :
-    rc == 3 ? throw(DimensionMismatch(lasterr())) : error(lasterr())
+    rc in (NUFFT_ERR_INVALID_ARG, NUFFT_ERR_SIZE_TOO_SMALL, NUFFT_ERR_LDS_TOO_SMALL, NUFFT_ERR_UNSUPPORTED, NUFFT_ERR_NO_POINTS, NUFFT_ERR_NO_DEVICE) ?
+        throw(ArgumentError(lasterr())) :
+    rc == NUFFT_ERR_DIM_MISMATCH ? throw(DimensionMismatch(lasterr())) : error(lasterr())
 
 # ---- plan-owned state ------------------------------------------------------------------------------------------------
-mutable struct MI355XBlockData{D} <: AbstractBlockData
-    handle::Ptr{Cvoid}                     # C_NULL until the first set_points!
-    Ns::Union{Nothing, Dims{D}}            # from default_block_size; nothing if the caller passed block_size itself
-    Ñs::Dims{D}
+# p.blocks: only what show(::PlanNUFFT) and the keyword checks ask of it (src/plan.jl:375-390) — no tile arrays
+struct MI355XBlockData{D, S <: StaticBool, Np} <: AbstractBlockData
     method::Symbol
-    sort_points::StaticBool
+    block_dims::Dims{D}
+    sort_points::S
+    batch_size::Val{Np}
 end
-function NonuniformFFTs.BlockDataGPU(::Type{Z}, b::MI355XBackend, block_dims::Dims{D}, Ñs::Dims{D}, ::HalfSupport,
-                                     sort_points::StaticBool; method::Symbol, batch_size::Val) where {Z <: Number, D}
+function NonuniformFFTs.BlockDataGPU(::Type{Z}, backend::MI355XBackend, block_dims::Dims{D}, Ñs::Dims{D}, h::HalfSupport{M},
+                                     sort_points::StaticBool; method::Symbol, batch_size::Val) where {Z <: Number, D, M}
     method ∈ (:global_memory, :shared_memory) || throw(ArgumentError("expected gpu_method ∈ (:global_memory, :shared_memory)"))   # src/blocking/gpu.jl:26
-    Ns = b.last_Ns[] isa Dims{D} ? b.last_Ns[] : nothing
-    b.last_Ns[] = nothing
-    bd = MI355XBlockData{D}(C_NULL, Ns, Ñs, method, sort_points)
-    finalizer(o -> o.handle == C_NULL || ccall((:nufft_plan_destroy, libnufft), Cint, (Ptr{Cvoid},), o.handle), bd)
-    bd
+    MI355XBlockData(method, block_dims, sort_points, batch_size)
 end
-NonuniformFFTs.gpu_method(bd::MI355XBlockData) = bd.method                 # what show(::PlanNUFFT) asks, src/plan.jl:380-388
-NonuniformFFTs.with_blocking(::MI355XBlockData) = true
-NonuniformFFTs.get_block_dims(::MI355XBlockData) = nothing
-NonuniformFFTs.get_sort_points(bd::MI355XBlockData) = bd.sort_points
-NonuniformFFTs.get_batch_size(::MI355XBlockData) = 0
+NonuniformFFTs.gpu_method(bd::MI355XBlockData) = bd.method                 # show(::PlanNUFFT), src/plan.jl:381
+NonuniformFFTs.with_blocking(bd::MI355XBlockData) = true
+NonuniformFFTs.get_batch_size(bd::MI355XBlockData) = NonuniformFFTs.get_batch_size(bd.batch_size)      # src/blocking/gpu.jl:38-39
+# get_block_dims(bd) = bd.block_dims and get_sort_points(bd) = bd.sort_points: the AbstractBlockData defaults (src/blocking/blocking.jl:3-4)
 
-struct MI355XData{Z, N, Nc, W, A} <: AbstractNUFFTData{Z, N, Nc}
+# What _PlanNUFFT asks of output_field(data) (src/plan.jl:531-535): `first(...)::AbstractArray{<:Complex}` and its `axes`, which
+# non_oversampled_indices! requires to be at least as long as ks (src/NonuniformFFTs.jl:322).  A storage-free array of the
+# oversampled spectrum's size: (Ñ₁÷2+1, Ñ₂, …) for real data, Ñs for complex data (src/plan.jl:43,55).  Never read.
+struct SpectrumShape{T, N} <: AbstractArray{Complex{T}, N}
+    dims::Dims{N}
+end
+Base.size(a::SpectrumShape) = a.dims
+Base.getindex(a::SpectrumShape{T, N}, I::Vararg{Int, N}) where {T, N} = zero(Complex{T})
+
+# p.data: the wavenumbers (size(p), check_nufft_uniform_data: src/plan.jl:426, src/NonuniformFFTs.jl:92-103) and the C handle,
+# created at the first set_points!.  No KA grids and no rocFFT plans: the handle owns them.
+mutable struct MI355XData{Z, N, Nc, W, T} <: AbstractNUFFTData{Z, N, Nc}
     ks::W
-    stub::A                                 # 1-element ROCArray{complex(real(Z)), N}: output_field for _PlanNUFFT's index_map lines
+    shape::NTuple{Nc, SpectrumShape{T, N}}
+    handle::Ptr{Cvoid}
 end
-NonuniformFFTs.output_field(d::MI355XData) = d.stub
-function NonuniformFFTs.init_plan_data(::Type{Z}, b::MI355XBackend, Ñs::Dims{N}, ks::NTuple, ::Val{Nc}; plan_kwargs) where {Z <: Number, N, Nc}
-    stub = KA.zeros(b, complex(real(Z)), ntuple(_ -> 1, Val(N)))
-    MI355XData{Z, N, Nc, typeof(ks), typeof(stub)}(ks, (stub,))
+NonuniformFFTs.output_field(data::MI355XData) = data.shape                 # a tuple of Nc arrays, as for RealNUFFTData (src/plan.jl:33)
+function new_plan_data(::Type{Z}, dims_out::Dims{N}, ks::W, ::Val{Nc}) where {Z, N, W, Nc}
+    T = real(Z)
+    shape = ntuple(_ -> SpectrumShape{T, N}(dims_out), Val(Nc))
+    data = MI355XData{Z, N, Nc, W, T}(ks, shape, C_NULL)
+    finalizer(d -> d.handle == C_NULL || ccall((:nufft_plan_destroy, libnufft), Cint, (Ptr{Cvoid},), d.handle), data)
+    data
 end
-# (the stock index_map of such a plan is non_oversampled_indices!(…, axes(stub)…): unused — the handle builds its own.)
+# one method per method of the reference (src/plan.jl:37-41, 52-56): the same first-argument types, so that these are strictly
+# more specific (a single `::Type{Z}` method would be ambiguous with both)
+function NonuniformFFTs.init_plan_data(::Type{T}, backend::MI355XBackend, Ñs::Dims, ks::NTuple, ::Val{Nc};
+                                       plan_kwargs) where {T <: AbstractFloat, Nc}
+    new_plan_data(T, (Ñs[1] ÷ 2 + 1, Base.tail(Ñs)...), ks, Val(Nc))
+end
+function NonuniformFFTs.init_plan_data(::Type{Complex{T}}, backend::MI355XBackend, Ñs::Dims, ks::NTuple, ::Val{Nc};
+                                       plan_kwargs) where {T <: AbstractFloat, Nc}
+    new_plan_data(Complex{T}, Ñs, ks, Val(Nc))
+end
 
-kernel_id(::BackwardsKaiserBesselKernel) = 0     # NUFFT_KERNEL_* of include/nufft_mi355x.h
-kernel_id(::KaiserBesselKernel) = 1
-kernel_id(::GaussianKernel) = 2
-kernel_id(::BSplineKernel) = 3
+# The kernel is the first type parameter of the kernel data (AbstractKernelData{K, M, T}, src/Kernels/Kernels.jl:63); the shape
+# parameter is a field of the data — already resolved per dimension by optimal_kernel, explicit or optimal, in the plan's precision:
+# β (kaiser_bessel_backwards.jl:84, kaiser_bessel.jl:112), σ = ℓ Δx (gaussian.jl:67,76-78); the B-spline has none.
+kernel_id(::AbstractKernelData{BackwardsKaiserBesselKernel}) = NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL
+kernel_id(::AbstractKernelData{KaiserBesselKernel}) = NUFFT_KERNEL_KAISER_BESSEL
+kernel_id(::AbstractKernelData{GaussianKernel}) = NUFFT_KERNEL_GAUSSIAN
+kernel_id(::AbstractKernelData{BSplineKernel}) = NUFFT_KERNEL_BSPLINE
+shape_param(g::AbstractKernelData{BackwardsKaiserBesselKernel}) = Float64(g.β)
+shape_param(g::AbstractKernelData{KaiserBesselKernel}) = Float64(g.β)
+shape_param(g::AbstractKernelData{GaussianKernel}) = Float64(g.σ / Kernels.gridstep(g))
+shape_param(g::AbstractKernelData{BSplineKernel}) = 0.0
 
 # nufft_params mirrored field by field (include/nufft_mi355x.h); nufft_sizeof_params() guards the layout
 struct CParams
@@ -83,40 +135,40 @@ struct CParams
     kernel::Int32; evalmode::Int32; ntransforms::Int32; fftshift::Int32; point_transform::Int32; gpu_method::Int32
     device::Int32; tile_dims::NTuple{3, Int32}; lds_budget_bytes::Int32; spread_threads::Int32; interp_threads::Int32
     interp_tile_dims::NTuple{3, Int32}; bin_log2::Int32; spread_method::Int32; kernel_param::Float64; reserved::NTuple{2, Int32}
+    kernel_param_dim::NTuple{3, Float64}; N_over::NTuple{3, Int64}
 end
 
-# Non-oversampled sizes of the plan.  Complex plans: length.(ks).  Real plans: N₁ ∈ {2L - 2, 2L - 1} with L = length(ks[1]);
-# recorded by default_block_size, else the candidate whose oversampled size reproduces Ñ₁ (src/plan.jl:491-494).
-function plan_Ns(p::PlanNUFFT{Z, N}, σ_wanted) where {Z, N}
-    bd = p.blocks
-    bd.Ns === nothing || return bd.Ns
-    Ls = map(length, p.data.ks)
-    Z <: Complex && return Ls
-    L = Ls[1]
-    cands = filter(n -> 2 * nextprod((2, 3, 5), floor(Int, σ_wanted * ((n + 1) ÷ 2))) == bd.Ñs[1], (2L - 2, 2L - 1))
-    isempty(cands) && throw(ArgumentError("cannot recover N₁ of a real plan created with an explicit block_size; omit block_size"))
-    (last(cands), Base.tail(Ls)...)
-end
+pad3(f, N, z) = ntuple(d -> d ≤ N ? f(d) : z, Val(3))
 
-function ensure_handle!(p::PlanNUFFT{Z, N, Nc, M}) where {Z, N, Nc, M}
-    bd = p.blocks
-    bd.handle == C_NULL || return bd.handle
+# The handle is built from the plan's own fields: the oversampled sizes and shape parameters the reference has already resolved
+# go over verbatim (N_over, kernel_param_dim), so the library repeats nothing of src/plan.jl:485-506.  For real data only
+# N₁÷2+1 wavenumbers survive in the plan (src/plan.jl:560): N₁ = 2(L - 1) is sent — with Ñ₁ and β given, nothing else depends on
+# the parity of N₁ (the retained modes k = 0 … L - 1, their ϕ̂ and the oversampled grid are the same for 2L - 2 and 2L - 1).
+function ensure_handle!(p::PlanNUFFT{Z, N, Nc, M, MI355XBackend}) where {Z, N, Nc, M}
+    data = p.data
+    data.handle == C_NULL || return data.handle
     ccall((:nufft_sizeof_params, libnufft), Int64, ()) == sizeof(CParams) || error("nufft_params layout differs from the library's")
-    fold = p.point_transform_fold                     # generate_point_transform_fold_function(point_transform, backend), src/plan.jl:459-464
-    pt = fold.point_transform                         # closure field: identity or _transform_point_convention
+    fold = p.point_transform_fold                     # closure of generate_point_transform_fold_function, src/plan.jl:459-464
+    pt = fold.point_transform                         # its captured `point_transform`: identity or _transform_point_convention
     pt === identity || pt === NonuniformFFTs._transform_point_convention ||
         throw(ArgumentError("MI355XBackend: point_transform must be identity or the AbstractNFFTs convention (closures cannot cross the C ABI); use ROCBackend()"))
-    kern = Kernels.kernel(first(p.kernels))          # the AbstractKernel the data was built from (β / ℓ explicit or nothing)
-    σ = Float64(p.σ)                                  # actual σ = max(Ñ ./ N): reproduces Ñ (nextprod is idempotent on 2-3-5 numbers)
-    Ns = plan_Ns(p, σ)
     T = real(Z)
-    prm = CParams(T === Float64 ? 1 : 0, Z <: Complex, N, ntuple(d -> d ≤ N ? Int64(Ns[d]) : Int64(0), 3), M, σ,
-                  kernel_id(kern), p.kernel_evalmode isa Direct ? 0 : 1, Nc, p.fftshift, pt === identity ? 0 : 1,
-                  bd.method === :shared_memory ? 1 : 0, AMDGPU.device_id(AMDGPU.device()) - 1,
-                  (0, 0, 0), 0, 0, 0, (0, 0, 0), 0, 0, something(Kernels.shape_parameter(kern), 0.0), (0, 0))
+    Ls = map(length, data.ks)
+    Ns = pad3(d -> Int64(Z <: Real && d == 1 ? 2 * (Ls[1] - 1) : Ls[d]), N, Int64(0))
+    Ñs = pad3(d -> Int64(Kernels.gridsize(p.kernels[d])), N, Int64(0))
+    βs = pad3(d -> shape_param(p.kernels[d]), N, 0.0)
+    dtype = T === Float64 ? NUFFT_F64 : NUFFT_F32
+    evalmode = p.kernel_evalmode isa Direct ? NUFFT_EVAL_DIRECT : NUFFT_EVAL_FAST_APPROXIMATION
+    ptrans = pt === identity ? NUFFT_POINT_TRANSFORM_IDENTITY : NUFFT_POINT_TRANSFORM_NFFT
+    method = NonuniformFFTs.gpu_method(p.blocks) === :shared_memory ? NUFFT_METHOD_SHARED_MEMORY : NUFFT_METHOD_GLOBAL_MEMORY
+    zero3 = (Int32(0), Int32(0), Int32(0))
+    prm = CParams(dtype, Int32(Z <: Complex), Int32(N), Ns, Int32(M), Float64(p.σ),
+                  kernel_id(first(p.kernels)), evalmode, Int32(Nc), Int32(p.fftshift), ptrans, method,
+                  Int32(AMDGPU.device_id(AMDGPU.device()) - 1),
+                  zero3, Int32(0), Int32(0), Int32(0), zero3, Int32(0), NUFFT_SPREAD_AUTO, 0.0, (Int32(0), Int32(0)), βs, Ñs)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:nufft_plan_create_ex, libnufft), Cint, (Ref{Ptr{Cvoid}}, Ref{CParams}), h, Ref(prm)))
-    bd.handle = h[]
+    data.handle = h[]
 end
 
 # ---- callback menu ---------------------------------------------------------------------------------------------------
@@ -133,56 +185,98 @@ function ccallbacks(cb::NUFFTCallbacks)
     Ref(CCallbacks(cptr(cb.nonuniform), cptr(cb.uniform)))
 end
 
-stream_ptr() = Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream().stream)
+stream_ptr() = reinterpret(Ptr{Cvoid}, AMDGPU.stream().stream)
 ptrs(xs::NTuple{N, ROCArray}) where {N} = Ptr{Cvoid}[Ptr{Cvoid}(UInt(pointer(x))) for x in xs]
-const MIPlan{Z, N, Nc, M} = PlanNUFFT{Z, N, Nc, M, MI355XBackend}
+on_device(xs::Tuple) = all(x -> x isa ROCArray, xs) ||
+    throw(ArgumentError("MI355XBackend: points, values and uniform arrays must be ROCArrays"))
 
 # ---- set_points!  (src/set_points.jl:33-52 + set_points_impl!, src/blocking/gpu.jl:73-142) ----------------------------
-function NonuniformFFTs.set_points!(p::MIPlan{Z, N}, xp::NTuple{N, ROCVector{T}}; kwargs...) where {Z, N, T}
+# the reference's signature with the plan narrowed to this backend: strictly more specific; the matrix / vector-of-tuples /
+# 1-D forms (src/set_points.jl:55-88) convert their argument and land here
+function NonuniformFFTs.set_points!(p::PlanNUFFT{Z, N, Nc, M, MI355XBackend}, xp::NTuple{N, AbstractVector{T}};
+                                    kwargs...) where {Z, N, Nc, M, T}
     T === real(Z) || throw(ArgumentError(lazy"input points must have the same accuracy as the created plan (got $T points for a $Z plan)"))
+    P_in, P_plan = typeof(xp), eltype(p.points_ref)
+    P_in === P_plan || throw(ArgumentError(lazy"""unexpected point container:
+        - expected:  points::$P_plan
+        - got:       points::$P_in"""))                # src/set_points.jl:36-44
+    on_device(xp)
     Np = length(xp[1])
     all(x -> length(x) == Np, xp) || throw(DimensionMismatch("input points must have the same length along all dimensions"))   # src/blocking/gpu.jl:86
     p.points_ref[] = xp                                # the plan keeps the caller's arrays, as the reference does (:45)
     h = ensure_handle!(p)
-    @timeit get_timer_nowarn(p) "Set points" begin
+    @timeit NonuniformFFTs.get_timer_nowarn(p) "Set points" begin
         GC.@preserve xp check(ccall((:nufft_set_points, libnufft), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}),
                                     h, Np, ptrs(xp), stream_ptr()))
-        maybe_synchronise(p)
+        NonuniformFFTs.maybe_synchronise(p)
     end
     p
 end
 
 # ---- exec_type1! / exec_type2!  (src/NonuniformFFTs.jl:148-195, 237-291) ---------------------------------------------
-function NonuniformFFTs.exec_type1!(ûs_k::NTuple{C, ROCArray{<:Complex}}, p::MIPlan{Z, N, C}, vp::NTuple{C, ROCVector{Z}};
-                                    callbacks::NUFFTCallbacks = NUFFTCallbacks()) where {Z, N, C}
-    eltype(first(ûs_k)) === complex(Z) || throw(ArgumentError("uniform data must have the same accuracy as the created plan"))   # :154
-    NonuniformFFTs.check_nufft_uniform_data(p, ûs_k)          # :92-103
-    NonuniformFFTs.check_nufft_nonuniform_data(p, vp)         # :105-114
+# (again the reference's signatures with the plan narrowed; T is the plan's non-uniform element type, Z the uniform one)
+function NonuniformFFTs.exec_type1!(ûs_k::NTuple{C, AbstractArray{Z}}, p::PlanNUFFT{T, N, Nc, M, MI355XBackend},
+                                    vp::NTuple{C, AbstractVector{T}};
+                                    callbacks::NUFFTCallbacks = NUFFTCallbacks()) where {T, Z, C, N, Nc, M}
+    Z === complex(T) || throw(ArgumentError(lazy"uniform data must have the same accuracy as the created plan (got $Z values for a $T plan)"))   # :154
     cb = ccallbacks(callbacks)
-    @timeit get_timer_nowarn(p) "Execute type 1" begin
+    @timeit NonuniformFFTs.get_timer_nowarn(p) "Execute type 1" begin
+        NonuniformFFTs.check_nufft_uniform_data(p, ûs_k)          # :92-103
+        NonuniformFFTs.check_nufft_nonuniform_data(p, vp)         # :105-114
+        on_device(ûs_k); on_device(vp)
         GC.@preserve ûs_k vp callbacks check(ccall((:nufft_exec_type1_cb, libnufft), Cint,
             (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ref{CCallbacks}, Ptr{Cvoid}),
-            p.blocks.handle, ptrs(ûs_k), ptrs(vp), cb, stream_ptr()))
-        maybe_synchronise(p)
+            p.data.handle, ptrs(ûs_k), ptrs(vp), cb, stream_ptr()))
+        NonuniformFFTs.maybe_synchronise(p)
     end
     ûs_k
 end
 
-function NonuniformFFTs.exec_type2!(vp::NTuple{C, ROCVector{Z}}, p::MIPlan{Z, N, C}, ûs_k::NTuple{C, ROCArray{<:Complex}};
-                                    callbacks::NUFFTCallbacks = NUFFTCallbacks()) where {Z, N, C}
-    eltype(first(ûs_k)) === complex(Z) || throw(ArgumentError("uniform data must have the same accuracy as the created plan"))   # :243
-    NonuniformFFTs.check_nufft_uniform_data(p, ûs_k)
-    NonuniformFFTs.check_nufft_nonuniform_data(p, vp)
+function NonuniformFFTs.exec_type2!(vp::NTuple{C, AbstractVector{T}}, p::PlanNUFFT{T, N, Nc, M, MI355XBackend},
+                                    ûs_k::NTuple{C, AbstractArray{Z}};
+                                    callbacks::NUFFTCallbacks = NUFFTCallbacks()) where {T, Z, C, N, Nc, M}
+    Z === complex(T) || throw(ArgumentError(lazy"uniform data must have the same accuracy as the created plan (got $Z values for a $T plan)"))   # :243
     cb = ccallbacks(callbacks)
-    @timeit get_timer_nowarn(p) "Execute type 2" begin
+    @timeit NonuniformFFTs.get_timer_nowarn(p) "Execute type 2" begin
+        NonuniformFFTs.check_nufft_uniform_data(p, ûs_k)
+        NonuniformFFTs.check_nufft_nonuniform_data(p, vp)
+        on_device(ûs_k); on_device(vp)
         GC.@preserve ûs_k vp callbacks check(ccall((:nufft_exec_type2_cb, libnufft), Cint,
             (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ref{CCallbacks}, Ptr{Cvoid}),
-            p.blocks.handle, ptrs(vp), ptrs(ûs_k), cb, stream_ptr()))
-        maybe_synchronise(p)
+            p.data.handle, ptrs(vp), ptrs(ûs_k), cb, stream_ptr()))
+        NonuniformFFTs.maybe_synchronise(p)
     end
     vp
 end
-# the single-array forms (exec_type1!(ûs::AbstractArray, p, vp::AbstractVector), :125) wrap their arguments in 1-tuples and
-# land here unchanged.
+# the single-array forms (src/NonuniformFFTs.jl:193-196, 288-291) wrap their arguments in 1-tuples and land here; a plan without
+# points has a C_NULL handle: check_nufft_nonuniform_data has then thrown already unless Np = 0, and the library answers
+# NUFFT_ERR_INVALID_ARG ("null plan") for that case.
+
+# ---- AbstractNFFTs entry (src/abstractNFFTs.jl:198-247) ---------------------------------------------------------------
+# NFFTPlan(xp, Ns; …) takes the backend from the array (KA.get_backend(xp), :214) and refuses any other (:218), so a ROCArray of
+# nodes always lands on the stock kernels.  The same constructor with the backend in front:
+function NonuniformFFTs.NFFTPlan(backend::MI355XBackend, xp::AbstractMatrix{T}, Ns::Dims;
+                                 fftflags = nothing, blocking = true, sortNodes = false,
+                                 window = NonuniformFFTs.default_kernel(backend), fftshift = true, precompute = nothing,
+                                 kws...) where {T <: AbstractFloat}
+    isnothing(precompute) || @warn "Precompute flags are not supported by the NonuniformFFTs backend and will be ignored."
+    kws_plan, kws_accuracy = NonuniformFFTs._split_accuracy_params(; kws...)
+    m_actual, σ_actual, reltol_actual = AbstractNFFTs.accuracyParams(; kws_accuracy...)
+    sort_points = sortNodes ? True() : False()
+    block_size = blocking ? NonuniformFFTs.default_block_size(Ns, backend) : nothing
+    kernel = window isa AbstractKernel ? window : NonuniformFFTs.convert_window_function(window, backend)
+    p = PlanNUFFT(Complex{T}, Ns, HalfSupport(m_actual); backend, σ = T(σ_actual), sort_points, fftshift, block_size, kernel,
+                  point_transform = NonuniformFFTs._transform_point_convention, kws_plan...)
+    pp = NonuniformFFTs.NFFTPlan(p)
+    AbstractNFFTs.nodes!(pp, xp)                       # -> set_points!(p, xp::AbstractMatrix) (:163-165) -> the method above
+    pp
+end
+
+# plan_nfft through AbstractNFFTs' backend selection: with(nfft_backend => NonuniformFFTsMI355XBackend()) do … end
+struct NonuniformFFTsMI355XBackend <: AbstractNFFTs.AbstractNFFTBackend end
+function AbstractNFFTs.plan_nfft(::NonuniformFFTsMI355XBackend, ::Type{Q}, xp::AbstractMatrix{T}, Ns::Dims{D};
+                                 kwargs...) where {Q, T, D}
+    NonuniformFFTs.NFFTPlan(MI355XBackend(), adapt(Q, xp), Ns; kwargs...)      # src/abstractNFFTs.jl:240-247
+end
 
 end # module

@@ -45,6 +45,8 @@ class NufftParams(C.Structure):
         ("spread_method", C.c_int32),
         ("kernel_param", C.c_double),
         ("reserved", C.c_int32 * 2),
+        ("kernel_param_dim", C.c_double * 3),
+        ("N_over", C.c_int64 * 3),
     ]
 
 
@@ -96,6 +98,7 @@ SYMBOLS = {
     "nufft_deconvolve_pad": (C.c_int, [_P, _PP, _P]),
     "nufft_fft_backward": (C.c_int, [_P, _P]),
     "nufft_interpolate": (C.c_int, [_P, _PP, _P]),
+    "nufft_complete_grid": (C.c_int, [_P, _P]),
     "nufft_grid_ptr": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "nufft_copy_grid": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "nufft_get_sort_result": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_uint32), C.c_int64, _P]),

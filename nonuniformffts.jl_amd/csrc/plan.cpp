@@ -173,7 +173,14 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         return fail(NUFFT_ERR_INVALID_ARG, "kernel_param must be positive (and BSplineKernel has no parameter)");
     if (p->evalmode != NUFFT_EVAL_DIRECT && p->evalmode != NUFFT_EVAL_FAST_APPROXIMATION)
         return fail(NUFFT_ERR_INVALID_ARG, "evalmode must be Direct (0) or FastApproximation (1)");
-    if (in->gpu_method != NUFFT_METHOD_SHARED_MEMORY) return fail(NUFFT_ERR_INVALID_ARG, "expected gpu_method = :shared_memory");
+    // gpu_method only reschedules the same sums in the reference (src/spreading/gpu.jl:168-214): both symbols are accepted
+    if (in->gpu_method != NUFFT_METHOD_SHARED_MEMORY && in->gpu_method != NUFFT_METHOD_GLOBAL_MEMORY)
+        return fail(NUFFT_ERR_INVALID_ARG, "expected gpu_method ∈ (:global_memory, :shared_memory)");      // src/blocking/gpu.jl:26
+    for (int d = 0; d < 3; ++d) {
+        if (in->kernel_param_dim[d] < 0.0 || (in->kernel_param_dim[d] != 0.0 && p->kernel == NUFFT_KERNEL_BSPLINE))
+            return fail(NUFFT_ERR_INVALID_ARG, "kernel_param_dim must be positive (and BSplineKernel has no parameter)");
+        if (in->N_over[d] < 0) return fail(NUFFT_ERR_INVALID_ARG, "N_over must be >= 0");
+    }
     if (in->point_transform != NUFFT_POINT_TRANSFORM_IDENTITY && in->point_transform != NUFFT_POINT_TRANSFORM_NFFT)
         return fail(NUFFT_ERR_UNSUPPORTED, "point_transform must be identity or the AbstractNFFTs convention (closures cannot cross the ABI)");
     p->point_transform = in->point_transform;
@@ -188,6 +195,11 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         if (p->N[d] < 1) return fail(NUFFT_ERR_INVALID_ARG, "grid dimensions must be >= 1");
         const bool r2c = !p->is_complex && d == 0;
         p->Nover[d] = oversampled_size(p->N[d], sigma_wanted, r2c);
+        if (in->N_over[d] > 0) {      // the caller holds the reference's plan already: gridsize(p.kernels[d]) verbatim
+            if (in->N_over[d] < p->N[d] || (r2c && (in->N_over[d] & 1)))
+                return fail(NUFFT_ERR_INVALID_ARG, "N_over must be >= N (and even along dimension 1 of a real plan)");
+            p->Nover[d] = in->N_over[d];
+        }
         if (p->Nover[d] < 2 * p->M) {   // check_nufft_size, src/plan.jl:545-556
             return fail(NUFFT_ERR_SIZE_TOO_SMALL, "data size is too small: sigma*N = " + std::to_string(p->Nover[d]) +
                                                       " < " + std::to_string(2 * p->M) + " = 2M");
@@ -204,7 +216,8 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         // optimal_kernel(kernel, T, h, Ñ, σ): shape parameter in the plan's precision, or the caller's
         // (kaiser_bessel_backwards.jl:123-136, kaiser_bessel.jl:151-165, gaussian.jl:107-116, bspline.jl:86-88)
         double beta = 0.0;
-        if (in->kernel_param > 0.0) beta = in->kernel_param;
+        if (in->kernel_param_dim[d] > 0.0) beta = in->kernel_param_dim[d];
+        else if (in->kernel_param > 0.0) beta = in->kernel_param;
         else if (p->kernel == NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL) beta = bkb_beta(p->M, sigma_d);
         else if (p->kernel == NUFFT_KERNEL_KAISER_BESSEL) beta = kb_beta(p->M, sigma_d);
         else if (p->kernel == NUFFT_KERNEL_GAUSSIAN) beta = gaussian_ell(p->M, sigma_d);
@@ -595,6 +608,49 @@ static int build_device(nufft_plan* p) {
         }
     }
 
+    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
+        hipDeviceProp_t prop;
+        NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
+        p->num_cus = prop.multiProcessorCount;
+        const bool other = needs_other_eval(p->kernel, p->evalmode);
+        int want_halo = p->smarch.halo;
+        if (want_halo == 2 && !(p->pruned_fft && p->compact_dim1) && env_int("NUFFT_SMARCH_HALO", 0) != 2) want_halo = 0;   // no fused consumer: not worth it
+        // the side buffer (0.52 x the grid per component at 32 x 32 columns, m = 4) is workspace the clipped columns do not need: when it
+        // does not fit, the plan keeps the ring without it instead of failing
+        for (;;) {
+            p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), other, p->num_cus, p->C, want_halo);
+            if (!p->smarch.eligible && want_halo)
+                p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), other, p->num_cus, p->C, 0);
+            if (!p->smarch.eligible || p->smarch.halo != 2) break;
+            const size_t bytes = (size_t)p->smarch.halo_reals * real_bytes(p) * p->C;
+            // (NUFFT_TEST_HALO_ALLOC_FAIL=1: the test of this fallback)
+            if (!env_int("NUFFT_TEST_HALO_ALLOC_FAIL", 0) && hipMalloc(&p->d_smarch_halo, bytes) == hipSuccess) { p->workspace_bytes += (int64_t)bytes; break; }
+            (void)hipGetLastError();
+            p->d_smarch_halo = nullptr;
+            want_halo = 0;
+        }
+        // build_host chose the engine for 256 CUs and the halo variant it hoped for: redo the automatic choice for what this device got
+        // (Float32 m = 7 belongs to the ring only with the halo variant: 20.1 ms clipped against 13.4 ms with the patches)
+        const int ring_max_m = !p->is_complex ? ((p->dtype == NUFFT_F32 && p->smarch.halo == 2) ? 7 : 6) : (p->dtype == NUFFT_F64 ? 4 : 3);
+        const bool keep = p->smarch.eligible && (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING || p->M <= ring_max_m);
+        if (!keep) {
+            if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING)
+                return fail(NUFFT_ERR_UNSUPPORTED, "marching-ring spreading: no decomposition for this device");
+            if (p->d_smarch_halo) { (void)hipFree(p->d_smarch_halo); p->d_smarch_halo = nullptr; }
+            p->smarch.eligible = false;
+            const bool prefer_patches = p->is_complex || p->M >= 5 || p->patch.planar != 0;
+            p->spread_method = (p->patch.eligible && prefer_patches) ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
+        }
+    }
+    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
+        NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M, p->smarch.halo));
+        const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_choice), 16 * sizeof(uint32_t)))) return rc;
+        NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 16 * sizeof(uint32_t)));
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, &p->d_smarch_tasks, (size_t)column_task_table_entries(p->smarch.ct, p->tile.nb[2]) * 8))) return rc;
+    }
+
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         NUFFT_HIP(prepare_spread_patch(p->dtype, p->is_complex, p->M, false, p->patch.planar));
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_choice), 16 * sizeof(uint32_t)))) return rc;
@@ -607,25 +663,6 @@ static int build_device(nufft_plan* p) {
         hipDeviceProp_t prop;
         NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
         p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
-    }
-
-    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
-        hipDeviceProp_t prop;
-        NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
-        p->num_cus = prop.multiProcessorCount;
-        int want_halo = p->smarch.halo;
-        if (want_halo == 2 && !(p->pruned_fft && p->compact_dim1) && env_int("NUFFT_SMARCH_HALO", 0) != 2) want_halo = 0;   // no fused consumer: not worth it
-        p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C, want_halo);
-        if (!p->smarch.eligible && want_halo)
-            p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), p->num_cus, p->C, 0);
-        if (!p->smarch.eligible) return fail(NUFFT_ERR_UNSUPPORTED, "marching-ring spreading: no decomposition for this device");
-        NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M, p->smarch.halo));
-        const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
-        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_choice), 16 * sizeof(uint32_t)))) return rc;
-        NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 16 * sizeof(uint32_t)));
-        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
-        if ((rc = dev_alloc(p, &p->d_smarch_tasks, (size_t)column_task_table_entries(p->smarch.ct, p->tile.nb[2]) * 8))) return rc;
-        if (p->smarch.halo == 2 && (rc = dev_alloc(p, &p->d_smarch_halo, (size_t)p->smarch.halo_reals * real_bytes(p) * p->C))) return rc;
     }
 
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->spread_method == NUFFT_SPREAD_MARCHING_RING || p->interp_march) NUFFT_HIP(prepare_column_tasks());
@@ -1332,10 +1369,10 @@ int nufft_fft_forward(nufft_plan* p, void* stream_) {
     StageTimer tm(p, NUFFT_STAGE_T1_FFT, stream);
     // behind nufft_spread_deferred: the dimension-1 pass of a real plan's own FFT adds the side buffer while it loads its lines;
     // every other FFT path gets the completed grid
-    struct Pending { nufft_plan* p; ~Pending() { p->halo_pending = false; } } pending{p};
+    // (the fused pass adds the buffer to the lines it has loaded, not to us: halo_pending stays set — us still lacks the reach, the
+    // side buffer stays valid until the next spread / set_points — and nufft_complete_grid / _copy_grid / _interpolate add it on demand)
     const bool fuse_halo = p->halo_pending && p->pruned_fft && p->compact_dim1 && p->D == 3 && p->halo_fuse;      // (compact_dim1: true for complex plans)
     if (p->halo_pending && !fuse_halo && (rc = complete_halo(p, stream))) return rc;
-    p->halo_pending = fuse_halo;
     if (p->pruned_fft) {
         if ((rc = pruned_forward_fft(p, stream))) return rc;
         if (p->D == 3 && p->C == 1) return pruned_forward_pass(p, 0, 1, nullptr, stream);
@@ -1498,6 +1535,9 @@ int nufft_grid_ptr(const nufft_plan* p, int which, int component, void** out_ptr
     if (rc) return rc;
     if (!out_ptr || component < 0 || component >= p->C) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
     if (which == 0) {
+        if (p->halo_pending)
+            return fail(NUFFT_ERR_INVALID_ARG, "us lacks the side buffer of a deferred spread (nufft_spread_deferred / nufft_exec_type1 on a "
+                                               "ring_halo plan): call nufft_complete_grid first, or use nufft_copy_grid");
         const size_t bytes = (size_t)p->grid_elems * value_bytes(p);
         *out_ptr = static_cast<char*>(p->d_us) + bytes * component;
         if (out_bytes) *out_bytes = (int64_t)bytes;
@@ -1511,15 +1551,26 @@ int nufft_grid_ptr(const nufft_plan* p, int which, int component, void** out_ptr
     return NUFFT_OK;
 }
 
-int nufft_copy_grid(const nufft_plan* p, int which, int component, void* dst, int64_t capacity_bytes, void* stream_) {
+int nufft_complete_grid(nufft_plan* p, void* stream_) {
+    int rc = require_device(p);
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    return complete_halo(p, static_cast<hipStream_t>(stream_));
+}
+
+int nufft_copy_grid(nufft_plan* p, int which, int component, void* dst, int64_t capacity_bytes, void* stream_) {
     void* src = nullptr;
     int64_t bytes = 0;
-    int rc = nufft_grid_ptr(p, which, component, &src, &bytes);
+    int rc = require_device(p);
     if (rc) return rc;
+    if (which == 0) {
+        DeviceGuard guard(p->device);
+        if ((rc = complete_halo(p, static_cast<hipStream_t>(stream_)))) return rc;
+    }
+    if ((rc = nufft_grid_ptr(p, which, component, &src, &bytes))) return rc;
     if (!dst) return fail(NUFFT_ERR_INVALID_ARG, "null destination");
     if (capacity_bytes < bytes) return fail(NUFFT_ERR_DIM_MISMATCH, "destination buffer too small");
     DeviceGuard guard(p->device);
-    if (which == 0 && p->halo_pending && (rc = complete_halo(const_cast<nufft_plan*>(p), static_cast<hipStream_t>(stream_)))) return rc;
     NUFFT_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream_)));
     return NUFFT_OK;
 }

@@ -205,7 +205,8 @@ class PlanNUFFT:
                  sort_points: bool = False, synchronise: bool = False, block_size=None, point_transform=None,
                  tile_dims: Optional[Sequence[int]] = None, interp_tile_dims: Optional[Sequence[int]] = None,
                  bin_log2: int = 0, lds_budget_bytes: int = 0, spread_threads: int = 0, interp_threads: int = 0,
-                 spread_method: Union[str, int] = "auto"):
+                 spread_method: Union[str, int] = "auto",
+                 kernel_param_dim: Optional[Sequence[float]] = None, oversampled_dims: Optional[Sequence[int]] = None):
         if dims is None:           # PlanNUFFT(dims; ...) form: ComplexF64 by default (src/plan.jl:597-599)
             Z, dims = torch.complex128, Z
         if isinstance(dims, int):
@@ -267,7 +268,15 @@ class PlanNUFFT:
         prm.ntransforms = self._ntransforms
         prm.fftshift = int(self.fftshift)
         prm.point_transform = ptrans
-        prm.gpu_method = 0
+        prm.gpu_method = 0 if gpu_method == "shared_memory" else 1      # NUFFT_METHOD_*: scheduling-only, both accepted
+        # what a binding that already holds the reference's plan forwards verbatim (julia/ext/NonuniformFFTsMI355XExt.jl):
+        # p.kernels[d].β (σ / Δx for the Gaussian) and gridsize(p.kernels[d]) per dimension
+        if kernel_param_dim is not None:
+            for d, v in enumerate(kernel_param_dim):
+                prm.kernel_param_dim[d] = float(v)
+        if oversampled_dims is not None:
+            for d, n in enumerate(oversampled_dims):
+                prm.N_over[d] = int(n)
         if backend is None:
             prm.device = -1
             self.device = None

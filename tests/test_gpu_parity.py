@@ -519,6 +519,115 @@ def test_spreading_ring_halo_variant_every_instantiation(Z, C, M, monkeypatch):
                 assert _rel(grid, refg[c]) < (1e-12 if np.dtype(Z) in (np.float64, np.complex128) else 1e-5), (M, c)
 
 
+@pytest.mark.parametrize("Z,C,fuse", [(np.float64, 1, "1"), (np.float64, 2, "1"), (np.float32, 1, "1"), (np.float64, 1, "0")])
+def test_oversampled_grid_after_exec_type1_on_halo_plans(Z, C, fuse, monkeypatch):
+    """`us` after exec_type1! is the spread field (the reference's r2c is out of place: `mul!(ûs, plan_fw, us)`,
+    src/NonuniformFFTs.jl:197-204).  On plans of the window's halo variant the fused FFT pass adds the side buffer to the lines it
+    loads, not to `us`: the grid is completed on demand (nufft_complete_grid / nufft_copy_grid / nufft_interpolate), once, and
+    nufft_grid_ptr refuses while that is pending."""
+    import ctypes as Ct
+    dims, Np, M = (48, 48, 56), 5000, 4
+    monkeypatch.setenv("NUFFT_SMARCH_HALO", "2")
+    monkeypatch.setenv("NUFFT_SMARCH_HALO_FUSE", fuse)
+    nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, O.DIRECT, C, Np, seed=4242, spread_method="marching_ring")
+    info = plan.info()
+    assert info.spread_method == 3 and info.ring_halo == 1
+    dev = plan.device
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+    vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
+    o64 = O.OraclePlan(dims, is_real=True, dtype=np.float64, M=M, sigma=2.0, evalmode=O.DIRECT, ntransforms=C)
+    O.set_points(o64, [x.astype(np.float64) for x in xs])
+    refg = O.spread(o64, [v.astype(np.float64) for v in vs])
+    scale = 2.0 ** sum(info.window_scale_log2[d] for d in range(3))
+    tol = 1e-12 if np.dtype(Z) == np.float64 else 1e-5
+    lib, h, stream = nufft.lib, plan._handle, plan._stream()
+    ptr, nbytes = Ct.c_void_p(), Ct.c_int64()
+
+    nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+    pending = fuse == "1"          # (the separate add pass in front of the FFT leaves nothing pending)
+    rc = lib.nufft_grid_ptr(h, 0, 0, Ct.byref(ptr), Ct.byref(nbytes))
+    assert rc == (nufft._lib.ERR_INVALID_ARG if pending else 0)
+    assert lib.nufft_grid_ptr(h, 1, 0, Ct.byref(ptr), Ct.byref(nbytes)) == 0          # the spectrum is not affected
+    grids = [nufft.oversampled_grid(plan, c).cpu().numpy().astype(np.float64) / scale for c in range(C)]      # nufft_copy_grid completes
+    for c in range(C):
+        assert _rel(grids[c], refg[c]) < tol, c
+    assert lib.nufft_grid_ptr(h, 0, 0, Ct.byref(ptr), Ct.byref(nbytes)) == 0
+    again = nufft.oversampled_grid(plan, 0).cpu().numpy().astype(np.float64) / scale                           # ... once: not added twice
+    assert np.array_equal(again, grids[0])
+
+    # nufft_complete_grid, then the raw pointer; and a second forward FFT + deconvolution on the completed grid gives the same modes
+    nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+    first = [u.clone() for u in us]
+    assert lib.nufft_complete_grid(h, stream) == 0 and lib.nufft_complete_grid(h, stream) == 0
+    assert lib.nufft_grid_ptr(h, 0, 0, Ct.byref(ptr), Ct.byref(nbytes)) == 0 and nbytes.value == grids[0].size * np.dtype(Z).itemsize
+    assert lib.nufft_fft_forward(h, stream) == 0
+    assert lib.nufft_deconvolve_truncate(h, nufft.plan._ptr_table(us), stream) == 0
+    for c in range(C):
+        assert _rel(us[c].cpu().numpy(), first[c].cpu().numpy()) < 10 * tol
+
+    # stage level: interpolation from the grid an exec_type1 left behind = interpolation of the oracle's spread field
+    nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+    out = tuple(torch.empty(Np, dtype=vd[0].dtype, device=dev) for _ in range(C))
+    nufft.interpolate(plan, out if C > 1 else out[0])
+    refv = O.interpolate(o64, [g.copy() for g in refg])
+    for c in range(C):
+        assert _rel(out[c].cpu().numpy().astype(np.float64) / scale ** 2, refv[c]) < (tol if np.dtype(Z) == np.float64 else 2e-5), c
+
+
+@pytest.mark.parametrize("Z,dims,M,sigma,kname", [(np.float64, (31, 20, 17), 4, 1.5, "BackwardsKaiserBesselKernel"),
+                                                 (np.float32, (35, 24), 5, 1.25, "KaiserBesselKernel"),
+                                                 (np.complex128, (33, 20), 6, 2.0, "GaussianKernel"),
+                                                 (np.float64, (64, 64, 64), 4, 2.0, "BackwardsKaiserBesselKernel")])
+def test_forwarded_kernel_data_reproduces_the_plan(Z, dims, M, sigma, kname):
+    """What the Julia extension sends (julia/ext/NonuniformFFTsMI355XExt.jl `ensure_handle!`): the oversampled sizes and the shape
+    parameter per dimension as the reference's plan holds them (`N_over`, `kernel_param_dim`), and N1 = 2 (L - 1) for real data
+    whatever the parity of N1.  The plan built from them transforms exactly like the plan built from (Ns, σ, kernel)."""
+    nufft = _nufft()
+    Z = np.dtype(Z)
+    D = len(dims)
+    kcls = getattr(nufft, kname)
+    p = nufft.PlanNUFFT(Z, dims, m=M, sigma=sigma, kernel=kcls(), backend=nufft.ROCBackend(0))
+    info = p.info()
+    Ls = [int(info.N_out[d]) for d in range(D)]
+    sent = tuple((2 * (Ls[0] - 1) if (Z.kind == "f" and d == 0) else Ls[d]) for d in range(D))
+    q = nufft.PlanNUFFT(Z, sent, m=M, sigma=float(info.sigma), kernel=kcls(), backend=nufft.ROCBackend(0),
+                        kernel_param_dim=[info.beta[d] for d in range(D)], oversampled_dims=[int(info.N_over[d]) for d in range(D)])
+    assert q.shape == p.shape and q.oversampled_dims == p.oversampled_dims
+    rng = np.random.default_rng(7)
+    Np = 3000
+    T = plan_real_dtype(Z)
+    xs = tuple(torch.from_numpy((rng.random(Np) * O.TWO_PI).astype(T)).cuda() for _ in dims)
+    v = rng.standard_normal(Np) + (1j * rng.standard_normal(Np) if Z.kind == "c" else 0)
+    v = torch.from_numpy(v.astype(Z)).cuda()
+    outs = []
+    for plan in (p, q):
+        nufft.set_points(plan, xs)
+        u = torch.empty(plan.shape, dtype=plan.eltype, device="cuda")
+        nufft.exec_type1(u, plan, v)
+        w = torch.empty(Np, dtype=v.dtype, device="cuda")
+        nufft.exec_type2(w, plan, u)
+        outs.append((u.cpu().numpy(), w.cpu().numpy()))
+    tol = 1e-13 if T == np.float64 else 1e-6          # summation order of the atomics only
+    assert _rel(outs[1][0], outs[0][0]) < tol and _rel(outs[1][1], outs[0][1]) < tol
+
+
+def test_halo_side_buffer_allocation_failure_keeps_the_ring(monkeypatch):
+    """when the side buffer (half a grid per component) cannot be allocated the plan keeps the ring with clipped
+    columns instead of failing (NUFFT_TEST_HALO_ALLOC_FAIL simulates the failure)."""
+    monkeypatch.setenv("NUFFT_TEST_HALO_ALLOC_FAIL", "1")
+    dims, Np = (48, 48, 56), 3000
+    nufft, plan, oplan, xs, vs = _make_case(np.float64, dims, 4, 2.0, O.DIRECT, 1, Np, seed=99, spread_method="marching_ring")
+    assert plan.info().spread_method == 3 and plan.info().ring_halo == 0
+    dev = plan.device
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    O.set_points(oplan, xs)
+    u = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    nufft.exec_type1(u, plan, torch.from_numpy(vs[0]).to(dev))
+    assert plan.spread_engine_used() == "marching_ring"
+    assert _rel(u.cpu().numpy(), O.exec_type1(oplan, vs[0])) < 1e-7
+
+
 @pytest.mark.parametrize("Z,C", [(np.float64, 1), (np.float64, 3), (np.float32, 2), (np.complex128, 1)])
 def test_spreading_ring_automatic_choice_and_fallback(Z, C, monkeypatch):
     """Automatic engine choice on a grid with enough columns for the chip (256 x 256 x 64 oversampled): real plans at M = 4

@@ -28,7 +28,7 @@ def test_library_exports_every_symbol_in_the_header(nufft):
     raw = C.CDLL(nufft.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert nufft.lib.nufft_version() == 102
+    assert nufft.lib.nufft_version() == 103
     assert b"success" in nufft.lib.nufft_strerror(0)
 
 
@@ -104,6 +104,58 @@ def test_host_plan_math_of_the_other_kernels(nufft, Z, kname, kid, param):
             assert np.max(np.abs(cs - o.coefs[d])) < 1e-12 * np.max(np.abs(o.coefs[d]))
         peak = {O.KERNEL_BKB: np.sinh(o.betas[d]) / np.pi, O.KERNEL_KB: float(np.i0(o.betas[d]))}.get(kid, 1.0)
         assert 0.5 <= peak * 2.0 ** info.window_scale_log2[d] <= 2.0
+
+
+FORWARD_CASES = [
+    (np.float64, (31, 20, 17), 4, 1.5, "BackwardsKaiserBesselKernel", None),      # odd N1 of a real plan: only N1 ÷ 2 + 1 survives in the plan
+    (np.float64, (30, 20, 17), 4, 1.5, "BackwardsKaiserBesselKernel", None),
+    (np.float32, (35, 24), 5, 1.25, "KaiserBesselKernel", None),
+    (np.complex128, (33, 20), 6, 2.0, "GaussianKernel", None),
+    (np.complex64, (18, 27), 3, 2.0, "GaussianKernel", 0.9),
+    (np.float64, (41,), 2, 2.0, "BSplineKernel", None),
+    (np.complex128, (24, 25, 26), 4, 1.3, "BackwardsKaiserBesselKernel", 11.5),
+]
+
+
+@pytest.mark.parametrize("Z,dims,M,sigma,kname,param", FORWARD_CASES)
+def test_plan_from_forwarded_kernel_data_is_identical(nufft, Z, dims, M, sigma, kname, param):
+    """What julia/ext/NonuniformFFTsMI355XExt.jl sends: gridsize(p.kernels[d]) and the shape parameter of p.kernels[d] per dimension
+    (`N_over`, `kernel_param_dim`), and for real data N1 = 2 (L - 1) whatever the parity of the plan's N1.  The plan built from them
+    has the same oversampled sizes, shape parameters, Fourier coefficients, polynomial coefficients and index maps, bit for bit."""
+    Z = np.dtype(Z)
+    kcls = getattr(nufft, kname)
+    kernel = kcls() if param is None else kcls(param)
+    p = nufft.PlanNUFFT(Z, dims, m=M, sigma=sigma, kernel=kernel, backend=None)
+    info = p.info()
+    D = len(dims)
+    Ls = [int(info.N_out[d]) for d in range(D)]
+    sent = tuple((max(1, 2 * (Ls[0] - 1)) if (Z.kind == "f" and d == 0) else Ls[d]) for d in range(D))
+    q = nufft.PlanNUFFT(Z, sent, m=M, sigma=float(info.sigma), kernel=kcls(), backend=None,
+                        kernel_param_dim=[info.beta[d] for d in range(D)], oversampled_dims=[int(info.N_over[d]) for d in range(D)])
+    qi = q.info()
+    assert q.oversampled_dims == p.oversampled_dims and q.size == p.size
+    for d in range(D):
+        assert qi.beta[d] == info.beta[d] and qi.window_scale_log2[d] == info.window_scale_log2[d]
+        assert np.array_equal(q.fourier_coefficients(d), p.fourier_coefficients(d))
+        assert np.array_equal(q.polynomial_coefficients(d), p.polynomial_coefficients(d))
+        assert np.array_equal(q.index_map(d), p.index_map(d))
+    # tiles and engines follow from the oversampled sizes: the same plan geometry
+    for name in ("bin_dims", "nbins", "spread_tile", "interp_tile"):
+        assert list(getattr(qi, name)) == list(getattr(info, name)), name
+    assert qi.spread_method == info.spread_method
+
+
+def test_forwarded_kernel_data_argument_errors(nufft):
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.float64, (16, 16), oversampled_dims=(33, 32), backend=None)         # odd along dimension 1 of a real plan
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.complex128, (16, 16), oversampled_dims=(12, 32), backend=None)      # smaller than N
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.float64, (16,), kernel=nufft.BSplineKernel(), kernel_param_dim=(1.0,), backend=None)
+    with pytest.raises(ValueError):
+        nufft.PlanNUFFT(np.float64, (16,), kernel_param_dim=(-1.0,), backend=None)
+    q = nufft.PlanNUFFT(np.float64, (16, 12), gpu_method="global_memory", backend=None)        # NUFFT_METHOD_GLOBAL_MEMORY: accepted
+    assert q.gpu_method == "global_memory"
 
 
 def test_kernel_argument_errors(nufft):
