@@ -62,9 +62,10 @@ def parse():
     ap.add_argument("--np", type=float, default=0, help="override: non-uniform points per GPU")
     ap.add_argument("--m", type=int, default=0)
     ap.add_argument("--sigma", type=float, default=0)
-    ap.add_argument("--evalmode", default="fast", choices=["direct", "fast"],
-                    help="window evaluation of the top-level value (default: FastApproximation, as in round 1's line; the other "
-                         "mode is measured too and reported as an equally complete sibling record)")
+    ap.add_argument("--evalmode", default="direct", choices=["direct", "fast"],
+                    help="window evaluation of the top-level value (default: Direct(), the reference's default on ROCBackend, "
+                         "ext/NonuniformFFTsAMDGPUExt.jl:56 — since round 5; rounds 1-4 led with FastApproximation; the other mode is "
+                         "measured too and reported as an equally complete sibling record, and as config.fast_value / config.direct_value)")
     ap.add_argument("--only-headline", action="store_true", help="skip the sibling evaluation mode, the reference "
                     "protocol, the density sweep, the HBM probe and the CPU baseline (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,8 +121,43 @@ def pmc_traffic(kernel_substr, config):
             continue
         for name, v in ks.items():
             if kernel_substr in name:
-                return float(v["hbm_bytes_per_launch"]), os.path.basename(f)
-    return None, None
+                return float(v["hbm_bytes_per_launch"]), os.path.basename(f), v.get("kernel_avg_us")
+    return None, None, None
+
+
+def sq_counters(kernel_substr, config):
+    """SQ counters per launch of a kernel from the newest committed profiles/*_sq.json of this configuration (written by
+    scripts/summarize_profile.py from the SQ passes of scripts/profile_bench.sh), with the derived figures that name the binding
+    resource; None if no such profile is committed.  Nothing here is typed in by hand."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")) if f"_{config}_" in os.path.basename(f) or f"_{config}." in os.path.basename(f))
+    for f in reversed(files):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        for name, v in ks.items():
+            if kernel_substr in name:
+                d = {"source": os.path.basename(f), "kernel": name, "counters": v}
+                busy = v.get("SQ_BUSY_CYCLES")
+                if busy:
+                    # SQ_BUSY_CYCLES counts per shader engine (x4 per XCD quadrant on gfx950): ratios between SQ counters of one
+                    # pass are what is meaningful; report instruction mix and active / wait shares of the wave cycles
+                    pass
+                wc = v.get("SQ_WAVE_CYCLES")
+                if wc:
+                    for key, label in (("SQ_ACTIVE_INST_VALU", "valu_active_share_of_wave_cycles"), ("SQ_ACTIVE_INST_LDS", "lds_active_share_of_wave_cycles"),
+                                       ("SQ_WAIT_INST_LDS", "wait_lds_share_of_wave_cycles")):
+                        if key in v:
+                            d[label] = v[key] / wc
+                if v.get("SQ_LDS_IDX_ACTIVE"):
+                    d["lds_bank_conflict_share_of_lds_active"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"]
+                if v.get("SQ_WAVES") and v.get("SQ_INSTS_LDS") is not None:
+                    d["lds_instructions_per_wave"] = v["SQ_INSTS_LDS"] / v["SQ_WAVES"]
+                if v.get("SQ_WAVES") and v.get("SQ_INSTS_VALU") is not None:
+                    d["valu_instructions_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+                return d
+    return None
 
 
 def launch_ranks(a):
@@ -386,6 +422,7 @@ def main():
             "workspace_bytes": int(plan.info().workspace_bytes),       # plan-owned device memory with this point set in place
             "ring_column": [int(info.ring_column[0]), int(info.ring_column[1])], "ring_segments": int(info.ring_segments),
             "ring_halo": int(info.ring_halo), "fft_plain_ms": fft_plain_ms,
+            "sort_columns": bool(plan.sort_columns_used()), "sort_column_bins": [int(info.sort_column[0]), int(info.sort_column[1])],
             "spread_engine": engine_used, "patch_f32acc": int(info.patch_f32acc), "patch_dims": [int(info.patch_dims[0]), int(info.patch_dims[1])], "patch_planar": int(info.patch_planar),
             "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
             "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
@@ -435,7 +472,9 @@ def main():
         n1c, n2c, mm = head["ring_column"][0], head["ring_column"][1], cfg["m"]
         xr, yr = (mm - 1) + ((mm - 1) & 1) + mm, 2 * mm - 1
         ab["spread_kernel_min"] += Cn * ab["G"] * ((n1c + xr) * (n2c + yr) / float(n1c * n2c) - 1.0)
-    traffic_b, traffic_src = pmc_traffic(kname, a.config)
+    traffic_b, traffic_src, profile_us = pmc_traffic(kname, a.config)
+    sq = sq_counters(kname, a.config)
+    interp_kname = "interp_march_staged_kernel" if head.get("sort_columns") else "interp_march_kernel"
     probe = hbm_probe(dev) if full else None
     peak_m = probe["peak_measured_GBs"] if probe else None
     achieved = ab["spread_kernel"] / spread_s / 1e9
@@ -446,7 +485,13 @@ def main():
         "peak_measured": peak_m, "frac_of_measured_peak": (achieved / peak_m) if peak_m else None,
         "traffic": (traffic_b / 1e9) if traffic_b is not None else None,
         "traffic_unit": "GB per launch = per stage (PMC FETCH_SIZE x2 + WRITE_SIZE; one launch covers the C components)", "traffic_source": traffic_src,
+        # what binds the kernel: the design note, and — where a counter profile of this configuration is committed — the
+        # SQ counters it rests on, read from profiles/*_sq.json (not typed in here)
         "binding_resource": binding,
+        "binding_resource_counters": sq if sq is not None else "no SQ counter profile of this configuration is committed (scripts/profile_bench.sh)",
+        # the profile the traffic figure comes from: its average duration of this kernel, and whether this run agrees with it
+        "profile_kernel_us": profile_us,
+        "profile_matches_run": (abs(profile_us / 1e3 - st1["spread"] / (Cn if head["spread_engine"] == "mfma_patches" and not head["patch_planar"] else 1)) < 0.1 * st1["spread"]) if profile_us else None,
         "algorithmic_bytes_per_stage": ab["spread_kernel"],
         "algorithmic_bytes_note": "SURVEY 8(d): zero + spread = 3G + P per component (what the reference's algorithm moves); the "
                                   "kernel's own compulsory traffic is G + P (every cell written once, no zero fill): achieved_own_traffic",
@@ -460,7 +505,10 @@ def main():
         "frac_incl_consumer": ab["spread_kernel"] / (spread_s + halo_extra_s) / 1e9 / HBM_PEAK_GBS,
         "interp": {"kernel_ms": st2["interp"], "algorithmic_bytes_per_stage": ab["interp_kernel"],
                    "achieved": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9, "frac": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "traffic": (lambda t: t[0] / 1e9 if t[0] is not None else None)(pmc_traffic("interp_march_kernel", a.config)),
+                   "kernel": interp_kname,
+                   "traffic": (lambda t: t[0] / 1e9 if t[0] is not None else None)(pmc_traffic(interp_kname, a.config)),
+                   "profile_kernel_us": pmc_traffic(interp_kname, a.config)[2],
+                   "binding_resource_counters": sq_counters(interp_kname, a.config),
                    "note": "type-2 gather stage (R(G) + R(points) + W(values)); z-marching LDS ring where the point set is not sliced"},
         "type1_exec_frac": ab["type1_exec"] / (exec1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "type2_exec_frac": ab["type2_exec"] / (exec2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -470,7 +518,8 @@ def main():
     }
     tname_z = {"float64": "Float64", "float32": "Float32", "complex64": "ComplexF32", "complex128": "ComplexF64"}[cfg["Z"]]
     result = {
-        "metric": f"NU-points/s, type-1 NUFFT (set_points! + exec_type1!), {cfg['n']}^3 {tname_z} m={cfg['m']}",
+        "metric": f"NU-points/s, type-1 NUFFT (set_points! + exec_type1!), {cfg['n']}^3 {tname_z} m={cfg['m']}, {head['evalmode']}() window"
+                  + (" (the reference's ROCBackend default)" if head["evalmode"] == "Direct" else ""),
         "value": head["value"],
         "unit": "NU-points/s",
         "n_gpus": world,
@@ -489,6 +538,9 @@ def main():
             "protocol": "set_points! + exec_type1! per step, inputs resident in HBM (reference benchmark protocol)",
             "spread_engine": head["spread_engine"], "spread_tile": head["spread_tile"], "interp_tile": head["interp_tile"],
             "ring_column": head["ring_column"], "ring_segments": head["ring_segments"], "ring_halo": head["ring_halo"], "workspace_bytes": head["workspace_bytes"],
+            "sort_columns": head["sort_columns"], "sort_column_bins": head["sort_column_bins"],
+            "set_points_ms": st1["set_points"], "spread_ms": st1["spread"], "fft_ms": st1["fft"], "deconv_ms": st1["deconv"], "interp_ms": st2["interp"],
+            "type2_value": head["type2"]["with_set_points_pts_per_s"],
             "parallelism": (f"ntransforms = {C_total} components of one transform sharded over {world} GPU(s) (component c on rank c mod N, same points)"
                             if P_sharded else f"{world} independent plan(s), one per GPU")
                            + ("" if not distributed or a.no_gather else "; RCCL gather of spectra to rank 0 overlapped on a side stream"),
@@ -509,6 +561,11 @@ def main():
     if direct_rec is not None:
         result["config"]["direct_value"] = direct_rec["value"]
         result["config"]["direct_ms_per_step"] = direct_rec["ms_per_step"]
+    fast_rec = head if head["evalmode"] == "FastApproximation" else other
+    if fast_rec is not None:
+        result["config"]["fast_value"] = fast_rec["value"]
+        result["config"]["fast_ms_per_step"] = fast_rec["ms_per_step"]
+        result["config"]["fast_type2_value"] = fast_rec["type2"]["with_set_points_pts_per_s"]
     if full and a.config == "c2" and not a.no_other_configs:
         del P
         torch.cuda.empty_cache()
@@ -517,7 +574,9 @@ def main():
             try:
                 oc = dict(CONFIGS[name])
                 Po = prepare(oc)
-                r = measure(Po, a.evalmode, 3, False)
+                # (polynomial window as in rounds 1-4, so that these records stay comparable; the Direct() value beside it)
+                r = measure(Po, "fast", 3, False)
+                rd = measure(Po, "direct", 3, False)
                 abo = algorithmic_bytes(Po["Np"], r["oversampled"], r["size"], Po["is_complex"], Po["real_bytes"], Po["Cn"])
                 sp_ms, ip_ms = r["type1"]["stages_ms"]["spread"], r["type2"]["stages_ms"]["interp"]
                 others[name] = {
@@ -530,6 +589,9 @@ def main():
                     "roofline_frac_own_traffic": abo["spread_kernel_min"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "interp_roofline_frac": abo["interp_kernel"] / (ip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "workspace_bytes": r["workspace_bytes"],
+                    "set_points_ms": r["type1"]["stages_ms"]["set_points"], "sort_columns": r["sort_columns"],
+                    "direct_value": rd["value"], "direct_type2_value": rd["type2"]["with_set_points_pts_per_s"],
+                    "direct_spread_ms": rd["type1"]["stages_ms"]["spread"], "direct_interp_ms": rd["type2"]["stages_ms"]["interp"],
                 }
                 if name == "c3":
                     # C3 is bound by arithmetic, not HBM: (2M)^3 multiply-adds per point and component on the FP32 pipes
@@ -554,7 +616,7 @@ def main():
                 result["config"][f"{name}_error"] = r["error"]
                 continue
             for k in ("value", "ms_per_step", "type2_value", "type2_ms_per_step", "spread_ms", "interp_ms", "spread_engine", "roofline_frac",
-                      "ring_halo", "fft_ms", "fft_plain_ms",
+                      "ring_halo", "fft_ms", "fft_plain_ms", "set_points_ms", "sort_columns", "direct_value", "direct_type2_value", "direct_spread_ms", "direct_interp_ms",
                       "roofline_frac_own_traffic", "interp_roofline_frac", "workspace_bytes", "fp32_achieved_tflops", "fp32_frac",
                       "interp_fp32_achieved_tflops", "interp_fp32_frac"):
                 if k in r:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NUFFT_MI355X_VERSION 103 /* 0.1.3: nufft_params grew (kernel_param_dim, N_over: what a binding that already holds the reference's
+#define NUFFT_MI355X_VERSION 103 /* 0.1.3: nufft_params grew (kernel_param_dim, N_over; nufft_info: sort_column: what a binding that already holds the reference's
                                     per-dimension kernel data forwards verbatim), NUFFT_METHOD_GLOBAL_MEMORY accepted, nufft_copy_grid
                                     takes a non-const plan since 102;
                                     0.1.2: nufft_spread_deferred added, nufft_info.reserved_info became ring_halo (same layout) since 101;
@@ -165,6 +165,9 @@ typedef struct nufft_info {
     int32_t ring_segments;   /* marching ring: segments a column is cut into along dimension 3 for uniform point sets  */
     int32_t ring_halo;       /* marching ring: 1 = halo variant (every point spread once by its own column; the stencil reach
                                 travels through a side buffer that the first FFT pass adds), 0 = clipped columns          */
+    int32_t sort_column[2];  /* plans whose spreading window (halo variant) and interpolation ring own the same columns: bins of a column
+                                along dimensions 1, 2 — set_points then groups the points by (column, layer of bins) only, unless a
+                                ring hands the point set to the tile kernels (nufft_sort_columns_used); 0: always the fine bins   */
 } nufft_info;
 
 /* ---- plan lifetime -------------------------------------------------------------------- */
@@ -273,6 +276,11 @@ int nufft_copy_grid(nufft_plan* plan, int which, int component, void* dst, int64
  * (cumulative_npoints_per_block, :13) to HOST buffers.  Synchronises `stream`. */
 int nufft_get_sort_result(nufft_plan* plan, int32_t* perm_host, int64_t perm_capacity,
                           uint32_t* tile_offsets_host, int64_t offsets_capacity, void* stream);
+
+/* Which sort the last nufft_set_points used: 1 = by column layers (nufft_info.sort_column; the offsets returned by
+ * nufft_get_sort_result then hold a column layer's points in its first bin and nothing in its other bins), 0 = by fine bins.
+ * Reads two device flags back (synchronises `stream`).  Inspection only. */
+int nufft_sort_columns_used(nufft_plan* plan, int* used_out, void* stream);
 
 /* ---- timing (TimerOutputs analogue, src/plan.jl:397-417) -------------------------------- */
 

@@ -70,6 +70,7 @@ class NufftInfo(C.Structure):
         ("spread_max_items", C.c_int32), ("interp_max_items", C.c_int32), ("spread_method", C.c_int32),
         ("patch_dims", C.c_int32 * 2), ("patch_f32acc", C.c_int32), ("patch_planar", C.c_int32),
         ("ring_column", C.c_int32 * 2), ("ring_segments", C.c_int32), ("ring_halo", C.c_int32),
+        ("sort_column", C.c_int32 * 2),
     ]
 
 
@@ -102,6 +103,7 @@ SYMBOLS = {
     "nufft_grid_ptr": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "nufft_copy_grid": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "nufft_get_sort_result": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_uint32), C.c_int64, _P]),
+    "nufft_sort_columns_used": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "nufft_set_timing": (C.c_int, [_P, C.c_int]),
     "nufft_get_stage_times": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "nufft_spread_engine_used": (C.c_int, [_P, C.POINTER(C.c_int), _P]),

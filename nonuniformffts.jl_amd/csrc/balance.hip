@@ -26,7 +26,8 @@ namespace nufft {
 constexpr int kWorkLanes = 16;
 
 __global__ __launch_bounds__(256) void tile_work_kernel(Geom g, int D, int M, const uint32_t* __restrict__ offsets,
-                                                       uint32_t* __restrict__ work) {
+                                                       uint32_t* __restrict__ work, const uint32_t* skip_a, const uint32_t* skip_b) {
+    if (skip_a && *skip_a != 0u && *skip_b != 0u) return;      // column-layer sorted point set: both rings serve it
     const int nsp = g.sp.ntiles, nip = g.ip.ntiles;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWorkLanes;      // (the tile of this group of lanes)
     const int lane = threadIdx.x & (kWorkLanes - 1);
@@ -71,8 +72,9 @@ __global__ __launch_bounds__(256) void tile_work_kernel(Geom g, int D, int M, co
 constexpr int kSumBlocks = 128;
 
 __global__ __launch_bounds__(256) void tile_work_sums_kernel(const uint32_t* __restrict__ work, int nsp, int nip,
-                                                            unsigned long long* __restrict__ part) {
+                                                            unsigned long long* __restrict__ part, const uint32_t* skip_a, const uint32_t* skip_b) {
     __shared__ unsigned long long wsum[2][256 / kWave];
+    if (skip_a && *skip_a != 0u && *skip_b != 0u) return;
     const int tid = threadIdx.x, n = nsp + nip;
     unsigned long long acc[2] = {0ull, 0ull};
     for (int t = blockIdx.x * blockDim.x + tid; t < n; t += gridDim.x * blockDim.x) acc[t >= nsp ? 1 : 0] += work[t];
@@ -92,8 +94,13 @@ __global__ __launch_bounds__(256) void tile_work_sums_kernel(const uint32_t* __r
 __global__ __launch_bounds__(256) void tile_slices_kernel(const uint32_t* __restrict__ work, int nsp, int nip,
                                                          uint32_t extra_sp, uint32_t extra_ip, uint32_t smax,
                                                          const unsigned long long* __restrict__ part,
-                                                         uint32_t* __restrict__ nslices) {
+                                                         uint32_t* __restrict__ nslices, const uint32_t* skip_a, const uint32_t* skip_b) {
     __shared__ unsigned long long tot[2];
+    if (skip_a && *skip_a != 0u && *skip_b != 0u) {      // no tile kernel will run: one slice per tile (nothing for zero_split_tiles to clear)
+        const int t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < nsp + nip) nslices[t] = 1u;
+        return;
+    }
     const int tid = threadIdx.x, n = nsp + nip;
     if (tid < 2 * kWave) {                              // waves 0, 1: total work of the spreading / interpolation tiling
         const int k = tid / kWave, lane = tid & (kWave - 1);
@@ -118,9 +125,14 @@ __global__ __launch_bounds__(256) void tile_slices_kernel(const uint32_t* __rest
 __global__ __launch_bounds__(256) void fill_desc_kernel(const uint32_t* __restrict__ nslices,
                                                        const uint32_t* __restrict__ desc_off, int nsp, int nip,
                                                        uint32_t ip_base, uint2* __restrict__ desc,
-                                                       uint32_t* __restrict__ slots_in_use) {
+                                                       uint32_t* __restrict__ slots_in_use, const uint32_t* skip_a, const uint32_t* skip_b,
+                                                       const uint32_t* sp_served) {
     constexpr int kLanes = 8;                            // lanes per tile (most tiles have one slice)
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) / kLanes, lane = threadIdx.x & (kLanes - 1);
+    if (skip_a && *skip_a != 0u && *skip_b != 0u) {      // both rings serve this point set: no slots for the tile kernels
+        if (blockIdx.x == 0 && threadIdx.x < 2) slots_in_use[threadIdx.x] = 0u;
+        return;
+    }
     if (t >= nsp + nip) return;
     const uint32_t split = desc_off[nsp];
     const bool interp = t >= nsp;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) void fill_desc_kernel(const uint32_t* __restri
     const uint32_t tile = interp ? (uint32_t)(t - nsp) : (uint32_t)t;
     for (uint32_t s = lane; s < S; s += kLanes) desc[off + s] = make_uint2(tile, (s << 16) | S);
     if (t == 0 && lane == 0) {
-        slots_in_use[0] = split;
+        slots_in_use[0] = (sp_served && *sp_served != 0u) ? 0u : split;      // (a ring spreads this point set: the tile kernel finds no work)
         slots_in_use[1] = desc_off[nsp + nip] - split;
     }
 }
@@ -150,17 +162,17 @@ hipError_t launch_balance(const BalanceArgs& b, hipStream_t stream) {
     const int nsp = b.g.sp.ntiles, nip = b.g.ip.ntiles, n = nsp + nip;
     const int waves_per_block = 256 / kWorkLanes;
     hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)((n + waves_per_block - 1) / waves_per_block)), dim3(256), 0, stream,
-                       b.g, b.D, b.M, b.offsets, b.work);
+                       b.g, b.D, b.M, b.offsets, b.work, b.skip_a, b.skip_b);
     // (the partial sums live behind the n + 1 work counters: balance_work_words())
     unsigned long long* part = reinterpret_cast<unsigned long long*>(b.work + balance_work_words(n) - 4 * kSumBlocks);
-    hipLaunchKernelGGL(tile_work_sums_kernel, dim3(kSumBlocks), dim3(256), 0, stream, b.work, nsp, nip, part);
+    hipLaunchKernelGGL(tile_work_sums_kernel, dim3(kSumBlocks), dim3(256), 0, stream, b.work, nsp, nip, part, b.skip_a, b.skip_b);
     hipLaunchKernelGGL(tile_slices_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, b.work, nsp, nip,
-                       b.enabled ? b.extra_sp : 0u, b.enabled ? b.extra_ip : 0u, b.smax, part, b.nslices);
+                       b.enabled ? b.extra_sp : 0u, b.enabled ? b.extra_ip : 0u, b.smax, part, b.nslices, b.skip_a, b.skip_b);
     size_t tmp = b.scan_tmp_bytes;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(b.scan_tmp, tmp, b.nslices, b.desc_off, n + 1, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fill_desc_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, b.nslices, b.desc_off, nsp, nip,
-                       (uint32_t)nsp + b.extra_sp, b.desc, b.slots_in_use);
+                       (uint32_t)nsp + b.extra_sp, b.desc, b.slots_in_use, b.skip_a, b.skip_b, b.sp_served);
     return hipGetLastError();
 }
 

@@ -54,8 +54,9 @@ constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 
 template <typename T, int D>
 __global__ __launch_bounds__(kCountThreads) void bin_count_kernel(BinArgs<T, D> a, uint32_t* __restrict__ counts,
-                                                                 uint2* __restrict__ binrank) {
+                                                                 uint2* __restrict__ binrank, const uint32_t* skip_a, const uint32_t* skip_b) {
     __shared__ uint32_t keys[kCountSlots], cnt[kCountSlots], base[kCountSlots];
+    if (skip_a && *skip_a != 0u && *skip_b != 0u) return;      // this point set is column-layer sorted (CoarseSort)
     constexpr int kChunkPts = kCountThreads * kCountPPT;
     const int tid = threadIdx.x;
     const int64_t nchunks = (a.np + kChunkPts - 1) / kChunkPts;
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(kCountThreads) void bin_count_kernel(BinArgs<T, D> 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs<T, D> a, const uint32_t* __restrict__ offsets,
                                                          const uint2* __restrict__ binrank,
-                                                         PointRec<T, D>* __restrict__ sorted, uint32_t* __restrict__ counts, int ncounts) {
+                                                         PointRec<T, D>* __restrict__ sorted, uint32_t* __restrict__ counts, int ncounts,
+                                                         const uint32_t* skip_a, const uint32_t* skip_b) {
+    if (skip_a && *skip_a != 0u && *skip_b != 0u) return;      // this point set is column-layer sorted (CoarseSort)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // the histogram has been scanned into `offsets`: clear it for the next set_points (saves that call's zero-fill launch)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncounts; i += stride) counts[i] = 0u;
@@ -152,7 +155,7 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
         int64_t blocks = (s.np + kCountThreads * kCountPPT - 1) / (kCountThreads * kCountPPT);
         if (blocks > 256 * 16) blocks = 256 * 16;
         hipLaunchKernelGGL((bin_count_kernel<T, D>), dim3((unsigned)blocks), dim3(kCountThreads), 0, stream, a, s.counts,
-                           static_cast<uint2*>(s.binrank));
+                           static_cast<uint2*>(s.binrank), (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     size_t tmp = s.scan_tmp_bytes;
     e = hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.nbins + 1, stream);
@@ -162,9 +165,207 @@ static hipError_t run_binsort(const SortArgs& s, hipStream_t stream) {
         int64_t blocks = (s.np + threads - 1) / threads;
         if (blocks > 256 * 32) blocks = 256 * 32;
         hipLaunchKernelGGL((bin_scatter_kernel<T, D>), dim3((unsigned)blocks), dim3(threads), 0, stream, a, s.offsets,
-                           static_cast<const uint2*>(s.binrank), static_cast<PointRec<T, D>*>(s.sorted), s.counts, s.g.nbins + 1);
+                           static_cast<const uint2*>(s.binrank), static_cast<PointRec<T, D>*>(s.sorted), s.counts, s.g.nbins + 1,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     return hipGetLastError();
+}
+
+// ---- column-layer sort (CoarseSort, kernels.h) -------------------------------------------------------------------------------
+struct CoarseGeom {
+    int cbx, cby, ncx, ncy, nkeys;
+};
+constexpr int kCoarseThreads = 1024;
+
+template <typename T>
+__device__ __forceinline__ uint32_t coarse_key(const BinArgs<T, 3>& a, const CoarseGeom& c, int64_t p, T (&r)[3]) {
+    int b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const T xf = transform_and_fold(a.x[d][p], a.point_transform);
+        r[d] = to_grid_units(xf, a.g.Nover[d]);
+        b[d] = cell_of(r[d], a.g.Nover[d]) >> a.g.blog[d];
+    }
+    return (uint32_t)((b[2] * c.ncy + b[1] / c.cby) * c.ncx + b[0] / c.cbx);
+}
+// first fine bin of a column layer: where its total sits in the fake fine histogram
+__device__ __forceinline__ int64_t coarse_rep_bin(const Geom& g, const CoarseGeom& c, int k) {
+    const int cx = k % c.ncx, t = k / c.ncx, cy = t % c.ncy, bz = t / c.ncy;
+    return ((int64_t)bz * g.nb[1] + cy * c.cby) * g.nb[0] + cx * c.cbx;
+}
+// slice of the point set that workgroup w counts and later scatters
+__device__ __forceinline__ void coarse_slice(int64_t np, int groups, int w, int64_t& lo, int64_t& hi) {
+    int64_t per = (np + groups - 1) / groups;
+    per = (per + kCoarseThreads - 1) / kCoarseThreads * kCoarseThreads;
+    lo = per * w < np ? per * w : np;
+    hi = lo + per < np ? lo + per : np;
+}
+
+// pass 1: histogram of the slice in LDS (one 32-bit counter per key), written out as one coalesced row of the table
+template <typename T>
+__global__ __launch_bounds__(kCoarseThreads) void coarse_count_kernel(BinArgs<T, 3> a, CoarseGeom c, uint32_t* __restrict__ table) {
+    extern __shared__ uint32_t hist[];
+    const int tid = threadIdx.x, w = blockIdx.x;
+    for (int k = tid; k < c.nkeys; k += kCoarseThreads) hist[k] = 0u;
+    __syncthreads();
+    int64_t lo, hi;
+    coarse_slice(a.np, (int)gridDim.x, w, lo, hi);
+    for (int64_t p0 = lo; p0 < hi; p0 += 4 * kCoarseThreads) {
+        uint32_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + u * kCoarseThreads + tid;
+            T r[3];
+            key[u] = p < hi ? coarse_key<T>(a, c, p, r) : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (key[u] != 0xffffffffu) atomicAdd(&hist[key[u]], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)w * c.nkeys;
+    for (int k = tid; k < c.nkeys; k += kCoarseThreads) row[k] = hist[k];
+}
+
+// per key: exclusive prefix over the slices (in place), and the key's total into the fake fine histogram
+__global__ __launch_bounds__(64) void coarse_prefix_kernel(Geom g, CoarseGeom c, int groups, uint32_t* __restrict__ table, uint32_t* __restrict__ counts) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= c.nkeys) return;
+    uint32_t run = 0u;
+    int w = 0;
+    for (; w + 8 <= groups; w += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(w + u) * c.nkeys + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            table[(size_t)(w + u) * c.nkeys + k] = run;
+            run += v[u];
+        }
+    }
+    for (; w < groups; ++w) {
+        const uint32_t v = table[(size_t)w * c.nkeys + k];
+        table[(size_t)w * c.nkeys + k] = run;
+        run += v;
+    }
+    counts[coarse_rep_bin(g, c, k)] = run;
+}
+
+// the fine sort takes over (a ring handed the point set to the tile kernels): the fake histogram is cleared first
+__global__ __launch_bounds__(256) void coarse_clear_kernel(Geom g, CoarseGeom c, uint32_t* __restrict__ counts, const uint32_t* fa, const uint32_t* fb) {
+    if (*fa != 0u && *fb != 0u) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < c.nkeys) counts[coarse_rep_bin(g, c, k)] = 0u;
+}
+
+// pass 2: cursors of the slice in LDS (start of the column layer + what the earlier slices put there), one record store per point
+template <typename T>
+__global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(BinArgs<T, 3> a, CoarseGeom c, const uint32_t* __restrict__ table,
+                                                                       const uint32_t* __restrict__ offsets, PointRec<T, 3>* __restrict__ sorted,
+                                                                       uint32_t* __restrict__ counts, const uint32_t* fa, const uint32_t* fb) {
+    extern __shared__ uint32_t cursor[];
+    if (*fa == 0u || *fb == 0u) return;                 // fine sort
+    const int tid = threadIdx.x, w = blockIdx.x;
+    const uint32_t* row = table + (size_t)w * c.nkeys;
+    for (int k = tid; k < c.nkeys; k += kCoarseThreads) {
+        const int64_t rep = coarse_rep_bin(a.g, c, k);
+        cursor[k] = offsets[rep] + row[k];
+    }
+    __syncthreads();
+    int64_t lo, hi;
+    coarse_slice(a.np, (int)gridDim.x, w, lo, hi);
+    for (int64_t p0 = lo; p0 < hi; p0 += 2 * kCoarseThreads) {
+        PointRec<T, 3> rec[2];
+        uint32_t key[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t p = p0 + u * kCoarseThreads + tid;
+            key[u] = 0xffffffffu;
+            if (p < hi) {
+                key[u] = coarse_key<T>(a, c, p, rec[u].r);
+                rec[u].idx = (int32_t)p;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (key[u] != 0xffffffffu) sorted[atomicAdd(&cursor[key[u]], 1u)] = rec[u];
+    }
+    // the histogram has been scanned: clear it for the next set_points (only the first bins of the column layers hold anything)
+    __syncthreads();
+    for (int k = w * kCoarseThreads + tid; k < c.nkeys; k += (int)gridDim.x * kCoarseThreads) counts[coarse_rep_bin(a.g, c, k)] = 0u;
+}
+
+static CoarseGeom coarse_geom(const CoarseSort& cs) { return CoarseGeom{cs.cbx, cs.cby, cs.ncx, cs.ncy, cs.nkeys}; }
+
+template <typename T>
+static BinArgs<T, 3> bin_args3(const SortArgs& s) {
+    BinArgs<T, 3> a;
+    for (int d = 0; d < 3; ++d) a.x[d] = static_cast<const T*>(s.coords[d]);
+    a.np = s.np;
+    a.g = s.g;
+    a.point_transform = s.point_transform;
+    return a;
+}
+
+hipError_t prepare_binsort_coarse(int dtype, int nkeys) {
+    const int bytes = nkeys * 4;
+    hipError_t e;
+    if (dtype == NUFFT_F32) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_count_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_scatter_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_count_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_scatter_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
+    return e;
+}
+
+template <typename T>
+static hipError_t coarse_count_t(const SortArgs& s, hipStream_t stream) {
+    const CoarseGeom c = coarse_geom(s.cs);
+    hipError_t e = hipSuccess;
+    if (!s.counts_clean) {
+        e = launch_zero_fill(s.counts, sizeof(uint32_t) * (size_t)(s.g.nbins + 1), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((coarse_count_kernel<T>), dim3((unsigned)s.cs.groups), dim3(kCoarseThreads), (size_t)c.nkeys * 4, stream, bin_args3<T>(s), c, s.cs.table);
+    hipLaunchKernelGGL(coarse_prefix_kernel, dim3((unsigned)((c.nkeys + 63) / 64)), dim3(64), 0, stream, s.g, c, s.cs.groups, s.cs.table, s.counts);
+    size_t tmp = s.scan_tmp_bytes;
+    return hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.nbins + 1, stream);
+}
+
+template <typename T>
+static hipError_t coarse_finish_t(const SortArgs& s, hipStream_t stream) {
+    const CoarseGeom c = coarse_geom(s.cs);
+    const BinArgs<T, 3> a = bin_args3<T>(s);
+    const uint32_t *fa = s.cs.flag_a, *fb = s.cs.flag_b;
+    // fine sort, only where the flags ask for it: clear the fake histogram, count by fine bins; the scan runs either way (on the
+    // unchanged fake histogram it reproduces the offsets it already holds)
+    hipLaunchKernelGGL(coarse_clear_kernel, dim3((unsigned)((c.nkeys + 255) / 256)), dim3(256), 0, stream, s.g, c, s.counts, fa, fb);
+    if (s.np > 0) {
+        int64_t blocks = (s.np + kCountThreads * kCountPPT - 1) / (kCountThreads * kCountPPT);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL((bin_count_kernel<T, 3>), dim3((unsigned)blocks), dim3(kCountThreads), 0, stream, a, s.counts, static_cast<uint2*>(s.binrank), fa, fb);
+    }
+    size_t tmp = s.scan_tmp_bytes;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.nbins + 1, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((coarse_scatter_kernel<T>), dim3((unsigned)s.cs.groups), dim3(kCoarseThreads), (size_t)c.nkeys * 4, stream, a, c, s.cs.table, s.offsets,
+                       static_cast<PointRec<T, 3>*>(s.sorted), s.counts, fa, fb);
+    if (s.np > 0) {
+        int64_t blocks = (s.np + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL((bin_scatter_kernel<T, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, a, s.offsets, static_cast<const uint2*>(s.binrank),
+                           static_cast<PointRec<T, 3>*>(s.sorted), s.counts, s.g.nbins + 1, fa, fb);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_binsort_coarse_count(const SortArgs& s, hipStream_t stream) {
+    return s.dtype == NUFFT_F32 ? coarse_count_t<float>(s, stream) : coarse_count_t<double>(s, stream);
+}
+hipError_t launch_binsort_coarse_finish(const SortArgs& s, hipStream_t stream) {
+    return s.dtype == NUFFT_F32 ? coarse_finish_t<float>(s, stream) : coarse_finish_t<double>(s, stream);
 }
 
 size_t binsort_scan_tmp_bytes(int nbins) {

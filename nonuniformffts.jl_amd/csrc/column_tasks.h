@@ -68,4 +68,21 @@ NUFFT_HD inline int halo_record_offset(const HaloLayout& h, int lxw, int ly) {
     return ly * h.sw + (lxw < h.xlo * h.nc ? lxw : lxw - h.n1 * h.nc);
 }
 
+// Column-layer sort (binsort.hip): plans whose spreading window (halo variant) and interpolation ring own the same columns of
+// cbx x cby bins only need the points grouped by (column, layer of bins) — ncx x ncy x nb[2] keys instead of nbins fine bins: few
+// enough for a histogram per workgroup in LDS, so neither pass issues a global atomic.  The fake fine histogram it leaves in
+// `counts` (a column layer's total in its first bin, zero elsewhere) scans to offsets that present a column layer as ONE run of the
+// sorted array to every consumer that walks rows of bins.  Point sets that either ring hands to the tile kernels (device flags
+// flag_a, flag_b of set_points' task kernels) are sorted by fine bins as before.
+struct CoarseSort {
+    int enabled;
+    int cbx, cby, ncx, ncy;    // bins per column, columns
+    int nkeys;                 // ncx * ncy * nb[2] (<= kCoarseMaxKeys)
+    int groups;                // workgroups = contiguous slices of the point set (one per compute unit)
+    uint32_t* table;           // [groups][nkeys]: per-slice counts, then exclusive prefixes over the slices
+    const uint32_t* flag_a;    // both nonzero: this point set is column-layer sorted
+    const uint32_t* flag_b;
+};
+constexpr int kCoarseMaxKeys = 36864;      // 144 KiB of LDS counters
+
 }  // namespace nufft

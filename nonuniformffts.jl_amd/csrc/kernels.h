@@ -12,6 +12,7 @@ namespace nufft {
 
 // ---- bin sort (binsort.hip) ------------------------------------------------------------------
 struct SortArgs {
+    CoarseSort cs;
     int dtype, D;
     int point_transform;   // NUFFT_POINT_TRANSFORM_*
     int64_t np;
@@ -28,6 +29,11 @@ struct SortArgs {
 size_t binsort_scan_tmp_bytes(int nbins);
 size_t point_record_bytes(int dtype, int D);
 hipError_t launch_binsort(const SortArgs& s, hipStream_t stream);
+// the two halves of a set_points on a plan with CoarseSort::enabled: column-layer histogram + scan (offsets valid for the task kernels
+// that decide flag_a / flag_b), then — after those kernels — the scatter of whichever sort the flags select
+hipError_t prepare_binsort_coarse(int dtype, int nkeys);
+hipError_t launch_binsort_coarse_count(const SortArgs& s, hipStream_t stream);
+hipError_t launch_binsort_coarse_finish(const SortArgs& s, hipStream_t stream);
 // zero fill by a kernel (hipGraph-safe, see binsort.hip); dst 16-byte aligned, bytes a multiple of 4
 hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);
 hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np, int32_t* perm_dev, hipStream_t stream);
@@ -48,6 +54,9 @@ struct BalanceArgs {
     uint32_t* slots_in_use;    // [2]
     void* scan_tmp;
     size_t scan_tmp_bytes;
+    const uint32_t* skip_a;    // both nonzero: the point set is column-layer sorted and served by the two rings — no tile tables (no slots)
+    const uint32_t* skip_b;
+    const uint32_t* sp_served; // nonzero: a ring spreads this point set (no spreading slots); null: the task kernels that follow decide
 };
 size_t balance_scan_tmp_bytes(int ntiles_both);
 size_t balance_work_words(int ntiles_both);       // 32-bit words of BalanceArgs::work (tile counters + partial sums)
@@ -85,6 +94,9 @@ struct TileKernelArgs {
     int fixed_tile;            // the tile (g.ip / g.sp) equals the compile-time one (kernel variant with constant strides)
     int cubes;                 // spreading with the compile-time tile: accumulate cube by cube with the FP64 matrix instruction
     void* halo;                // marching ring, halo variant: side buffer of the stencil reach (C components, SMarchPlan::halo_reals each)
+    int coarse;                // plan of the column-layer sort (CoarseSort): point sets with both flags nonzero are sorted that way
+    const uint32_t* coarse_a;
+    const uint32_t* coarse_b;
 };
 // Compile-time interpolation tile of an instantiation: n[0..2] cells (n[0] == 0: none), n[3] = LDS row
 // stride in reals; see fixed_interp_tile().
@@ -95,6 +107,9 @@ bool spread_cubes_available(int dtype, int is_complex, int D, int M);
 // z-marching interpolation (march_kernels.h): available for this plan?  (3-D, 4-cell bins, default window evaluation)
 bool interp_march_available(int dtype, int is_complex, int D, int M, bool poly, const Geom& g, bool other);
 hipError_t prepare_interp_march(int dtype, int is_complex, int M, bool poly);
+// ... its variant for column-layer sorted point sets (same columns and tasks)
+bool interp_march_staged_available(int dtype, int is_complex, int M, bool poly);
+hipError_t prepare_interp_march_staged(int dtype, int is_complex, int M, bool poly);
 // columns (the kernel's compile-time column) and evenly cut tasks of the ring for this grid
 ColumnTasks march_column_tasks(int dtype, int is_complex, int M, bool poly, const Geom& g);
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);

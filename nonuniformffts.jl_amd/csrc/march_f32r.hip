@@ -2,4 +2,5 @@
 #define NUFFT_T float
 #define NUFFT_CPLX false
 #define NUFFT_MARCH_GETTER march_kernel_f32r
+#define NUFFT_MARCH_GETTER_STAGED march_kernel_f32r_staged
 #include "march_inst.h"

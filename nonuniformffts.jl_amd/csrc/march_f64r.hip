@@ -2,4 +2,5 @@
 #define NUFFT_T double
 #define NUFFT_CPLX false
 #define NUFFT_MARCH_GETTER march_kernel_f64r
+#define NUFFT_MARCH_GETTER_STAGED march_kernel_f64r_staged
 #include "march_inst.h"

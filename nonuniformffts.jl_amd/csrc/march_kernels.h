@@ -40,11 +40,13 @@ struct MarchGeom {
     int n1, n2;                     // spreading ring (smarch_kernels.h): the column chosen for this grid (<= its compile-time one)
     void* halo;                     // ... its halo variant: side buffer of the stencil reach (reals), component stride in reals
     int64_t halo_comp;
+    const uint32_t* coarse_a;       // interpolation ring on plans of the column-layer sort (CoarseSort, kernels.h): both nonzero = this point set
+    const uint32_t* coarse_b;       // is column-layer sorted — interp_march_staged_kernel serves it, interp_march_kernel returns (null: no such plan)
 };
 
 constexpr int kMarchMaxRows = 16;   // rows of bins of a column (n2 <= 64)
 
-template <typename T, bool CPLX, int M, bool POLY = true>
+template <typename T, bool CPLX, int M, bool POLY = true, bool STG = false>       // STG: configuration of interp_march_staged_kernel
 struct MarchCfg {
     static constexpr int NC = CPLX ? 2 : 1;
     static constexpr int L = 2 * M, HALO = L - 1;
@@ -68,6 +70,13 @@ struct MarchCfg {
 #elif defined(NUFFT_MARCH_FORCE_512)
         return 512;
 #else
+        // staged kernel, polynomial window, Float64: the 24 coefficients (48 registers) beside the prefetched planes and the record piece do
+        // not fit 128 registers — 22 spilled, reloaded in the serial section between the two barriers of a chunk: 1.67 ms at C2 against
+        // 1.26 ms for the plain kernel; 12 waves have 170 registers each
+#ifndef NUFFT_STAGED_POLY_THREADS
+#define NUFFT_STAGED_POLY_THREADS 768
+#endif
+        if (STG && POLY && sizeof(T) == 8) return NUFFT_STAGED_POLY_THREADS;
         if (!POLY) return 1024;                                 // Direct(): no spills at 128 registers in any instantiation
         if (sizeof(T) == 8) return M <= (CPLX ? 6 : 5) ? 1024 : 512;
         return 1024;                                            // Float32, ComplexF32 (m = 8: with row groups of 4, below)
@@ -146,126 +155,32 @@ struct MarchCfg {
     static constexpr int lds_bytes() { return RING_BYTES + fixed_bytes(); }
     static constexpr int NPF = (BZ * PS + THREADS - 1) / THREADS;    // prefetched reals per thread and layer
     static constexpr bool FITS = N1 > 0;                // (ComplexF64 at M = 10: not even a 4 x 4 column fits 160 KiB)
+    // STAGED variant (column-layer sorted point sets: the points of a bin layer of the column are ONE run, in no particular order):
+    // the records of the next chunk of points travel global -> registers -> LDS while the current chunk is gathered, and are put
+    // in bin order on the way (counting sort over <= 64 keys), so that the points of a wave pass share stencil rows as they do
+    // after the fine sort.  One 16-byte piece per thread; a chunk never spans layers.
+    static constexpr int REC_BYTES = (int)sizeof(PointRec<T, 3>);
+    static constexpr int PIECES = REC_BYTES / 16;
+    static constexpr int STAGE_RECS = THREADS / PIECES;
+    static constexpr int STAGE_BYTES = STAGE_RECS * REC_BYTES;          // = 16 THREADS
+    static constexpr int NBX = FITS ? N1 / 4 : 1, NBY = FITS ? N2 / 4 : 1;
+    static constexpr int key_shift(int nbx, int nby, bool for_y) {      // coarsen the bins until at most 64 keys are left
+        int sx = 0, sy = 0;
+        while (((nbx + (1 << sx) - 1) >> sx) * ((nby + (1 << sy) - 1) >> sy) > 64) { if (((nbx + (1 << sx) - 1) >> sx) >= ((nby + (1 << sy) - 1) >> sy)) ++sx; else ++sy; }
+        return for_y ? sy : sx;
+    }
+    static constexpr int KSX = key_shift(NBX, NBY, false), KSY = key_shift(NBX, NBY, true), KNX = (NBX + (1 << KSX) - 1) >> KSX;
+    static constexpr int staged_extra_bytes() { return STAGE_BYTES + 2 * 64 * 4 + 64; }
+    static constexpr int staged_lds_bytes() { return lds_bytes() + staged_extra_bytes(); }
+    static constexpr bool FITS_STAGED = FITS && staged_lds_bytes() <= 163840 - 256 && (REC_BYTES % 16 == 0);
 };
 
 // A task is a column and a segment of its bin layers (at most kSegMax) from set_points' table: segments of about equal
 // point count, or of equal length for uniform point sets (balance.hip).
 template <typename T, bool CPLX, int M, bool POLY>
 __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_march_kernel(TileArgs<T> a, MarchGeom mg) {
-    using C = MarchCfg<T, CPLX, M, POLY>;
-    constexpr int kMarchThreads = C::THREADS;
-    using GP = typename C::GP;
-    constexpr int NC = C::NC, L = C::L, RZ = C::RZ, BZ = C::BZ, RS = C::RS, PS = C::PS, P1 = C::P1, P2 = C::P2;
-    constexpr int N1 = C::N1, N2 = C::N2, NPF = C::NPF, PSP = C::PSP, ZP = C::ZP, PPW = C::PPW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    if (*mg.flag == 0u) return;                         // interp_tile_kernel serves this point set
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const Geom& g = a.g;
-    const int task = xcd_remap_chunked((int)blockIdx.x, (int)gridDim.x, a.xcd_chunk);
-    if (task >= mg.ntasks) return;
-    const int comp_id = blockIdx.y;
-    const uint2 te = mg.tasktab[task];
-    const int tx = (int)te.x % mg.ntx, ty = (int)te.x / mg.ntx;
-    const int zb0 = (int)(te.y & 0xffffu), zb1 = (int)(te.y >> 16);
-    if (zb1 <= zb0) return;                             // a task that received no layers
-    const int org1 = tx * N1, org2 = ty * N2;
-    const int neff1 = min(N1, g.Nover[0] - org1), neff2 = min(N2, g.Nover[1] - org2);
-    const int nlay = zb1 - zb0;
-    const int nrows = (neff2 + 3) >> 2;                 // rows of bins of the column
-    const int bx0 = org1 >> 2, nbx = (neff1 + 3) >> 2, by0 = org2 >> 2;
-
-    T* ring = reinterpret_cast<T*>(smem);
-    uint2* runs = reinterpret_cast<uint2*>(smem + C::RING_BYTES);                 // [layer][row] -> [p0, p1) of the sorted array
-    int* maxp = reinterpret_cast<int*>(runs + kMarchMaxRows * C::kSegMax);        // [layer] -> passes of its longest run
-    int* counter = reinterpret_cast<int*>(smem + C::RING_BYTES + C::table_bytes(C::kSegMax) - 64);   // [0] pass counter, [1] any point
-    T* strip_wave = reinterpret_cast<T*>(smem + C::RING_BYTES + C::table_bytes(C::kSegMax) + wave * C::strip_bytes());
-
-    // ---- runs of the segment, and whether it holds any point at all ----
-    if (tid < 2) counter[tid] = 0;
-    for (int i = tid; i < nlay; i += kMarchThreads) maxp[i] = 0;
-    __syncthreads();
-    {
-        int any = 0;
-        for (int i = tid; i < nlay * nrows; i += kMarchThreads) {
-            const int lay = i / nrows, row = i % nrows;
-            const int64_t bin0 = ((int64_t)(zb0 + lay) * g.nb[1] + by0 + row) * g.nb[0] + bx0;
-            const uint2 pr = make_uint2(a.offsets[bin0], a.offsets[bin0 + nbx]);
-            runs[lay * kMarchMaxRows + row] = pr;
-            any |= pr.x != pr.y;
-            atomicMax(&maxp[lay], (int)((pr.y - pr.x + PPW - 1) / PPW));
-        }
-        if (any) counter[1] = 1;
-    }
-    __syncthreads();
-    if (counter[1] == 0) return;
-
-    const T* grid = a.grid[comp_id];
-    const int zbase = 4 * zb0 - (M - 1);                // first plane of the segment's first window (may be negative)
-    const int o1 = org1 - (M - 1), o2 = org2 - (M - 1);
-
-    // lane roles: G lanes per point, lane q = (j1, component) — or j1 alone with both components per lane (PAIR)
-    constexpr bool PAIR = C::PAIR;
-    constexpr int NCL = PAIR ? 1 : NC;                  // components that have lanes of their own
-    typedef T VT2 __attribute__((ext_vector_type(2)));
-    using VT = typename std::conditional<PAIR, VT2, T>::type;      // what one lane gathers per stencil node
-    auto vfma = [](VT x, T w, VT acc) __attribute__((always_inline)) -> VT {
-        if constexpr (PAIR) return __builtin_elementwise_fma(x, VT{w, w}, acc);
-        else return fma(x, w, acc);
-    };
-    const int grp = lane / (GP::G * ZP), q = lane % GP::G;
-    const int zp = ZP > 1 ? (lane / GP::G) % ZP : 0;   // which of the point's rows: stencil planes zp, zp + ZP, ...
-    const bool lane_active = q < GP::W1;
-    const int comp = q % NCL, j1 = (q / NCL) % L;
-    T* strip = strip_wave + grp * (3 * L);
-    using WEv = WindowEval<T, NCL, 3, M, GP::G, false>;
-    WEv we;
-    const EvalArgs<T, POLY ? NUFFT_EVAL_FAST_APPROXIMATION : NUFFT_EVAL_DIRECT> am(a);       // (the instantiation fixes the evaluation mode)
-    we.init(am, q);
-    if constexpr (ZP == 2) {
-        // the second row holds the dimension-3 values with neighbouring pairs exchanged: a row broadcast from lane 2 jj
-        // then hands row 0 value 2 jj and row 1 value 2 jj + 1 — each row the weight of its own plane
-        if (zp) {
-#pragma unroll
-            for (int sl = 0; sl < WEv::NSLOT; ++sl)
-                if (we.dsel[sl] == 2) {
-                    we.jsel[sl] ^= 1;
-#pragma unroll
-                    for (int c = 0; c < WEv::NP; ++c) we.cs[sl][c] = a.coefs[(2 * WEv::NP + c) * L + we.jsel[sl]];
-                }
-        }
-    }
-    const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.sorted);
-    T* vout = a.vout[comp_id];
-    __syncthreads();
-
-    // Layer-invariant part of the plane prefetch: element e = tid + u * THREADS of the BZ new planes is real `el` of plane k; its
-    // offset inside a plane of the grid (periodic in x, y) and its place in an LDS plane never change from phase to phase — only
-    // the plane index does.  (Recomputing them per phase — two divisions and two periodic wraps per element — was 50 of the 184
-    // vector instructions per point at C3, where a layer of a 16 x 16 column holds only ~95 points, and 13 of 43 at C2.)
-    int pf_off[NPF], pf_el[NPF];                        // grid offset within a plane; k << 24 | el  (-1: no element)
-    const int64_t plane_reals = (int64_t)g.Nover[1] * g.Nover[0] * NC;
-#pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-        const int e = tid + u * kMarchThreads;
-        pf_off[u] = 0;
-        pf_el[u] = -1;
-        if (e < BZ * PS) {
-            const int k = e / PS, el = e % PS, r = el / RS, xx = el % RS;
-            pf_off[u] = (wrap_index(o2 + r, g.Nover[1]) * g.Nover[0] + wrap_index(o1 + xx / NC, g.Nover[0])) * NC + xx % NC;
-            pf_el[u] = (k << 24) | el;
-        }
-    }
-    // ---- first window: RZ planes straight into the ring (plane zbase + k in slot k), BZ planes at a time with the same tables ----
-    for (int b0 = 0; b0 < RZ; b0 += BZ) {
-#pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int pl = b0 + (pf_el[u] >> 24);
-            if (pf_el[u] >= 0 && pl < RZ)
-                ring[pl * PSP + (pf_el[u] & 0xffffff)] = grid[(int64_t)wrap_index(zbase + pl, g.Nover[2]) * plane_reals + pf_off[u]];
-        }
-    }
-    __syncthreads();
+    constexpr bool STAGED_KERNEL = false;
+#include "march_setup.inc"
     constexpr int KL = C::KL;
     int pm = 0;                                         // (BZ * phase) mod RZ: slot of the first plane of the window
     const int nphase = (nlay + KL - 1) / KL;
@@ -304,129 +219,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_
             const uint32_t p = p0 + grp;
             const bool have = p < p1;
             const PointRec<T, 3> rec = sorted[min(p, p1 - 1)];
-            int s[3];
-            T X[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int c = cell_of(rec.r[d], g.Nover[d]);
-                X[d] = rec.r[d] - T(c);
-                s[d] = c;
-            }
-            s[0] -= org1; s[1] -= org2;                   // first stencil node in padded-column coordinates
-            int s3 = pm + 4 * kl + (s[2] & 3) + zp;      // ring slot of this lane's first stencil plane
-            if (s3 >= RZ) s3 -= RZ;
-            T wv[WEv::NSLOT];
-            T w1;
-            if constexpr (C::REGW) {
-                we.eval_regs(am, X, wv);
-                w1 = wv[0];
-            } else {
-                wave_lds_fence();
-                we.eval_to_strip(am, X, strip, q);
-                wave_lds_fence();
-                w1 = strip[j1];
-            }
-            auto wfetch = [&](int d, int j) __attribute__((always_inline)) -> T {
-                const int kk = d * L + j;
-                const T x = wv[kk / GP::G];
-                if constexpr (GP::G == 16) return row_bcast(x, kk % GP::G);
-                const T lo = row_bcast(x, kk % GP::G), hi = row_bcast(x, kk % GP::G + 8);
-                return (lane & 8) ? hi : lo;
-            };
-            const T* base = ring + (s[0] + j1) * NC + comp + s[1] * RS;
-            int poff = s3 * PSP;                         // plane offset of the lane's stencil plane (wraps at RZ * PSP)
-            T acc = T(0);
-            VT accv = VT(0);
-            if constexpr (C::REGW) {
-                T w2[L];
-#pragma unroll
-                for (int j = 0; j < L; ++j) w2[j] = wfetch(1, j);
-                // rows per group of the hand-scheduled form (0: compiler-scheduled reads): what compiles without spills
-                // (m = 4 at 16 waves: groups of 4 spill 8 registers for Float64, 1.31 against 1.26 ms; Float32 gains 3 %: left at 2)
-                // (m = 8 at 16 waves: 8 rows in flight twice over spill 18 registers, groups of 4 fit — C3: 49.8 against 45.0 ms; groups of 2: 47.4)
-                constexpr int R = L <= 8 ? ((CPLX || C::THREADS != 512 || L % 4 != 0) ? 2 : 4) : (L % 8 == 0 ? (C::THREADS == 512 ? 8 : 4) : (L % 4 == 0 ? 4 : 0));
-                static_assert(R == 0 || L % R == 0, "row groups must tile the stencil");
-                if constexpr (R > 0) {
-                // hand-scheduled LDS reads (as in interp_tile_kernel): groups of R rows with immediate offsets from the
-                // plane's own address (the ring wraps between planes), the next group in flight while this one is consumed
-                constexpr int GPP = L / R, NG = (L / ZP) * GPP, RB = RS * (int)sizeof(T);
-
-                const uint32_t a0 = (uint32_t)(uintptr_t)base;
-                VT buf[2][R];
-                lds_read_rows<VT, R, 0, RB>(buf[0], a0 + (uint32_t)poff * (uint32_t)sizeof(T), std::make_integer_sequence<int, R>{});
-                // (ComplexF32: two accumulation chains per plane — a v_pk_fma_f32 that depends on the previous one issues
-                // every 6.2 cycles instead of 4.5 even with other waves to fill the gap, scripts/microbench10.hip)
-#ifndef NUFFT_MARCH_NT_ALL
-#define NUFFT_MARCH_NT_ALL 0
-#endif
-                constexpr int NT = (PAIR || NUFFT_MARCH_NT_ALL) ? 2 : 1;
-                VT t2[NT];
-#pragma unroll
-                for (int c = 0; c < NT; ++c) t2[c] = VT(0);
-#pragma unroll
-                for (int gi = 0; gi < NG; ++gi) {
-                    if (gi + 1 < NG) {
-                        if ((gi + 1) % GPP == 0) {                 // next group starts the lane's next plane
-                            poff += ZP * PSP;
-                            if (poff >= RZ * PSP) poff -= RZ * PSP;
-                        }
-                        const uint32_t ad = a0 + (uint32_t)poff * (uint32_t)sizeof(T) + (uint32_t)(((gi + 1) % GPP) * R * RB);
-                        lds_read_rows<VT, R, 0, RB>(buf[(gi + 1) & 1], ad, std::make_integer_sequence<int, R>{});
-                        lds_wait_rows<R>(buf[gi & 1]);
-                    } else {
-                        lds_wait_rows<0>(buf[gi & 1]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) t2[r % NT] = vfma(buf[gi & 1][r], w2[(gi % GPP) * R + r], t2[r % NT]);
-                    if (gi % GPP == GPP - 1) {
-                        VT tp = t2[0];
-                        if constexpr (NT == 2) tp += t2[1];
-                        accv = vfma(tp, wfetch(2, ZP * (gi / GPP)), accv);
-#pragma unroll
-                        for (int c = 0; c < NT; ++c) t2[c] = VT(0);
-                    }
-                }
-                } else {
-                    // wide stencils: the unrolled hand-scheduled form (2M x M groups) spills; the compiler schedules the reads
-#pragma unroll
-                    for (int j3 = 0; j3 < L; j3 += ZP) {
-                        const VT* plane = reinterpret_cast<const VT*>(base + poff);
-                        VT t2 = VT(0);
-#pragma unroll
-                        for (int j2 = 0; j2 < L; ++j2) t2 = vfma(*reinterpret_cast<const VT*>(reinterpret_cast<const T*>(plane) + j2 * RS), w2[j2], t2);
-                        accv = vfma(t2, wfetch(2, j3), accv);
-                        poff += ZP * PSP;
-                        if (poff >= RZ * PSP) poff -= RZ * PSP;
-                    }
-                }
-                if constexpr (PAIR) {
-                    const bool okl = have && lane_active;
-                    const T re = group_sum<T, GP::G * ZP, false>(okl ? accv[0] * w1 : T(0));
-                    const T im = group_sum<T, GP::G * ZP, false>(okl ? accv[1] * w1 : T(0));
-                    if (have && q == 0 && zp == 0) *reinterpret_cast<VT*>(vout + (int64_t)rec.idx * 2) = VT{re * a.prefactor, im * a.prefactor};
-                    continue;
-                } else {
-                    acc = accv;
-                }
-                acc = (have && lane_active) ? acc * w1 : T(0);
-            } else if (have && lane_active) {
-                T w2[L];
-#pragma unroll
-                for (int j = 0; j < L; ++j) w2[j] = strip[L + j];
-#pragma unroll
-                for (int j3 = 0; j3 < L; ++j3) {
-                    const T* plane = base + poff;
-                    T t2 = T(0);
-#pragma unroll
-                    for (int j2 = 0; j2 < L; ++j2) t2 = fma(plane[j2 * RS], w2[j2], t2);
-                    acc = fma(t2, strip[2 * L + j3], acc);
-                    poff += PSP;
-                    if (poff >= RZ * PSP) poff -= RZ * PSP;
-                }
-                acc *= w1;
-            }
-            acc = group_sum<T, GP::G * ZP, CPLX>(acc);
-            if (have && q < NC && zp == 0) vout[(int64_t)rec.idx * NC + q] = acc * a.prefactor;
+#include "march_gather.inc"
         }
         __syncthreads();                                 // every wave has finished with this phase's window
         if (more) {
@@ -444,6 +237,155 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_
             if (pm >= RZ) pm -= RZ;
             __syncthreads();
         }
+    }
+}
+
+// The same kernel for column-layer sorted point sets (CoarseSort, kernels.h): a bin layer of the column is ONE run of the sorted
+// array (row 0 of the table; the other rows are empty), in no particular order, cut into chunks of STAGE_RECS records.  While the waves
+// gather the chunk staged in LDS, every thread holds one 16-byte piece of the next chunk in registers; at the chunk boundary the
+// records are counted by bin (LDS atomics before the barrier, the 64-key scan redone by every wave after it: no extra barrier) and
+// written to the stage in bin order — the points of a wave pass then share stencil rows as they do after the fine sort (without
+// the ordering the 64-bit LDS reads of a pass conflict more: + 0.28 ms at C2, round 4), and no pass waits for a record from memory.
+template <typename T, bool CPLX, int M, bool POLY>
+__global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY, true>::THREADS)) void interp_march_staged_kernel(TileArgs<T> a, MarchGeom mg) {
+    constexpr bool STAGED_KERNEL = true;
+#include "march_setup.inc"
+    constexpr int KL = C::KL;
+    static_assert(KL == 1, "staged records: one bin layer per phase");
+    int pm = 0;                                         // (BZ * layer) mod RZ: slot of the first plane of the window
+    constexpr int PIECES = C::PIECES, SREC = C::STAGE_RECS;
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    unsigned char* stage = smem + C::lds_bytes();
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + C::STAGE_BYTES);        // [2][64]
+    const PointRec<T, 3>* staged = reinterpret_cast<const PointRec<T, 3>*>(stage);
+    const int myrec = tid / PIECES, mysub = tid % PIECES;
+    // (run bounds through readfirstlane: uniform values in scalar registers — as vector registers they cost this kernel, which sits
+    // at the 128-register limit of 16 waves per CU, spills in the serial section between the two barriers of a chunk)
+    auto run_of = [&](int lay, int& r0, int& n) __attribute__((always_inline)) {
+        const uint2 pr = runs[lay * kMarchMaxRows];
+        r0 = __builtin_amdgcn_readfirstlane((int)pr.x);
+        n = __builtin_amdgcn_readfirstlane((int)(pr.y - pr.x));
+    };
+    auto chunk_records = [&](int lay, int ch) __attribute__((always_inline)) -> int {
+        int r0, n;
+        run_of(lay, r0, n);
+        const int left = n - ch * SREC;
+        return left < SREC ? (left > 0 ? left : 0) : SREC;
+    };
+    auto chunks_of = [&](int lay) __attribute__((always_inline)) -> int {
+        int r0, n;
+        run_of(lay, r0, n);
+        return n > 0 ? (n + SREC - 1) / SREC : 1;
+    };
+    // the piece of this thread in chunk `ch` of layer `lay` (n: records of the chunk; uniform) — issued, not waited for
+    auto load_piece = [&](int lay, int ch, int n) __attribute__((always_inline)) -> U4 {
+        U4 v = U4{0u, 0u, 0u, 0u};
+        if (myrec < n) {
+            int r0, nn;
+            run_of(lay, r0, nn);
+            v = *reinterpret_cast<const U4*>(reinterpret_cast<const unsigned char*>(sorted + (uint32_t)(r0 + ch * SREC)) + (size_t)tid * 16);
+        }
+        return v;
+    };
+    // bin key of the record whose first piece this thread holds (r1, r2 sit in the first 16 bytes for both precisions)
+    auto key_of = [&](const U4& v) __attribute__((always_inline)) -> int {
+        T r0, r1;
+        if constexpr (sizeof(T) == 8) {
+            r0 = __builtin_bit_cast(T, ((unsigned long long)v[1] << 32) | v[0]);
+            r1 = __builtin_bit_cast(T, ((unsigned long long)v[3] << 32) | v[2]);
+        } else {
+            r0 = __builtin_bit_cast(T, v[0]);
+            r1 = __builtin_bit_cast(T, v[1]);
+        }
+        const int bx = (cell_of(r0, g.Nover[0]) - org1) >> 2, by = (cell_of(r1, g.Nover[1]) - org2) >> 2;
+#ifdef NUFFT_STAGED_NOSORT
+        return 0;                                       // (ablation build: the records stay in arrival order)
+#endif
+        return ((bx >> C::KSX) + (by >> C::KSY) * C::KNX) & 63;
+    };
+    // counting sort, second half: start of every key from the counters (each wave scans them for itself), then the piece goes to its place
+    auto place_piece = [&](const U4& v, int key, uint32_t rank, int n, const uint32_t* cn) __attribute__((always_inline)) {
+        const uint32_t c = cn[lane];
+        uint32_t incl = c;
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += t;
+        }
+        const uint32_t start = __shfl(incl - c, key, kWave);
+        uint32_t dest = start + rank;
+        if constexpr (PIECES > 1) dest = __shfl(dest, lane & ~(PIECES - 1), kWave);       // the record's other pieces follow its first
+        if (myrec < n) *reinterpret_cast<U4*>(stage + (size_t)dest * C::REC_BYTES + mysub * 16) = v;
+    };
+    int lay = 0, ch = 0, par = 1;                       // current layer and chunk; counter set of the next chunk
+    int cur_n = chunk_records(0, 0);                    // records staged
+    {
+        if (tid < 128) cnt[tid] = 0u;
+        __syncthreads();
+        const U4 v = load_piece(0, 0, cur_n);
+        int key = 0;
+        uint32_t rank = 0u;
+        if (mysub == 0 && myrec < cur_n) { key = key_of(v); rank = atomicAdd(&cnt[key], 1u); }
+        __syncthreads();
+        place_piece(v, key, rank, cur_n, cnt);
+        __syncthreads();
+    }
+    for (;;) {
+        // ---- what comes next: another chunk of this layer, or the first chunk of the next one with its four new planes ----
+        int nlay2 = lay, nch2 = ch + 1;
+        if (nch2 >= chunks_of(lay)) { nlay2 = lay + 1; nch2 = 0; }
+        const bool has_next = nlay2 < nlay, more = has_next && nlay2 != lay;
+        const int next_n = has_next ? chunk_records(nlay2, nch2) : 0;
+        U4 pc = U4{0u, 0u, 0u, 0u};
+        if (has_next) pc = load_piece(nlay2, nch2, next_n);
+        T pf[NPF];
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                pf[u] = T(0);
+                if (pf_el[u] >= 0) {
+                    int gz = zbase + RZ + BZ * lay + (pf_el[u] >> 24);
+                    if (gz >= g.Nover[2]) gz -= g.Nover[2];
+                    pf[u] = grid[(int64_t)gz * plane_reals + pf_off[u]];
+                }
+            }
+        }
+        // ---- the staged chunk: passes of PPW points, pulled from a counter ----
+        const int nitems = (cur_n + PPW - 1) / PPW;
+        for (;;) {
+            int item = 0;
+            if (lane == 0) item = atomicAdd(counter, 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item >= nitems) break;
+            constexpr int kl = 0;
+            const int p = item * PPW + grp;
+            const bool have = p < cur_n;
+            const PointRec<T, 3> rec = staged[min(p, cur_n - 1)];
+#include "march_gather.inc"
+        }
+        // ---- the next chunk is counted by bin as soon as this wave's pieces are here ----
+        int key = 0;
+        uint32_t rank = 0u;
+        if (has_next && mysub == 0 && myrec < next_n) { key = key_of(pc); rank = atomicAdd(&cnt[par * 64 + key], 1u); }
+        __syncthreads();                                 // every wave has finished with the stage (and, if the layer ends, with its window)
+        if (!has_next) break;
+        place_piece(pc, key, rank, next_n, cnt + par * 64);
+        if (tid < 64) cnt[(par ^ 1) * 64 + tid] = 0u;
+        if (tid == 0) counter[0] = 0;
+        if (more) {
+            // the BZ new planes take the slots of the BZ oldest: slots pm .. pm + BZ - 1 (mod RZ)
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                if (pf_el[u] >= 0) {
+                    int slot = pm + (pf_el[u] >> 24);
+                    if (slot >= RZ) slot -= RZ;
+                    ring[slot * PSP + (pf_el[u] & 0xffffff)] = pf[u];
+                }
+            }
+            pm += BZ;
+            if (pm >= RZ) pm -= RZ;
+        }
+        lay = nlay2; ch = nch2; cur_n = next_n; par ^= 1;
+        __syncthreads();
     }
 }
 

@@ -157,6 +157,7 @@ struct nufft_plan {
     uint32_t* d_counts = nullptr;      // [ntiles + 1]  histogram
     bool counts_clean = false;         // d_counts is all zero (plan creation; every completed set_points leaves it so)
     uint32_t* d_offsets = nullptr;     // [ntiles + 1]  exclusive scan
+    nufft::CoarseSort coarse{};        // column-layer sort (binsort.hip): enabled on plans whose two rings own the same columns; table allocated
     void* d_binrank = nullptr;         // uint2[Np]: (tile, rank)
     void* d_sorted = nullptr;          // PointRec<T, D>[Np]
     void* d_scan_tmp = nullptr;

@@ -665,6 +665,29 @@ static int build_device(nufft_plan* p) {
         p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
     }
 
+    // Column-layer sort (binsort.hip, CoarseSort): where the spreading window (halo variant: a column visits its own points only) and
+    // the interpolation ring own the same columns, set_points only groups the points by (column, layer of bins) — few enough keys for
+    // LDS histograms, no global atomics — and the interpolation ring's staged variant orders a layer's points by bin on their way
+    // into LDS.  Per point set: only while both rings serve it (device flags); NUFFT_COARSE_SORT=0 keeps the fine sort (A/B runs).
+    p->coarse = CoarseSort{};
+    if (p->spread_method == NUFFT_SPREAD_MARCHING_RING && p->smarch.halo == 2 && p->interp_march && D == 3 && env_int("NUFFT_COARSE_SORT", 1) != 0) {
+        const ColumnTasks &sc = p->smarch.ct, &mc = p->march_ct;
+        const int nkeys = sc.ncolx * sc.ncoly * p->tile.nb[2];
+        const bool same = sc.ncolx == mc.ncolx && sc.ncoly == mc.ncoly && p->smarch.n1 == 4 * mc.bxw && p->smarch.n2 == 4 * mc.byw &&
+                          p->Nover[0] % p->smarch.n1 == 0 && p->Nover[1] % p->smarch.n2 == 0;
+        if (same && nkeys <= kCoarseMaxKeys && interp_march_staged_available(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT)) {
+            p->coarse.enabled = 1;
+            p->coarse.cbx = mc.bxw; p->coarse.cby = mc.byw; p->coarse.ncx = mc.ncolx; p->coarse.ncy = mc.ncoly;
+            p->coarse.nkeys = nkeys;
+            p->coarse.groups = p->num_cus;
+            p->coarse.flag_a = p->d_smarch_choice + 2;
+            p->coarse.flag_b = p->d_march_choice + 2;
+            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->coarse.table), (size_t)p->coarse.groups * nkeys * sizeof(uint32_t)))) return rc;
+            NUFFT_HIP(prepare_binsort_coarse(p->dtype, nkeys));
+            NUFFT_HIP(prepare_interp_march_staged(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
+        }
+    }
+
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->spread_method == NUFFT_SPREAD_MARCHING_RING || p->interp_march) NUFFT_HIP(prepare_column_tasks());
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
@@ -686,7 +709,7 @@ static void release(nufft_plan* p) {
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
         fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks); fr(p->d_march_choice); fr(p->d_march_cols); fr(p->d_march_tasks);
-        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks); fr(p->d_smarch_halo);
+        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks); fr(p->d_smarch_halo); fr(p->coarse.table);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -744,7 +767,10 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.weights = p->cb_point_weights;
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
-    a.march = interp && p->interp_march && !p->cb_point_weights;
+    a.march = interp && p->interp_march;      // (the ring applies per-point weights itself)
+    a.coarse = p->coarse.enabled;
+    a.coarse_a = p->coarse.flag_a;
+    a.coarse_b = p->coarse.flag_b;
     a.march_ct = p->march_ct;
     a.march_flag = p->d_march_choice ? p->d_march_choice + 2 : nullptr;
     a.march_tasks = static_cast<const uint2*>(p->d_march_tasks);
@@ -1066,6 +1092,8 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->ring_column[1] = ring ? p->smarch.n2 : 0;
     o->ring_segments = ring ? p->smarch.ct.nseg : 0;
     o->ring_halo = (ring && p->smarch.halo == 2) ? 1 : 0;
+    o->sort_column[0] = p->coarse.enabled ? p->coarse.cbx : 0;
+    o->sort_column[1] = p->coarse.enabled ? p->coarse.cby : 0;
     return NUFFT_OK;
 }
 
@@ -1138,9 +1166,14 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     s.sorted = p->d_sorted;
     s.scan_tmp = p->d_scan_tmp;
     s.scan_tmp_bytes = p->scan_tmp_bytes;
-    NUFFT_HIP(launch_binsort(s, stream));
+    s.cs = p->coarse;
+    const bool coarse = p->coarse.enabled != 0;
+    // plans of the column-layer sort: histogram by column layers first — its offsets are all the task kernels below need to decide
+    // whether both rings serve this point set; the scatter pass (of whichever sort that decision selects) and the tile tables follow
+    if (coarse) NUFFT_HIP(launch_binsort_coarse_count(s, stream));
+    else NUFFT_HIP(launch_binsort(s, stream));
     // slices per tile from the work each tile now holds (balance.hip)
-    {
+    auto balance = [&]() -> int {
         const nufft_plan::Balance& b = p->bal;
         BalanceArgs q{};
         q.g = s.g;
@@ -1158,8 +1191,13 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         q.slots_in_use = b.d_slots;
         q.scan_tmp = b.d_tmp;
         q.scan_tmp_bytes = b.tmp_bytes;
+        q.skip_a = coarse ? p->coarse.flag_a : nullptr;
+        q.skip_b = coarse ? p->coarse.flag_b : nullptr;
+        q.sp_served = coarse ? p->coarse.flag_a : nullptr;      // (otherwise the task kernels below clear the spreading slots)
         NUFFT_HIP(launch_balance(q, stream));
-    }
+        return NUFFT_OK;
+    };
+    if (!coarse && (rc = balance())) return rc;
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
         // which engine serves this point set: decided on the device from the heaviest patch task (balance.hip)
         PatchPlan pp{};
@@ -1218,6 +1256,11 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         NUFFT_HIP(launch_march_tasks(s.g, p->march_ct, p->d_offsets, np, p->num_cus, advantage, 2.5 * rho_star, p->d_march_choice, p->d_march_cols,
                                      p->d_march_cols + ncols, static_cast<uint2*>(p->d_march_tasks), stream));
     }
+    if (coarse) {
+        // both rings have decided: column-layer scatter, or the fine sort for a point set one of them hands to the tile kernels
+        NUFFT_HIP(launch_binsort_coarse_finish(s, stream));
+        if ((rc = balance())) return rc;
+    }
     if (p->debug_tasks) {
         // development check: every column's tasks tile [0, nb[2]) without gaps or overlaps
         auto check = [&](const char* name, const ColumnTasks& ct, const void* tab, const uint32_t* choice) {
@@ -1274,12 +1317,28 @@ int nufft_spread_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
     return NUFFT_OK;
 }
 
+int nufft_sort_columns_used(nufft_plan* p, int* used_out, void* stream_) {
+    int rc = require_points(p);
+    if (rc) return rc;
+    if (!used_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
+    *used_out = 0;
+    if (!p->coarse.enabled) return NUFFT_OK;
+    DeviceGuard guard(p->device);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    uint32_t fa = 0, fb = 0;
+    NUFFT_HIP(hipMemcpyAsync(&fa, p->coarse.flag_a, sizeof(fa), hipMemcpyDeviceToHost, stream));
+    NUFFT_HIP(hipMemcpyAsync(&fb, p->coarse.flag_b, sizeof(fb), hipMemcpyDeviceToHost, stream));
+    NUFFT_HIP(hipStreamSynchronize(stream));
+    *used_out = (fa != 0 && fb != 0) ? 1 : 0;
+    return NUFFT_OK;
+}
+
 int nufft_interp_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
     int rc = require_points(p);
     if (rc) return rc;
     if (!engine_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
     *engine_out = NUFFT_INTERP_LDS_TILES;
-    if (!p->interp_march || p->cb_point_weights) return NUFFT_OK;      // (per-point weights of the callback menu: always the tile kernel)
+    if (!p->interp_march) return NUFFT_OK;
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t flag = 0;

@@ -22,6 +22,25 @@ static const void* march_kernel(int dtype, int is_complex, int M, bool poly, int
     if (dtype == NUFFT_F32) return is_complex ? march_kernel_f32c(M, poly, lds_bytes, n) : march_kernel_f32r(M, poly, lds_bytes, n);
     return is_complex ? march_kernel_f64c(M, poly, lds_bytes, n) : march_kernel_f64r(M, poly, lds_bytes, n);
 }
+// interp_march_staged_kernel: the ring for column-layer sorted point sets (null: none for this configuration)
+const void* march_kernel_f32r_staged(int M, bool poly, int* lds_bytes, int* n);
+const void* march_kernel_f32c_staged(int M, bool poly, int* lds_bytes, int* n);
+const void* march_kernel_f64r_staged(int M, bool poly, int* lds_bytes, int* n);
+const void* march_kernel_f64c_staged(int M, bool poly, int* lds_bytes, int* n);
+static const void* march_staged_kernel(int dtype, int is_complex, int M, bool poly, int* lds_bytes, int* n) {
+    if (dtype == NUFFT_F32) return is_complex ? march_kernel_f32c_staged(M, poly, lds_bytes, n) : march_kernel_f32r_staged(M, poly, lds_bytes, n);
+    return is_complex ? march_kernel_f64c_staged(M, poly, lds_bytes, n) : march_kernel_f64r_staged(M, poly, lds_bytes, n);
+}
+bool interp_march_staged_available(int dtype, int is_complex, int M, bool poly) {
+    int lds = 0, n[4];
+    return march_staged_kernel(dtype, is_complex, M, poly, &lds, n) != nullptr;
+}
+hipError_t prepare_interp_march_staged(int dtype, int is_complex, int M, bool poly) {
+    int lds = 0, n[4];
+    const void* fn = march_staged_kernel(dtype, is_complex, M, poly, &lds, n);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
 bool interp_march_available(int dtype, int is_complex, int D, int M, bool poly, const Geom& g, bool other) {
     int lds = 0, n[4];
     if (D != 3 || other || !march_kernel(dtype, is_complex, M, poly, &lds, n)) return false;
@@ -345,7 +364,8 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
     if (!fn) return hipErrorInvalidValue;
     // z-marching interpolation: launched next to the tile kernel; the flag set_points left on the device (heaviest ring task
     // and total work against the ring's advantage limit, balance.hip) decides which of the two finds work
-    const bool march = interp && a.march != 0 && !other;
+    // (the ring applies the per-point weights of the callback menu itself; the tile kernel next to it is then the general variant)
+    const bool march = interp && a.march != 0 && !needs_other_eval(a.kernel, a.evalmode);
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
         const int nc = (a.C - c0) < kMaxCompPerLaunch ? (a.C - c0) : kMaxCompPerLaunch;
         TileArgs<T> k = fill_tile_args<T>(a, c0, nc);
@@ -365,9 +385,19 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
             mg.ntasks = column_task_table_entries(a.march_ct, a.g.nb[2]);
             mg.flag = a.march_flag;
             mg.tasktab = a.march_tasks;
+            mg.coarse_a = a.coarse ? a.coarse_a : nullptr;
+            mg.coarse_b = a.coarse ? a.coarse_b : nullptr;
             void* mparams[] = {&k, &mg};
             e = hipLaunchKernel(mfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)n[3], 1, 1), mparams, (size_t)lds, stream);
             if (e != hipSuccess) return e;
+            if (a.coarse) {
+                // plans of the column-layer sort: the staged kernel serves the point sets sorted that way (device flags), the plain one the others
+                int slds = 0, sn[4];
+                const void* sfn = march_staged_kernel(a.dtype, a.is_complex, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &slds, sn);
+                if (!sfn) return hipErrorInvalidValue;
+                e = hipLaunchKernel(sfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)sn[3], 1, 1), mparams, (size_t)slds, stream);
+                if (e != hipSuccess) return e;
+            }
         }
     }
     return hipSuccess;

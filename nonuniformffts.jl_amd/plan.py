@@ -322,6 +322,13 @@ class PlanNUFFT:
         _check(lib.nufft_plan_info(self._handle, C.byref(self._info)))
         return self._info
 
+    def sort_columns_used(self) -> bool:
+        """True if the last set_points grouped the points by (column, layer of bins) only (plans with ``info().sort_column`` > 0,
+        point sets both rings serve); reads two device flags back and synchronises."""
+        out = C.c_int(0)
+        _check(lib.nufft_sort_columns_used(self._handle, C.byref(out), self._stream()))
+        return bool(out.value)
+
     def spread_engine_used(self) -> str:
         """Engine that serves the point set of the last set_points: "lds_tiles" or "mfma_patches" (plans of the
         patch engine decide per point set on the device; this reads the decision back and synchronises)."""

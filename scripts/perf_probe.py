@@ -99,4 +99,4 @@ t2e = sum(np.median(acc[k]) for k in ("t2_deconv_pad", "t2_fft", "t2_interp"))
 sp = np.median(acc["set_points"])
 print(f"type-1 exec {t1e:.3f} ms -> {Np / t1e / 1e6:.3f} Gpts/s ; with set_points {Np / (t1e + sp) / 1e6:.3f} Gpts/s")
 print(f"type-2 exec {t2e:.3f} ms -> {Np / t2e / 1e6:.3f} Gpts/s ; with set_points {Np / (t2e + sp) / 1e6:.3f} Gpts/s")
-print(f"engines: spread {plan.spread_engine_used()}, interp {plan.interp_engine_used()}")
+print(f"engines: spread {plan.spread_engine_used()}, interp {plan.interp_engine_used()}, column-layer sort {plan.sort_columns_used()} (plan: {list(info.sort_column)})")

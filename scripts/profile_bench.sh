@@ -13,6 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 2 --only-headline "$@" > $OUT/stats_line.json 2> $OUT/stats_stderr.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --only-headline "$@" > $OUT/fetch_line.json 2> $OUT/fetch_stderr.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 3 --warmup 1 --only-headline "$@" > $OUT/write_line.json 2> $OUT/write_stderr.txt
+# SQ counters of the same command (what binds the kernels: bench.py derives roofline.binding_resource from these)
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq_a -- python3 $R/bench.py --steps 3 --warmup 1 --only-headline "$@" > $OUT/sq_a_line.json 2> $OUT/sq_a_stderr.txt
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $OUT/sq_b -- python3 $R/bench.py --steps 3 --warmup 1 --only-headline "$@" > $OUT/sq_b_line.json 2> $OUT/sq_b_stderr.txt
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/sq_c -- python3 $R/bench.py --steps 3 --warmup 1 --only-headline "$@" > $OUT/sq_c_line.json 2> $OUT/sq_c_stderr.txt
 cd $R
 # keep only the small csv files (the merged-back directory is capped at 64 MiB)
 find $OUT -name "*.db" -delete 2>/dev/null

@@ -4,7 +4,12 @@ of --pmc runs) into the small tracked summaries under profiles/.
 
 usage: python scripts/summarize_profile.py <gpurun_out/prof_dir> <profiles/out_prefix> [note]
 expects <dir>/stats/**/**_kernel_stats.csv, optionally <dir>/fetch/**/**_counter_collection.csv and
-<dir>/write/**/**_counter_collection.csv (separate PMC passes, as MI355X_MICROARCH.md prescribes).
+<dir>/write/**/**_counter_collection.csv (separate PMC passes, as MI355X_MICROARCH.md prescribes), and
+<dir>/sq_a, <dir>/sq_b (SQ counter passes of the same command: scripts/profile_bench.sh).
+
+Writes <prefix>.md, <prefix>_kernel_stats.csv, <prefix>_traffic.json (HBM bytes per launch AND the profile's average
+kernel duration, so that bench.py can state whether the run it describes matches the profile) and <prefix>_sq.json
+(SQ counters per launch of the nufft kernels, from which bench.py derives `roofline.binding_resource`).
 """
 import collections
 import csv
@@ -58,6 +63,10 @@ def main():
                 continue
             out.append(f"| `{short(n)}` | {f:.3f} | {2 * f:.3f} | {w:.3f} | {2 * f + w:.3f} |")
         out.append("")
+    avg_us = {}
+    if stats:
+        for r in csv.DictReader(open(stats[0])):
+            avg_us[short(r["Name"])] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]))
     if pmc:
         import json
         traffic = {}
@@ -66,9 +75,34 @@ def main():
             w = pmc.get("write", {}).get(n, 0.0) * 1024
             traffic[short(n)] = {"fetch_size_bytes_raw": f, "read_bytes_corrected": 2 * f, "write_bytes": w,
                                  "hbm_bytes_per_launch": 2 * f + w}
+            if short(n) in avg_us:
+                traffic[short(n)]["kernel_avg_us"] = avg_us[short(n)][0]
+                traffic[short(n)]["kernel_calls"] = avg_us[short(n)][1]
         with open(prefix + "_traffic.json", "w") as fh:
             json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, "
                                  "FETCH_SIZE x2 gfx950 correction (MI355X_MICROARCH.md)", "kernels": traffic}, fh, indent=1)
+    # SQ counters per launch (averages over the launches of a kernel) of the library's own kernels
+    sq = collections.defaultdict(dict)
+    for key in ("sq_a", "sq_b", "sq_c"):
+        for f in glob.glob(os.path.join(src, key, "**", "*counter_collection.csv"), recursive=True):
+            agg = collections.defaultdict(lambda: collections.defaultdict(list))
+            for r in csv.DictReader(open(f)):
+                if "nufft::" in r["Kernel_Name"]:
+                    agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                for c, vals in v.items():
+                    sq[k][c] = sum(vals) / len(vals)
+    if sq:
+        import json
+        big = {k: v for k, v in sq.items() if v.get("SQ_BUSY_CYCLES", 0) > 1e6 or v.get("SQ_WAVE_CYCLES", 0) > 1e8 or v.get("SQ_WAIT_ANY", 0) > 1e7}
+        out.append("## SQ counters per launch (separate --pmc passes of the same command)\n")
+        cols = sorted({c for v in big.values() for c in v})
+        out.append("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
+        for k, v in sorted(big.items()):
+            out.append(f"| `{k[:70]}` | " + " | ".join(f"{v.get(c, float('nan')):.4g}" for c in cols) + " |")
+        out.append("")
+        with open(prefix + "_sq.json", "w") as fh:
+            json.dump({"source": "rocprofv3 --kernel-trace --pmc <SQ counters> (separate passes; averages per launch)", "kernels": big}, fh, indent=1)
     with open(prefix + ".md", "w") as fh:
         fh.write("\n".join(out) + "\n")
     if stats:

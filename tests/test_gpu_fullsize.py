@@ -154,10 +154,12 @@ def test_nonuniform_distributions_spot_check_and_balance(dist):
     assert float((out - out0).norm() / out0.norm()) < 1e-13
 
 
-def test_c2_full_grid_rel_l2_against_c_oracle():
+@pytest.mark.parametrize("mode", ["FastApproximation", "Direct"])
+def test_c2_full_grid_rel_l2_against_c_oracle(mode):
     """Full rel-L2 over all 129 x 256 x 256 output modes of the C2 transform at its stated size (256^3, sigma = 2, m = 4,
     Float64, Np = 1e7) against the C restatement of the reference's blocked CPU
-    algorithm (oracle/nufft_oracle.c + pocketfft), and of type 2 over all points."""
+    algorithm (oracle/nufft_oracle.c + pocketfft), and of type 2 over all points — with the polynomial window and
+    with Direct(), the ROC default (ext/NonuniformFFTsAMDGPUExt.jl:56) and the window of bench.py's headline value."""
     from oracle import c_oracle as CO, nufft_oracle as O
     from nufft_pkg import nufft
     if not CO.available():
@@ -166,20 +168,23 @@ def test_c2_full_grid_rel_l2_against_c_oracle():
     rng = np.random.default_rng(2024)
     xs = [rng.random(Np) * O.TWO_PI for _ in range(3)]
     v = rng.standard_normal(Np)
-    oplan = O.OraclePlan((N, N, N), is_real=True, M=M, sigma=SIGMA, evalmode=O.FAST_APPROXIMATION)
+    oplan = O.OraclePlan((N, N, N), is_real=True, M=M, sigma=SIGMA, evalmode=O.FAST_APPROXIMATION if mode == "FastApproximation" else O.DIRECT)
     O.set_points(oplan, xs)
     ref = CO.exec_type1(oplan, v)
     plan = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, backend=nufft.ROCBackend(0),
-                           kernel_evalmode=nufft.FastApproximation())
+                           kernel_evalmode=getattr(nufft, mode)())
     nufft.set_points(plan, tuple(torch.from_numpy(x).cuda() for x in xs))
     u = torch.empty(plan.shape, dtype=torch.complex128, device="cuda")
     nufft.exec_type1(u, plan, torch.from_numpy(v).cuda())
     got = u.cpu().numpy()
-    assert np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel()) < 1e-11
+    e1 = np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel())
     out = torch.empty(Np, dtype=torch.float64, device="cuda")
     nufft.exec_type2(out, plan, u)
     ref2 = CO.exec_type2(oplan, got)
-    assert np.linalg.norm(out.cpu().numpy() - ref2) / np.linalg.norm(ref2) < 1e-11
+    e2 = np.linalg.norm(out.cpu().numpy() - ref2) / np.linalg.norm(ref2)
+    print(f"C2 full size, {mode}: type 1 rel-L2 vs C oracle {e1:.2e}, type 2 {e2:.2e}; engines {plan.spread_engine_used()} / "
+          f"{plan.interp_engine_used()}, column-layer sort {plan.sort_columns_used()}")
+    assert e1 < 1e-11 and e2 < 1e-11, (e1, e2)
 
 
 def test_config_c4_ntransforms3_spot_check():
@@ -258,7 +263,7 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
     rng = np.random.default_rng(3)
     num = den = 0.0
     errs = []
-    for _ in range(64):
+    for _ in range(256):
         i1, i2, i3 = (int(rng.integers(0, Ns)) for _ in range(3))
         phase = k[i1] * x64[0] + k[i2] * x64[1] + k[i3] * x64[2]
         exact = (v64 * torch.polar(torch.ones_like(phase), -phase)).sum()
@@ -266,8 +271,12 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
         num += errs[-1] ** 2
         den += float(exact.abs() ** 2)
     # Float32 data: the bound is the Float32 round-off of coordinates (k x with |k| <= 256 and x in Float32: 256 * 2 pi * 6e-8 = 1e-4 of a
-    # radian per point) and of sums over 1e8 Float32 terms, not the m = 8 window (1e-14): 64 random modes, rel-L2 <= 1e-4
-    assert np.sqrt(num / den) < 1e-4, (np.sqrt(num / den), max(errs))
+    # radian per point, random in sign) and of sums over 1e8 Float32 terms, not the m = 8 window (1e-14): 256 random modes.  Measured
+    # 2e-5 ... 3e-5 (printed); the bar is 5e-5 — the reference's own Float32 criterion is 1e-5 against its Float32 CPU path, which
+    # shares the coordinate rounding, while this is against exact Float64 sums (the dense 128^3 case below holds 1e-5 against the C oracle)
+    e1 = np.sqrt(num / den)
+    print(f"C3 full size: type 1 rel-L2 over 256 modes vs exact sums {e1:.2e} (largest deviation {max(errs):.3e})")
+    assert e1 < 5e-5, (e1, max(errs))
     # type 2 back from a smooth random spectrum: spot-check points
     w = torch.complex(torch.randn(plan.shape, dtype=torch.float32, device="cuda", generator=g),
                       torch.randn(plan.shape, dtype=torch.float32, device="cuda", generator=g))
@@ -282,7 +291,9 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
         exact = torch.einsum("cba,c,b,a->", w64, e3, e2, e1)
         num += float((out[j].to(torch.complex128) - exact).abs() ** 2)
         den += float(exact.abs() ** 2)
-    assert np.sqrt(num / den) < 1e-4, np.sqrt(num / den)
+    e2 = np.sqrt(num / den)
+    print(f"C3 full size: type 2 rel-L2 over 12 points vs exact sums {e2:.2e}")
+    assert e2 < 5e-5, e2
 
 
 def test_complexf32_m8_dense_128_cubed_against_c_oracle():
