@@ -33,7 +33,8 @@ struct SMarchPlan {
     int hlo, hhi;               // layers of points a segment visits below / above its own
     int halo;                   // 0: columns clipped in x and y; 2: halo variant (every point spread once by its own column, the stencil reach
                                 // into a side buffer that the consumer of the grid adds: smarch_kernels.h)
-    int64_t halo_reals;         // halo = 2: reals of the side buffer per component
+    int64_t halo_reals;         // halo = 2: reals of the side buffer per component (parts = 2: per part of a component)
+    int parts;                  // 2: complex data through the REAL kernel, real and imaginary parts as two launch rows per component (smarch_kernels.h); else 1
     int lds_bytes, threads;
     ColumnTasks ct;             // columns and evenly cut tasks
     double visits, efficiency;  // model: point visits per point, and the share of the chip the launch keeps busy

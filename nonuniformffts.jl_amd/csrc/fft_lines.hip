@@ -369,29 +369,42 @@ struct RealLineArgs {
 // (columns are wider than the reach).  Rows of the y reach (lines within the reach of a column boundary only): the rows of
 // neighbouring columns overlap, so even and odd columns take turns (and the last column of an odd count goes alone).
 // NC = 1: real lines, a pair = two cells = one complex element of the packed line (n = cells per line); NC = 2: complex lines, a pair = one cell.
-template <typename T, typename C, int NC>
-__device__ __forceinline__ void add_halo_to_line(const void* halo, const HaloLayout& h, int ny, C* line, int64_t line_id, int lane, int n) {
+// PLANAR (NC = 1 layout, complex lines): complex data spread part by part by the real kernel (smarch_kernels.h, MarchGeom::parts = 2) —
+// `halo` holds the real parts' side buffer, `halo2` the imaginary parts'; a pair of each = that part of two neighbouring cells of the
+// line, both added in one pass (two whole complex elements per step).
+template <typename T, typename C, int NC, bool PLANAR = false>
+__device__ __forceinline__ void add_halo_to_line(const void* halo, const HaloLayout& h, int ny, C* line, int64_t line_id, int lane, int n, const void* halo2 = nullptr) {
     typedef T T2 __attribute__((ext_vector_type(2)));
     const int y = (int)(line_id % ny), z = (int)(line_id / ny);
     const int ty = y / h.n2, ly = y - ty * h.n2;
     const T* hz = static_cast<const T*>(halo) + (int64_t)z * h.plane;
-    auto add_pair = [&](int x0, T2 v) __attribute__((always_inline)) {       // x0: first cell of the pair
+    const int64_t d2 = PLANAR ? static_cast<const T*>(halo2) - static_cast<const T*>(halo) : 0;      // from a real-part pair to the imaginary-part pair
+    auto add_pair = [&](int x0, const T* src) __attribute__((always_inline)) {       // x0: first cell of the pair
+        const T2 v = *reinterpret_cast<const T2*>(src);
         if (x0 < 0) x0 += n;
         if (x0 >= n) x0 -= n;
+        if constexpr (PLANAR) {                         // (pairs are aligned and n is even: x0 + 1 < n)
+            const T2 w = *reinterpret_cast<const T2*>(src + d2);
+            C c0 = line[lpad(x0)], c1 = line[lpad(x0 + 1)];
+            c0.x += v.x; c0.y += w.x;
+            c1.x += v.y; c1.y += w.y;
+            line[lpad(x0)] = c0;
+            line[lpad(x0 + 1)] = c1;
+            return;
+        }
         const int e = NC == 1 ? x0 >> 1 : x0;
         C c = line[lpad(e)];
         c.x += v.x;
         c.y += v.y;
         line[lpad(e)] = c;
     };
-    constexpr int CPP = 2 / NC;                         // cells per pair
+    constexpr int CPP = PLANAR ? 2 : 2 / NC;            // cells per pair
     {
         const int sp = h.sw / 2;
         const T* row = hz + (int64_t)ty * h.ntx * h.rec + ly * h.sw;
         for (int idx = lane; idx < h.ntx * sp; idx += kWave) {
             const int tx = idx / sp, pi = idx - tx * sp, i = CPP * pi;       // i: cell index within the strip
-            const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + 2 * pi);
-            add_pair(i < h.xlo ? tx * h.n1 - h.xlo + i : tx * h.n1 + h.n1 + (i - h.xlo), v);
+            add_pair(i < h.xlo ? tx * h.n1 - h.xlo + i : tx * h.n1 + h.n1 + (i - h.xlo), row + (int64_t)tx * h.rec + 2 * pi);
         }
         wave_lds_fence();
     }
@@ -407,8 +420,7 @@ __device__ __forceinline__ void add_halo_to_line(const void* halo, const HaloLay
             for (int idx = lane; idx < ncol * rp; idx += kWave) {
                 const int k = idx / rp, pi = idx - k * rp;
                 const int tx = par == 2 ? h.ntx - 1 : 2 * k + par;
-                const T2 v = *reinterpret_cast<const T2*>(row + (int64_t)tx * h.rec + 2 * pi);
-                add_pair(tx * h.n1 - h.xlo + CPP * pi, v);
+                add_pair(tx * h.n1 - h.xlo + CPP * pi, row + (int64_t)tx * h.rec + 2 * pi);
             }
             wave_lds_fence();
         }
@@ -498,6 +510,7 @@ struct CplxLineArgs {
     const void* twiddle;    // complex<T>[N]
     // forward pass behind the halo variant of the spreading ring (see RealLineArgs)
     const void* halo;
+    const void* halo2;      // complex data spread by the real kernel: `halo` holds the real parts' side buffer, `halo2` the imaginary parts' (hl.nc = 1)
     const uint32_t* hflag;
     int ny;
     HaloLayout hl;
@@ -524,7 +537,13 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
         load_line_wide(line, zin, N, lane);
         wave_lds_fence();
         if constexpr (HALO) {
-            if (*a.hflag != 0u) add_halo_to_line<T, C, 2>(a.halo, a.hl, a.ny, line, line_id, lane, N);
+            if (*a.hflag != 0u) {
+                if (a.halo2) {
+                    add_halo_to_line<T, C, 1, true>(a.halo, a.hl, a.ny, line, line_id, lane, N, a.halo2);
+                } else {
+                    add_halo_to_line<T, C, 2>(a.halo, a.hl, a.ny, line, line_id, lane, N);
+                }
+            }
         }
         fft_line<T, N, -1>(line, tw, lane);
         C* xout = static_cast<C*>(a.out) + line_id * a.k1;
@@ -692,22 +711,26 @@ __global__ __launch_bounds__(1024) void halo_add_lines_kernel(T* grid, const T* 
     C* g = reinterpret_cast<C*>(grid + (int64_t)blockIdx.y * grid_comp) + line_id * ne;
     load_line_wide(line, g, ne, lane);
     wave_lds_fence();
-    add_halo_to_line<T, C, NC>(halo + (int64_t)blockIdx.y * halo_comp, h, ny, line, line_id, lane, NC == 1 ? 2 * ne : ne);
+    if constexpr (NC == 3) {        // complex grid, planar side buffers of its two parts (2 blockIdx.y, 2 blockIdx.y + 1)
+        add_halo_to_line<T, C, 1, true>(halo + (int64_t)(2 * blockIdx.y) * halo_comp, h, ny, line, line_id, lane, ne, halo + (int64_t)(2 * blockIdx.y + 1) * halo_comp);
+    } else {
+        add_halo_to_line<T, C, NC>(halo + (int64_t)blockIdx.y * halo_comp, h, ny, line, line_id, lane, NC == 1 ? 2 * ne : ne);
+    }
     store_line_wide(g, line, ne, lane);
 }
 
 template <typename T>
 static hipError_t launch_halo_add_lines_t(void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, int n1cells, int ny, int nz,
-                                          int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream) {
+                                          int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream, bool planar) {
     using Cx = typename Cplx2<T>::type;
-    const int ne = h.nc == 1 ? n1cells / 2 : n1cells;
+    const int ne = (h.nc == 1 && !planar) ? n1cells / 2 : n1cells;
     const int LINE = ne + (ne >> 4) + 1;
     int nw = 16;
     while (nw > 1 && (size_t)nw * LINE * sizeof(Cx) > 72 * 1024) nw >>= 1;
     const size_t lds = (size_t)nw * LINE * sizeof(Cx);
-    if (lds > kFftLdsLimit || (h.nc == 1 && (n1cells & 1))) return hipErrorInvalidValue;
+    if (lds > kFftLdsLimit || (h.nc == 1 && (n1cells & 1)) || (planar && h.nc != 1)) return hipErrorInvalidValue;
     const int64_t nlines = (int64_t)ny * nz;
-    auto fn = h.nc == 1 ? halo_add_lines_kernel<T, 1> : halo_add_lines_kernel<T, 2>;
+    auto fn = planar ? halo_add_lines_kernel<T, 3> : (h.nc == 1 ? halo_add_lines_kernel<T, 1> : halo_add_lines_kernel<T, 2>);
     static std::atomic<unsigned long long> prepared{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -715,6 +738,7 @@ static hipError_t launch_halo_add_lines_t(void* grid, const void* halo, int64_t 
     if (!(prepared.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(halo_add_lines_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLdsLimit);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(halo_add_lines_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLdsLimit);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(halo_add_lines_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFftLdsLimit);
         if (e != hipSuccess) return e;
         prepared.fetch_or(bit, std::memory_order_relaxed);
     }
@@ -724,9 +748,9 @@ static hipError_t launch_halo_add_lines_t(void* grid, const void* halo, int64_t 
 }
 
 hipError_t launch_halo_add_lines(int dtype, void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, int n1cells, int ny, int nz,
-                                 int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream) {
-    return dtype == NUFFT_F32 ? launch_halo_add_lines_t<float>(grid, halo, grid_comp_reals, halo_comp_reals, n1cells, ny, nz, C, h, flag, stream)
-                              : launch_halo_add_lines_t<double>(grid, halo, grid_comp_reals, halo_comp_reals, n1cells, ny, nz, C, h, flag, stream);
+                                 int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream, bool planar) {
+    return dtype == NUFFT_F32 ? launch_halo_add_lines_t<float>(grid, halo, grid_comp_reals, halo_comp_reals, n1cells, ny, nz, C, h, flag, stream, planar)
+                              : launch_halo_add_lines_t<double>(grid, halo, grid_comp_reals, halo_comp_reals, n1cells, ny, nz, C, h, flag, stream, planar);
 }
 
 hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
@@ -734,8 +758,8 @@ hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in,
     CplxLineArgs a{};
     a.in = in; a.out = out; a.nlines = nlines; a.k1 = k1; a.map = map; a.twiddle = twiddle;
     if (halo && halo->buffer && forward) {
-        if (halo->layout.nc != 2 || halo->ny <= 0) return hipErrorInvalidValue;
-        a.halo = halo->buffer; a.hflag = halo->flag; a.ny = halo->ny; a.hl = halo->layout;
+        if (halo->layout.nc != (halo->buffer2 ? 1 : 2) || halo->ny <= 0 || (halo->buffer2 && (n & 1))) return hipErrorInvalidValue;
+        a.halo = halo->buffer; a.halo2 = halo->buffer2; a.hflag = halo->flag; a.ny = halo->ny; a.hl = halo->layout;
     }
     if (dtype == NUFFT_F32) return forward ? launch_cplx_t<float, true>((int)n, a, stream) : launch_cplx_t<float, false>((int)n, a, stream);
     return forward ? launch_cplx_t<double, true>((int)n, a, stream) : launch_cplx_t<double, false>((int)n, a, stream);

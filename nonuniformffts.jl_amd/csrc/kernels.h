@@ -158,7 +158,7 @@ hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* so
 // ---- spreading on the z-marching LDS ring (smarch_kernels.h, smarch_*.hip) -------------------------------------------
 // 3-D plans with 4-cell bins and the default window evaluation whose axes are long enough; cus: compute units, C: components
 // halo: 0 = output-driven in x and y; 2 = the halo variant (real data, grids the column divides; falls back to 0 where it cannot run)
-SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo);
+SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo, int parts = 1);
 hipError_t prepare_spread_march(int dtype, int is_complex, int M, int halo);
 // flag: device flag of set_points (1: the ring serves this point set); tasktab: its task table
 hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream);
@@ -208,6 +208,8 @@ bool real_lines_supported(int dtype, int64_t n);
 // planes of ny rows), added to every line while it is loaded — when *flag != 0 (the ring served the point set)
 struct RealLineHalo {
     const void* buffer;
+    const void* buffer2;       // complex lines, data spread part by part by the real kernel: planar side buffers of the real (buffer) and
+                               // imaginary parts (buffer2), layout.nc = 1; null: one interleaved buffer (layout.nc = 2) / real lines
     const uint32_t* flag;
     int ny;
     HaloLayout layout;
@@ -217,7 +219,7 @@ hipError_t launch_real_lines(int dtype, int64_t n, bool forward, const void* in,
 hipError_t launch_fft_lines(int dtype, int64_t n, bool forward, const FftLinePass& p, hipStream_t stream);
 // grid += side buffer of the spreading window's halo variant, line by line (C components; lines of n1cells cells, planes of ny lines)
 hipError_t launch_halo_add_lines(int dtype, void* grid, const void* halo, int64_t grid_comp_reals, int64_t halo_comp_reals, int n1cells, int ny, int nz,
-                                 int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream);
+                                 int C, const HaloLayout& h, const uint32_t* flag, hipStream_t stream, bool planar = false);
 // c2c of `nlines` contiguous complex lines of length n with a compact spectrum of k1 kept modes (map: kept -> FFT index)
 hipError_t launch_cplx_lines(int dtype, int64_t n, bool forward, const void* in, void* out, int64_t nlines, int k1,
                              const int32_t* map, const void* twiddle, hipStream_t stream, const RealLineHalo* halo = nullptr);

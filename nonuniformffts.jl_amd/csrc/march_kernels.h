@@ -40,6 +40,9 @@ struct MarchGeom {
     int n1, n2;                     // spreading ring (smarch_kernels.h): the column chosen for this grid (<= its compile-time one)
     void* halo;                     // ... its halo variant: side buffer of the stencil reach (reals), component stride in reals
     int64_t halo_comp;
+    int parts;                      // spreading ring, complex data through the real kernel (smarch_kernels.h): 2 = blockIdx.y counts (component,
+                                    // part) pairs — part 0 / 1 spreads the real / imaginary parts of the values into the real / imaginary
+                                    // parts of the interleaved grid (value and cell stride 2 reals); 0 / 1: plain components
     const uint32_t* coarse_a;       // interpolation ring on plans of the column-layer sort (CoarseSort, kernels.h): both nonzero = this point set
     const uint32_t* coarse_b;       // is column-layer sorted — interp_march_staged_kernel serves it, interp_march_kernel returns (null: no such plan)
 };
@@ -103,7 +106,18 @@ struct MarchCfg {
     static constexpr int ZP = (REGW && GP::G == 16 && L == 16) ? NUFFT_MARCH_ZP : 1;   // (measured: M = 5..7 lose 6-17 % with their 10-14 of 16 lanes)
     static constexpr int PPW = GP::PPW / ZP;            // points per wave pass
     static constexpr int ROW_BYTES = GP::G * (PAIR ? 2 : 1) * (int)sizeof(T);
+    // Staged kernel, Float64 real data, one row of G lanes per point: the records of a chunk are put in BANK order, not bin order — the 32-lane
+    // LDS group of a 64-bit read holds 32 / G points whose G-lane rows (64 or 128 bytes) collide unless their start addresses differ by
+    // exact multiples of the row's bytes; with points of one bin (or in any spatial order) they almost never do, and half of the gather's
+    // LDS array cycles are conflicts (profiles/round4_sq_counters.md, round5_c_*_sq.json: SQ_LDS_BANK_CONFLICT 2.1e8 of 4.2e8).  The start
+    // address of a point's rows is (s0 + RS s1) reals modulo the 32-real bank period — the same for every stencil row and plane once the
+    // plane stride is a multiple of the period — so points with equal phase modulo G and distinct phase / G form conflict-free groups.
+#ifndef NUFFT_STAGED_BANK_ORDER
+#define NUFFT_STAGED_BANK_ORDER 0
+#endif
+    static constexpr bool BANK_ORDER = STG && NUFFT_STAGED_BANK_ORDER && sizeof(T) == 8 && !CPLX && REGW && ZP == 1 && (GP::G == 8 || GP::G == 16);
     static constexpr int pad_plane(int ps) {            // plane stride in reals: = ROW_BYTES (mod 2 ROW_BYTES) bytes
+        if (BANK_ORDER) return (ps + 31) / 32 * 32;     // a whole number of bank periods: the phase of a point is the same in every plane
         if (ZP == 1) return ps;
         const int b = ps * (int)sizeof(T), m = 2 * ROW_BYTES;
         return ps + ((ROW_BYTES - b % m + m) % m) / (int)sizeof(T);
@@ -297,22 +311,46 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY, true>::THREADS)) void i
             r0 = __builtin_bit_cast(T, v[0]);
             r1 = __builtin_bit_cast(T, v[1]);
         }
-        const int bx = (cell_of(r0, g.Nover[0]) - org1) >> 2, by = (cell_of(r1, g.Nover[1]) - org2) >> 2;
+        const int s0 = cell_of(r0, g.Nover[0]) - org1, s1 = cell_of(r1, g.Nover[1]) - org2;
 #ifdef NUFFT_STAGED_NOSORT
         return 0;                                       // (ablation build: the records stay in arrival order)
 #endif
-        return ((bx >> C::KSX) + (by >> C::KSY) * C::KNX) & 63;
+        if constexpr (C::BANK_ORDER) {
+            // key = (phase mod G) (32 / G) + phase / G: the sub-classes of one alignment class are neighbouring keys
+            const int t = (s0 + s1 * RS) & 31;
+            return (t % GP::G) * (32 / GP::G) + t / GP::G;
+        }
+        return (((s0 >> 2) >> C::KSX) + ((s1 >> 2) >> C::KSY) * C::KNX) & 63;
     };
     // counting sort, second half: start of every key from the counters (each wave scans them for itself), then the piece goes to its place
     auto place_piece = [&](const U4& v, int key, uint32_t rank, int n, const uint32_t* cn) __attribute__((always_inline)) {
         const uint32_t c = cn[lane];
+        uint32_t dest;
+        if constexpr (C::BANK_ORDER) {
+            // alignment class = Q neighbouring keys (its Q sub-classes): the first m = min count records of every sub-class interleave into
+            // conflict-free groups [class][rank][sub-class]; what is left over follows behind all groups, in key order
+            constexpr int Q = 32 / GP::G;
+            uint32_t m = min(c, (uint32_t)__shfl_xor((int)c, 1, kWave));
+            if constexpr (Q == 4) m = min(m, (uint32_t)__shfl_xor((int)m, 2, kWave));
+            uint32_t qi = (lane % Q == 0) ? Q * m : 0u, li = c - m;
+            const uint32_t q0 = qi, l0 = li;
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t tq = __shfl_up(qi, o, kWave), tl = __shfl_up(li, o, kWave);
+                if (lane >= o) { qi += tq; li += tl; }
+            }
+            const uint32_t nquad = (uint32_t)__builtin_amdgcn_readlane((int)qi, kWave - 1);
+            const uint32_t mk = (uint32_t)__shfl((int)m, key, kWave);
+            const uint32_t qb = (uint32_t)__shfl((int)(qi - q0), key & ~(Q - 1), kWave), lb = (uint32_t)__shfl((int)(li - l0), key, kWave);
+            dest = rank < mk ? qb + Q * rank + (uint32_t)(key & (Q - 1)) : nquad + lb + (rank - mk);
+        } else {
         uint32_t incl = c;
         for (int o = 1; o < kWave; o <<= 1) {
             const uint32_t t = __shfl_up(incl, o, kWave);
             if (lane >= o) incl += t;
         }
         const uint32_t start = __shfl(incl - c, key, kWave);
-        uint32_t dest = start + rank;
+        dest = start + rank;
+        }
         if constexpr (PIECES > 1) dest = __shfl(dest, lane & ~(PIECES - 1), kWave);       // the record's other pieces follow its first
         if (myrec < n) *reinterpret_cast<U4*>(stage + (size_t)dest * C::REC_BYTES + mysub * 16) = v;
     };

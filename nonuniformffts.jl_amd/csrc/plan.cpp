@@ -149,8 +149,19 @@ static int env_int(const char* name, int fallback) {
 // ComplexF32 m = 2, 3 (2.55 -> 1.97, 4.03 -> 3.51); with 16 x 16 columns the reach is 1.2 x the grid (ComplexF64 m = 3: 4.70 -> 5.08 ms).
 static int smarch_halo_default(const nufft_plan* p) {      // (build_device: ... and only on the plan's own pruned FFT path)
     if (p->D != 3) return 0;
-    if (!p->is_complex) return 2;
+    if (!p->is_complex || p->smarch_parts == 2) return 2;      // (complex data part by part through the real kernel: as real data)
     return p->M <= (p->dtype == NUFFT_F32 ? 3 : 2) ? 2 : 0;
+}
+
+// Largest half-support for which the automatic choice takes the marching window (measured spread + FFT stages):
+// real data 6 (Float32 with the halo variant: 7); complex data part by part through the real kernel: 6 — measured round 5, 256^3 -> 512^3,
+// Np = 1e7, spread + FFT stages in ms, window against patches: ComplexF64 m = 4 5.46 / 6.31 (interleaved window), m = 5 9.87 / 14.30, m = 6 14.47 / 24.88,
+// m = 7 24.10 / 24.29; ComplexF32 m = 4 4.65 / 5.61, m = 5 8.78 / 9.94, m = 6 13.08 / 15.08, m = 7 20.67 / 14.94; the interleaved complex
+// instantiations (NUFFT_SMARCH_SPLIT=0): ComplexF64 4, ComplexF32 3
+static int ring_max_half_support(const nufft_plan* p) {
+    if (!p->is_complex) return (p->dtype == NUFFT_F32 && p->smarch.halo == 2) ? 7 : 6;
+    if (p->smarch.parts == 2 && p->smarch.halo == 2) return 6;
+    return p->dtype == NUFFT_F64 ? 4 : 3;
 }
 
 static int build_host(nufft_plan* p, const nufft_params* in) {
@@ -386,15 +397,25 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         // 4.71 against 4.10 patches).  256 CUs assumed here, build_device() redoes the decomposition for the device.
         // halo variant of the ring (every point spread once, the stencil reach through a side buffer that the first FFT pass adds):
         // real data on grids whose axes the column divides; NUFFT_SMARCH_HALO=0 / 2 forces the choice (A/B runs, tests)
+        // complex data part by part through the REAL window kernel (smarch_kernels.h: 8 x 8 faces, 32 x 32 columns, halo variant — ComplexF64
+        // m = 4: 5.06 -> 3.9 ms); NUFFT_SMARCH_SPLIT=0: the interleaved complex instantiations (A/B runs, tests)
+        p->smarch_parts = (p->is_complex && env_int("NUFFT_SMARCH_SPLIT", 1) != 0) ? 2 : 1;
         const int want_halo = env_int("NUFFT_SMARCH_HALO", smarch_halo_default(p)) == 2 ? 2 : 0;
-        p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, want_halo);
+        p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, want_halo, p->smarch_parts);
         if (!p->smarch.eligible && want_halo)
-            p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, 0);
+            p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, 0, p->smarch_parts);
+        if (!p->smarch.eligible && p->smarch_parts == 2) {      // no real-kernel decomposition: the complex instantiations as before
+            p->smarch_parts = 1;
+            const int wh = env_int("NUFFT_SMARCH_HALO", smarch_halo_default(p)) == 2 ? 2 : 0;
+            p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, wh, 1);
+            if (!p->smarch.eligible && wh)
+                p->smarch = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, 0, 1);
+        }
         if (req == NUFFT_SPREAD_MARCHING_RING && !p->smarch.eligible)
             return fail(NUFFT_ERR_UNSUPPORTED, "spread_method = marching ring needs a 3-D grid of 4-cell bins with every oversampled axis a multiple "
                                                "of 4 and longer than a column plus a stencil, and the default window evaluation");
         // (with the halo variant the window also beats the patches for Float32 at M = 7: 10.8 against 12.8 ms spread + FFT)
-        const int ring_max_m = !p->is_complex ? ((p->dtype == NUFFT_F32 && p->smarch.halo == 2) ? 7 : 6) : (p->dtype == NUFFT_F64 ? 4 : 3);
+        const int ring_max_m = ring_max_half_support(p);
         const bool prefer_ring = env_int("NUFFT_PREFER_RING", 1) != 0 && p->M <= ring_max_m && env_int("NUFFT_PREFER_PATCHES", 0) == 0;
         if (p->smarch.eligible && (req == NUFFT_SPREAD_MARCHING_RING || (req == NUFFT_SPREAD_AUTO && prefer_ring)))
             p->spread_method = NUFFT_SPREAD_MARCHING_RING;
@@ -618,11 +639,11 @@ static int build_device(nufft_plan* p) {
         // the side buffer (0.52 x the grid per component at 32 x 32 columns, m = 4) is workspace the clipped columns do not need: when it
         // does not fit, the plan keeps the ring without it instead of failing
         for (;;) {
-            p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), other, p->num_cus, p->C, want_halo);
+            p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), other, p->num_cus, p->C, want_halo, p->smarch_parts);
             if (!p->smarch.eligible && want_halo)
-                p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), other, p->num_cus, p->C, 0);
+                p->smarch = smarch_plan(p->dtype, p->is_complex, D, p->M, make_geom(p), other, p->num_cus, p->C, 0, p->smarch_parts);
             if (!p->smarch.eligible || p->smarch.halo != 2) break;
-            const size_t bytes = (size_t)p->smarch.halo_reals * real_bytes(p) * p->C;
+            const size_t bytes = (size_t)p->smarch.halo_reals * real_bytes(p) * p->C * p->smarch.parts;
             // (NUFFT_TEST_HALO_ALLOC_FAIL=1: the test of this fallback)
             if (!env_int("NUFFT_TEST_HALO_ALLOC_FAIL", 0) && hipMalloc(&p->d_smarch_halo, bytes) == hipSuccess) { p->workspace_bytes += (int64_t)bytes; break; }
             (void)hipGetLastError();
@@ -631,7 +652,7 @@ static int build_device(nufft_plan* p) {
         }
         // build_host chose the engine for 256 CUs and the halo variant it hoped for: redo the automatic choice for what this device got
         // (Float32 m = 7 belongs to the ring only with the halo variant: 20.1 ms clipped against 13.4 ms with the patches)
-        const int ring_max_m = !p->is_complex ? ((p->dtype == NUFFT_F32 && p->smarch.halo == 2) ? 7 : 6) : (p->dtype == NUFFT_F64 ? 4 : 3);
+        const int ring_max_m = ring_max_half_support(p);
         const bool keep = p->smarch.eligible && (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING || p->M <= ring_max_m);
         if (!keep) {
             if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING)
@@ -643,7 +664,7 @@ static int build_device(nufft_plan* p) {
         }
     }
     if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
-        NUFFT_HIP(prepare_spread_march(p->dtype, p->is_complex, p->M, p->smarch.halo));
+        NUFFT_HIP(prepare_spread_march(p->dtype, p->smarch.parts == 2 ? 0 : p->is_complex, p->M, p->smarch.halo));
         const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_smarch_choice), 16 * sizeof(uint32_t)))) return rc;
         NUFFT_HIP(hipMemset(p->d_smarch_choice, 0, 16 * sizeof(uint32_t)));
@@ -839,7 +860,7 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
     if (fuse) {
         hh.flag = p->d_smarch_choice + 2;
         hh.ny = (int)p->Nover[1];
-        hh.layout = make_halo_layout(p->smarch.n1, p->smarch.n2, p->M, p->is_complex ? 2 : 1, p->smarch.ct.ncolx, p->smarch.ct.ncoly);
+        hh.layout = make_halo_layout(p->smarch.n1, p->smarch.n2, p->M, (p->is_complex && p->smarch.parts != 2) ? 2 : 1, p->smarch.ct.ncolx, p->smarch.ct.ncoly);
     }
     if (p->is_complex) {
         int64_t per = 1;
@@ -848,7 +869,8 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
         for (int c = 0; c < p->C; ++c) {
             const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * cb;
             void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * cb;
-            hh.buffer = static_cast<char*>(p->d_smarch_halo) + (size_t)c * p->smarch.halo_reals * real_bytes(p);
+            hh.buffer = static_cast<char*>(p->d_smarch_halo) + (size_t)c * p->smarch.parts * p->smarch.halo_reals * real_bytes(p);
+            hh.buffer2 = p->smarch.parts == 2 ? static_cast<const char*>(hh.buffer) + (size_t)p->smarch.halo_reals * real_bytes(p) : nullptr;      // (planar: real parts, then imaginary parts)
             NUFFT_HIP(launch_cplx_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], p->d_index_map[0], p->d_tw_fw[0], stream,
                                         fuse ? &hh : nullptr));
         }
@@ -1230,7 +1252,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING) advantage = 0.0;
         const size_t ncols = (size_t)p->smarch.ct.ncolx * p->smarch.ct.ncoly;
         // (the C components are independent workgroups of one launch: each component has num_cus / C compute units' worth of the chip)
-        NUFFT_HIP(launch_smarch_tasks(s.g, p->smarch, p->d_offsets, np, std::max(1, p->num_cus / p->C), advantage, p->d_smarch_choice, p->bal.d_slots, p->d_smarch_cols,
+        NUFFT_HIP(launch_smarch_tasks(s.g, p->smarch, p->d_offsets, np, std::max(1, p->num_cus / (p->C * p->smarch.parts)), advantage, p->d_smarch_choice, p->bal.d_slots, p->d_smarch_cols,
                                       p->d_smarch_cols + ncols, static_cast<uint2*>(p->d_smarch_tasks), stream));
     }
     if (p->interp_march) {

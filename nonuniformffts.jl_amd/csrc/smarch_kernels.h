@@ -35,6 +35,14 @@
 // (Round 4b accumulated the reach with global float atomics onto zeroed bands of the grid instead: 1.2e8 atomics per launch at
 // 66 G/s — 3.71 + 0.31 ms against 2.44 ms; with plain stores the same kernel took 1.94 ms.)
 //
+// Complex data through the real kernel (MarchGeom::parts = 2; round 5).  The complex instantiations accumulate (component, j1, j2)
+// faces: 128 lanes = two wave instructions per plane at M = 4, and the interleaved window halves the column (ComplexF64 m = 4: 5.06 ms
+// against 1.87 ms for real data).  Real and imaginary parts are independent real transforms of the same points, so a complex plan
+// can run the REAL kernel twice per component — blockIdx.y = 2 component + part — reading the part's half of every value (stride 2
+// reals) and storing the part's half of every cell of the interleaved grid (two 8-byte stores instead of one 16-byte store per
+// pair); the side buffer of the halo variant stays planar, one per (component, part), and its consumers add it to the real or
+// imaginary parts of the lines (fft_lines.hip).  The 8 x 8-face FAST path, the 32 x 32 column and the halo variant of real data carry over.
+//
 // Tasks: column x segment of bin layers from the table set_points builds per point set on the device (balance.hip):
 // equal-length segments for uniform sets, column quantiles otherwise; point sets whose heaviest task would hold the chip
 // up — and grids with too few columns — go to spread_tile_kernel, which shares heavy tiles between workgroups (device
@@ -221,7 +229,10 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     const Geom& g = a.g;
     const int task = xcd_remap_chunked((int)blockIdx.x, (int)gridDim.x, a.xcd_chunk);
     if (task >= mg.ntasks) return;
-    const int comp_id = blockIdx.y;
+    // (complex data through this real kernel: blockIdx.y = 2 component + part, see the header)
+    const bool split = !CPLX && mg.parts == 2;
+    const int comp_id = split ? (int)blockIdx.y >> 1 : (int)blockIdx.y, part = split ? (int)blockIdx.y & 1 : 0;
+    const int vgs = split ? 2 : 1;                      // reals between consecutive values / cells of this part
     const uint2 te = mg.tasktab[task];
     const int tx = (int)te.x % mg.ntx, ty = (int)te.x / mg.ntx;
     const int zb0 = (int)(te.y & 0xffffu), zb1 = (int)(te.y >> 16);
@@ -294,8 +305,8 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         lane_addr[ps] = ring_base + (uint32_t)((j1f[ps] * NC + cmpf[ps] + j2f[ps] * RS) * 8);
     }
     const PointRec<T, 3>* sorted = static_cast<const PointRec<T, 3>*>(a.sorted);
-    const T* vin = a.vin[comp_id];
-    T* grid = a.grid[comp_id];
+    const T* vin = a.vin[comp_id] + part;
+    T* grid = a.grid[comp_id] + part;
     // halo variant: the side buffer's records (columns of mg.n1 x mg.n2 cells: the plan takes it only for grids they divide)
     const HaloLayout hl = make_halo_layout(mg.n1, mg.n2, M, NC, mg.ntx, mg.nty);
     __syncthreads();
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
 #if NUFFT_SMARCH_ABL == 6
                 return T(r.idx);
 #endif
-                v = vin[(int64_t)r.idx * NC + (FAST ? 0 : q)];
+                v = vin[(int64_t)r.idx * (NC * vgs) + (FAST ? 0 : q)];
                 if (a.weights) v *= a.weights[r.idx];   // callbacks.nonuniform(v, n), src/spreading/gpu.jl:289
             }
             return v;
@@ -545,20 +556,26 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                     const int lx = 2 * xp / NC - C::XLO, ly = r - C::YLO;          // relative to the column's first cell
                     T* dst0;
                     int64_t pstride;                                               // reals between consecutive planes
+                    bool to_grid = true;
                     if ((HX || HY) && (lx < 0 || lx >= neff1 || ly < 0 || ly >= neff2)) {
-                        dst0 = static_cast<T*>(mg.halo) + (int64_t)comp_id * mg.halo_comp + (int64_t)(4 * zb0) * hl.plane +
+                        // (one planar side buffer per launch row: blockIdx.y = component, or (component, part) for split complex data)
+                        dst0 = static_cast<T*>(mg.halo) + (int64_t)blockIdx.y * mg.halo_comp + (int64_t)(4 * zb0) * hl.plane +
                                ((int64_t)ty * mg.ntx + tx) * hl.rec + halo_record_offset(hl, 2 * xp, ly);
                         pstride = hl.plane;
+                        to_grid = false;
                     } else {
                         const int gx = wrap_index(org1 + lx, g.Nover[0]), gy = wrap_index(org2 + ly, g.Nover[1]);
-                        pstride = (int64_t)g.Nover[1] * g.Nover[0] * NC;
-                        dst0 = grid + (int64_t)(4 * zb0) * pstride + ((int64_t)gy * g.Nover[0] + gx) * NC + (2 * xp) % NC;
+                        pstride = (int64_t)g.Nover[1] * g.Nover[0] * (NC * vgs);
+                        dst0 = grid + (int64_t)(4 * zb0) * pstride + (((int64_t)gy * g.Nover[0] + gx) * NC + (2 * xp) % NC) * vgs;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int qq = wq + k;
-                        if (qq >= 0 && qq < nq)         // (plane 4 zb0 + qq < Nover[2]: the task owns it)
-                            *reinterpret_cast<T2*>(dst0 + (int64_t)qq * pstride) = T2{(T)v[k].x, (T)v[k].y};
+                        if (qq >= 0 && qq < nq) {       // (plane 4 zb0 + qq < Nover[2]: the task owns it)
+                            T* d = dst0 + (int64_t)qq * pstride;
+                            if (split && to_grid) { d[0] = (T)v[k].x; d[2] = (T)v[k].y; }      // this part of two neighbouring complex cells
+                            else *reinterpret_cast<T2*>(d) = T2{(T)v[k].x, (T)v[k].y};
+                        }
                     }
 #else
 #pragma unroll

@@ -130,11 +130,16 @@ static double smarch_makespan(const std::vector<double>& task_work, int C, int c
 // (multiples of the bin edge) and the number of segments along z that minimise  point visits / chip utilisation,
 // where visits = prod (n + 2M - 1) / n over x, y (partial last columns counted) x (segl + c_z) / segl for the layers a
 // segment visits beyond its own, and the utilisation comes from the launch model above.
-SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo) {
+SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo, int parts) {
     SMarchPlan sp{};
     int lds = 0, n[5];
     if (halo != 2) halo = 0;
     sp.halo = halo;
+    sp.parts = (parts == 2 && is_complex) ? 2 : 1;
+    if (sp.parts == 2) {            // complex data as two real transforms of the same points: the real kernel, twice the launch rows
+        is_complex = 0;
+        C *= 2;
+    }
     if (D != 3 || other || !smarch_kernel(dtype, is_complex, M, halo, true, &lds, n)) return sp;
     const bool hx = halo == 2, hy = halo == 2;
     const int xreach = hx ? (M - 1) + ((M - 1) & 1) + M : 0, yreach = hy ? 2 * M - 1 : 0;
@@ -211,6 +216,7 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
     return sp;
 }
 
+// (is_complex = 0 for complex plans whose SMarchPlan::parts is 2)
 hipError_t prepare_spread_march(int dtype, int is_complex, int M, int halo) {
     for (int poly = 0; poly < 2; ++poly) {
         int lds = 0, n[5];
@@ -600,7 +606,8 @@ hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np
 template <typename T>
 static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
     int lds = 0, n[5];
-    const void* fn = smarch_kernel(a.dtype, a.is_complex, a.M, sp.halo, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
+    const int parts = (sp.parts == 2 && a.is_complex) ? 2 : 1;      // complex data part by part through the real kernel
+    const void* fn = smarch_kernel(a.dtype, parts == 2 ? 0 : a.is_complex, a.M, sp.halo, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
     if (!fn) return hipErrorInvalidValue;
     if (sp.halo == 2 && !a.halo) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
@@ -616,10 +623,11 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
         mg.tasktab = tasktab;
         mg.n1 = sp.n1;
         mg.n2 = sp.n2;
-        mg.halo = sp.halo == 2 ? static_cast<void*>(static_cast<T*>(a.halo) + (int64_t)c0 * sp.halo_reals) : nullptr;
+        mg.halo = sp.halo == 2 ? static_cast<void*>(static_cast<T*>(a.halo) + (int64_t)c0 * parts * sp.halo_reals) : nullptr;
         mg.halo_comp = sp.halo_reals;
+        mg.parts = parts;
         void* params[] = {&k, &mg};
-        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)n[4], 1, 1), params, (size_t)lds, stream);
+        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)mg.ntasks, (unsigned)(nc * parts), 1), dim3((unsigned)n[4], 1, 1), params, (size_t)lds, stream);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -631,6 +639,11 @@ hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp,
     if (sp.halo != 2) return hipSuccess;
     if (!a.halo) return hipErrorInvalidValue;
     const int ncr = a.is_complex ? 2 : 1;
+    if (sp.parts == 2 && a.is_complex) {
+        // planar side buffers of the real and imaginary parts (complex data through the real kernel) onto the interleaved grid
+        const HaloLayout h = make_halo_layout(sp.n1, sp.n2, a.M, 1, sp.ct.ncolx, sp.ct.ncoly);
+        return launch_halo_add_lines(a.dtype, a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g.Nover[0], a.g.Nover[1], a.g.Nover[2], a.C, h, flag, stream, true);
+    }
     // line by line through LDS (fft_lines.hip: 0.6 ms at C2); the element-wise gather kernel (1.5 ms) where a line does not fit
     static const bool gather = [] { const char* e = std::getenv("NUFFT_SMARCH_HALO_ADD_GATHER"); return e && *e && std::atoi(e) != 0; }();
     if (!gather) {

@@ -272,7 +272,7 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
         den += float(exact.abs() ** 2)
     # Float32 data: the bound is the Float32 round-off of coordinates (k x with |k| <= 256 and x in Float32: 256 * 2 pi * 6e-8 = 1e-4 of a
     # radian per point, random in sign) and of sums over 1e8 Float32 terms, not the m = 8 window (1e-14): 256 random modes.  Measured
-    # 2e-5 ... 3e-5 (printed); the bar is 5e-5 — the reference's own Float32 criterion is 1e-5 against its Float32 CPU path, which
+    # 3.2e-5 for both types (printed; round 5); the bar is 5e-5 — the reference's own Float32 criterion is 1e-5 against its Float32 CPU path, which
     # shares the coordinate rounding, while this is against exact Float64 sums (the dense 128^3 case below holds 1e-5 against the C oracle)
     e1 = np.sqrt(num / den)
     print(f"C3 full size: type 1 rel-L2 over 256 modes vs exact sums {e1:.2e} (largest deviation {max(errs):.3e})")

@@ -448,7 +448,10 @@ def test_spreading_ring_every_instantiation(Z, M, monkeypatch):
     concentrated in a corner exercises the tasks of equal point count (quantile segments, empty tasks that only store zeros)."""
     dims, Np = (48, 40, 56), 4000
     monkeypatch.setenv("NUFFT_SMARCH_HALO", "0")
-    for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
+    # complex data: part by part through the real kernel (the default), and the interleaved complex instantiations (NUFFT_SMARCH_SPLIT=0)
+    cases = [(e, "1") for e in (O.FAST_APPROXIMATION, O.DIRECT)] + ([(O.FAST_APPROXIMATION, "0"), (O.DIRECT, "0")] if np.dtype(Z).kind == "c" else [])
+    for evalmode, split in cases:
+        monkeypatch.setenv("NUFFT_SMARCH_SPLIT", split)
         if np.dtype(Z) == np.complex128 and M == 10:
             # the LDS tiles of this plan need 2-cell bins (plan_math.cpp); the ring, like the patches, sorts by 4-cell bins
             nufft, plan, *_ = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=300 + M)
@@ -473,6 +476,18 @@ def test_spreading_ring_every_instantiation(Z, M, monkeypatch):
 @pytest.mark.parametrize("M", range(2, 11))
 @pytest.mark.parametrize("Z,C", [(np.float32, 1), (np.float64, 1), (np.float64, 2), (np.complex64, 1), (np.complex128, 1)])
 def test_spreading_ring_halo_variant_every_instantiation(Z, C, M, monkeypatch):
+    _ring_halo_variant_case(Z, C, M, monkeypatch, split=True)
+
+
+@pytest.mark.parametrize("M", range(2, 6))
+@pytest.mark.parametrize("Z", [np.complex64, np.complex128])
+def test_spreading_ring_halo_variant_interleaved_complex_instantiations(Z, M, monkeypatch):
+    """The complex instantiations of the halo variant (interleaved window; NUFFT_SMARCH_SPLIT=0) — by default complex data runs part by
+    part through the real kernel (the test above)."""
+    _ring_halo_variant_case(Z, 1, M, monkeypatch, split=False)
+
+
+def _ring_halo_variant_case(Z, C, M, monkeypatch, split):
     """The halo variant of spread_march_kernel (every point spread once by its own column, the stencil's reach beyond
     the column through a side buffer) for every M, both window evaluations, against the oracle — three consumers of the side
     buffer: the plan's own dimension-1 FFT pass (exec_type1), the separate add pass in front of the FFT
@@ -486,13 +501,14 @@ def test_spreading_ring_halo_variant_every_instantiation(Z, C, M, monkeypatch):
     if np.dtype(Z) == np.complex128 and M == 10:
         pytest.skip("2-cell bins: no ring (test_spreading_ring_every_instantiation)")
     monkeypatch.setenv("NUFFT_SMARCH_HALO", "2")
+    monkeypatch.setenv("NUFFT_SMARCH_SPLIT", "1" if split else "0")
     for evalmode, fuse in ((O.FAST_APPROXIMATION, "1"), (O.DIRECT, "1"), (O.FAST_APPROXIMATION, "0")):
         monkeypatch.setenv("NUFFT_SMARCH_HALO_FUSE", fuse)
         nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, C, Np, seed=500 + M, spread_method="marching_ring")
         info = plan.info()
         assert info.spread_method == 3 and info.ring_column[0] > 0
         assert 96 % info.ring_column[0] == 0 and 96 % info.ring_column[1] == 0 or info.ring_halo == 0
-        if M <= (7 if is_real else 5):
+        if M <= (7 if (is_real or split) and not (np.dtype(Z) in (np.dtype(np.float64), np.dtype(np.complex128)) and M > 7) else 5):
             assert info.ring_halo == 1, (M, list(info.ring_column))
         dev = plan.device
         for name in ("uniform", "corner"):
