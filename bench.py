@@ -624,6 +624,17 @@ def main():
                     result["config"][f"{name}_{k}"] = r[k]
     if full and a.config == "c2" and not a.no_reference_protocol:
         result["reference_protocol"] = reference_protocol(cfg, nufft, dev, sweep=not a.no_density_sweep)
+        torch.cuda.empty_cache()
+        try:       # the reference's default element type, next to its published ComplexF64 table (tests/golden/reference_dat.json: ComplexF64_ROC_shared)
+            result["reference_protocol_complexf64"] = reference_protocol(cfg, nufft, dev, sweep=not a.no_density_sweep, complex_data=True)
+            rp = result["reference_protocol_complexf64"]
+            result["config"]["refproto_c128_type1_value"] = rp["type1_pts_per_s"]
+            result["config"]["refproto_c128_type2_value"] = rp["type2_pts_per_s"]
+        except Exception as exc:
+            result["reference_protocol_complexf64"] = {"error": repr(exc)}
+        rp = result["reference_protocol"]
+        result["config"]["refproto_f64_type1_value"] = rp["type1_pts_per_s"]
+        result["config"]["refproto_f64_type2_value"] = rp["type2_pts_per_s"]
     if rank == 0 and full and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
@@ -641,7 +652,7 @@ def published_rows():
         return {}
 
 
-def reference_protocol(cfg, nufft, dev, sweep=True):
+def reference_protocol(cfg, nufft, dev, sweep=True, complex_data=False):
     """The reference's published benchmark protocol, for comparison with BASELINE.md (not the headline metric):
     sigma = 1.5, BackwardsKaiserBessel with Direct() evaluation (the ROC defaults), coordinates ~ N(0, 1) folded
     into the period, time = set_points! + exec! + sync, median over repetitions
@@ -649,15 +660,18 @@ def reference_protocol(cfg, nufft, dev, sweep=True):
     next to the rows the reference published for MI300A (tests/golden/reference_dat.json)."""
     n, m = cfg["n"], cfg["m"]
     dims = (n, n, n)
-    plan = nufft.PlanNUFFT(torch.float64, dims, m=m, sigma=1.5, kernel_evalmode=nufft.Direct(), backend=nufft.ROCBackend(dev.index or 0))
+    Zt = torch.complex128 if complex_data else torch.float64      # (ComplexF64 is the reference's default element type)
+    plan = nufft.PlanNUFFT(Zt, dims, m=m, sigma=1.5, kernel_evalmode=nufft.Direct(), backend=nufft.ROCBackend(dev.index or 0))
     u = torch.empty(plan.shape, dtype=torch.complex128, device=dev)
-    pub = {r["Np"]: r for r in published_rows().get("Float64_ROC_shared", {}).get("rows", [])}
+    pub = {r["Np"]: r for r in published_rows().get("ComplexF64_ROC_shared" if complex_data else "Float64_ROC_shared", {}).get("rows", [])}
 
     def run(Np, reps):
         g = torch.Generator(device=dev).manual_seed(4242)
         xs = tuple(torch.randn(Np, dtype=torch.float64, device=dev, generator=g) for _ in dims)
         v = torch.randn(Np, dtype=torch.float64, device=dev, generator=g)
-        out = torch.empty(Np, dtype=torch.float64, device=dev)
+        if complex_data:
+            v = torch.complex(v, torch.randn(Np, dtype=torch.float64, device=dev, generator=g))
+        out = torch.empty(Np, dtype=Zt, device=dev)
         res = {}
         for name, fn in (("type1", lambda: nufft.exec_type1(u, plan, v)), ("type2", lambda: nufft.exec_type2(out, plan, u))):
             nufft.set_points(plan, xs); fn()
@@ -674,11 +688,14 @@ def reference_protocol(cfg, nufft, dev, sweep=True):
 
     Np = int(cfg["np"])
     res = run(Np, 10)
-    res["config"] = f"Ns={n}^3, Np={Np:.0e} ~ N(0,1) folded, Float64, m={m}, sigma=1.5 (oversampled {plan.oversampled_dims}), Direct window, set_points! + exec! + sync, median of 10"
-    res["published_mi300a_pts_per_s"] = {"type1": "2.4e8-2.7e8", "type2": "6.2e8-9.6e8", "source": "BASELINE.md (Np = 1.7e7 ... 1.7e8)"}
+    res["config"] = (f"Ns={n}^3, Np={Np:.0e} ~ N(0,1) folded, {'ComplexF64' if complex_data else 'Float64'}, m={m}, sigma=1.5 (oversampled {plan.oversampled_dims}), "
+                     "Direct window, set_points! + exec! + sync, median of 10")
+    res["published_mi300a_pts_per_s"] = ({"type1": "1.88e8-2.50e8", "type2": "3.83e8-6.38e8", "source": "BASELINE.md (Np = 1.7e7 ... 1.7e8)"} if complex_data else
+                                         {"type1": "2.4e8-2.7e8", "type2": "6.2e8-9.6e8", "source": "BASELINE.md (Np = 1.7e7 ... 1.7e8)"})
+    res["spread_engine"] = plan.spread_engine_used()
     if sweep:
         rows = []
-        for k in range(11):                                   # rho = 10^(-4 + k / 2), Np = round(rho N^3): the reference's list
+        for k in (range(6, 11) if complex_data else range(11)):      # rho = 10^(-4 + k / 2), Np = round(rho N^3): the reference's list (complex data: rho >= 0.1)
             rho = 10.0 ** (-4 + 0.5 * k)
             Npk = int(round(rho * n ** 3))
             r = run(Npk, 5 if Npk > 2e7 else 8)

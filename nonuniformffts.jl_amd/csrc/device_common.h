@@ -505,6 +505,33 @@ __device__ __forceinline__ void row_bcast4(float x, float (&w)[4]) {
         : "v"(x), "n"(BASE), "n"(BASE + 1), "n"(BASE + 2), "n"(BASE + 3));
 }
 
+// Groups of 8 lanes: lane J of its own group to every lane — lanes 0-7 of a row take lane J, lanes 8-15 lane J + 8 of the row: two DPP moves
+// that each write one half of the row (bank_mask), instead of two full broadcasts and a select on (lane & 8).
+template <int J>
+__device__ __forceinline__ float half_bcast_asm(float x) {
+    float r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3\n\tv_mov_b32_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(r) : "v"(x), "n"(J), "n"(J + 8));
+    return r;
+}
+template <int J>
+__device__ __forceinline__ double half_bcast_asm(double x) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3\n\tv_mov_b64_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(r) : "v"(x), "n"(J), "n"(J + 8));
+    return r;
+}
+// j (0..7) must be a compile-time constant after unrolling
+template <typename T>
+__device__ __forceinline__ T half_bcast(T x, int j) {
+    switch (j & 7) {
+        case 0: return half_bcast_asm<0>(x);   case 1: return half_bcast_asm<1>(x);
+        case 2: return half_bcast_asm<2>(x);   case 3: return half_bcast_asm<3>(x);
+        case 4: return half_bcast_asm<4>(x);   case 5: return half_bcast_asm<5>(x);
+        case 6: return half_bcast_asm<6>(x);   default: return half_bcast_asm<7>(x);
+    }
+}
+
 // j must be a compile-time constant after unrolling (the switch folds away)
 template <typename T>
 __device__ __forceinline__ T row_bcast(T x, int j) {

@@ -6,6 +6,8 @@ Tolerances (written here as the reference writes them): rtol 1e-7 for Float64 an
 the 2-norm (test/pseudo_gpu.jl:159-171).  Summation order inside a tile is nondeterministic on the
 GPU (atomics), so comparisons are never bitwise.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -822,8 +824,15 @@ def test_spreading_engine_selection():
     def method(Z, dims=(64, 64, 64), **kw):
         return nufft.PlanNUFFT(Z, dims, backend=nufft.ROCBackend(0), **kw).info().spread_method
     assert method(np.float64) == 3 and method(np.float64, m=6) == 3 and method(np.float64, m=7) == 2
-    assert method(np.complex128) == 3 and method(np.complex128, m=5) == 2
-    assert method(np.complex64, m=3) == 3 and method(np.complex64) == 2
+    # complex data runs part by part through the real window kernel: the window up to M = 6, the patches above
+    assert method(np.complex128) == 3 and method(np.complex128, m=5) == 3 and method(np.complex128, m=6) == 3 and method(np.complex128, m=7) == 2
+    assert method(np.complex64, m=3) == 3 and method(np.complex64) == 3 and method(np.complex64, m=6) == 3 and method(np.complex64, m=7) == 2
+    os.environ["NUFFT_SMARCH_SPLIT"] = "0"          # the interleaved complex instantiations: ComplexF64 up to M = 4, ComplexF32 up to M = 3
+    try:
+        assert method(np.complex128) == 3 and method(np.complex128, m=5) == 2
+        assert method(np.complex64, m=3) == 3 and method(np.complex64) == 2
+    finally:
+        del os.environ["NUFFT_SMARCH_SPLIT"]
     assert method(np.complex128, (35, 64, 40), sigma=1.5) == 1 and method(np.float64, (64, 64)) == 1
     # real plans with ntransforms = 2 / 3: the ring spreads the components one after the other (7.3 against 7.5 ms at C4); an
     # explicit request for the patches still spreads them together
@@ -1012,8 +1021,8 @@ def test_automatic_engine_choice_per_point_set(dist):
         "cluster": tuple(torch.randn(Np, dtype=torch.float64, device="cuda", generator=g) * 0.05 + np.pi for _ in range(3)),
     }
     v = torch.randn(Np, dtype=torch.complex128, device="cuda", generator=g)
-    auto = nufft.PlanNUFFT(torch.complex128, (n, n, n), m=5, backend=nufft.ROCBackend(0))       # (M = 5: the patches are the automatic choice)
-    ref = nufft.PlanNUFFT(torch.complex128, (n, n, n), m=5, spread_method="lds_tiles", backend=nufft.ROCBackend(0))
+    auto = nufft.PlanNUFFT(torch.complex128, (n, n, n), m=7, backend=nufft.ROCBackend(0))       # (M = 7: the patches are the automatic choice)
+    ref = nufft.PlanNUFFT(torch.complex128, (n, n, n), m=7, spread_method="lds_tiles", backend=nufft.ROCBackend(0))
     assert auto.info().spread_method == 2 and ref.info().spread_method == 1
     for name in (dist, "uniform" if dist == "cluster" else "cluster", dist):
         nufft.set_points(auto, sets[name])
@@ -1035,7 +1044,7 @@ def test_automatic_engine_choice_on_a_grid_with_more_tasks_than_wave_slots():
     nufft = _nufft()
     Np = 2_000_000
     g = torch.Generator(device="cuda").manual_seed(12)
-    auto = nufft.PlanNUFFT(torch.complex64, (256, 128, 128), backend=nufft.ROCBackend(0))
+    auto = nufft.PlanNUFFT(torch.complex64, (256, 128, 128), m=7, backend=nufft.ROCBackend(0))      # (M = 7: the patches are the automatic choice)
     assert auto.info().spread_method == 2
     for name in ("uniform", "cluster", "uniform"):
         if name == "uniform":
