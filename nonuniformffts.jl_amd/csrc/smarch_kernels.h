@@ -225,7 +225,7 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     if (*mg.flag == 0u) return;                         // spread_tile_kernel serves this point set
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);      // (wave: a scalar)
     const Geom& g = a.g;
     const int task = xcd_remap_chunked((int)blockIdx.x, (int)gridDim.x, a.xcd_chunk);
     if (task >= mg.ntasks) return;
@@ -344,7 +344,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         };
 
         // one chunk of up to PPW points
-        auto chunk = [&](auto clip_c, const PointRec<T, 3>& rec, T vmine, bool have) __attribute__((always_inline)) {
+        // (part, nparts: the chunks of a layer's last, incomplete round are shared by nparts waves each — every wave evaluates the windows
+        // of the whole chunk, wave `part` adds the points gi with gi nparts / PPW == part)
+        auto chunk = [&](auto clip_c, const PointRec<T, 3>& rec, T vmine, bool have, int part, int nparts) __attribute__((always_inline)) {
             constexpr bool CLIPZ = decltype(clip_c)::value;
             int s[2];
             T X[3];
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                 constexpr int PB = 3 * L * (int)sizeof(T);
                 for_each_pair<0, PPW>([&](auto G0c) {
                     constexpr int g0 = decltype(G0c)::value;
+                    if (nparts > 1 && g0 * nparts / PPW != part) return;
                     T pre[6];
                     lds_read_imm<T, (g0 + 0) * PB>(pre[0], sb1);
                     lds_read_imm<T, (g0 + 0) * PB>(pre[1], sb2);
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             } else {
 #pragma unroll
                 for (int gi = 0; gi < PPW; ++gi) {
+                    if (nparts > 1 && gi * nparts / PPW != part) continue;
                     const T* sp = strip_wave + gi * (3 * L);
                     T w1v[NPASS], w2v[NPASS];
 #pragma unroll
@@ -497,9 +501,27 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         // ---- chunks wave, wave + NW, ... of this layer; the next chunk's records are requested before the current one is
         //      processed, its values right after ----
         {
-            int item = wave;
+            // the last, incomplete round of the layer (rem < NW chunks left): 2 or 4 waves share a chunk, so that the LDS atomic pipe does not
+            // idle behind a few waves — a layer of a 32 x 32 column holds ~38 chunks at C2: rounds of 16, 16 and 6.  Measured (round 5, C2
+            // spread stage): Direct() 1.98 -> 2.11 ms, polynomial window 1.90 -> 1.93: every sharing wave evaluates the windows of the
+            // whole chunk, which costs more than the idle lanes of the tail — off
+#ifndef NUFFT_SMARCH_SPLIT_TAIL
+#define NUFFT_SMARCH_SPLIT_TAIL 0
+#endif
+            const int full = nchunks / NW * NW, rem = nchunks - full;
+            const int tparts = (NUFFT_SMARCH_SPLIT_TAIL && PPW >= 4 && rem > 0) ? (rem * 4 <= NW ? 4 : (rem * 2 <= NW ? 2 : 1)) : 1;
+            auto item_of = [&](int it, int& part, int& np) __attribute__((always_inline)) -> int {      // chunk of the wave's item `it` (-1: none)
+                part = 0; np = 1;
+                if (it < full) return it;
+                const int w = it - full;            // = wave, in the tail round
+                if (w >= rem * tparts) return -1;
+                part = w % tparts; np = tparts;
+                return full + w / tparts;
+            };
+            int it = wave, part = 0, nparts = 1;
+            int item = item_of(it, part, nparts);
             uint32_t p0 = 0, p1 = 0;
-            bool valid = item < nchunks;
+            bool valid = item >= 0;
             PointRec<T, 3> rec{};
             T vcur = T(0);
             if (valid) {
@@ -508,8 +530,10 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                 vcur = value_of(rec);
             }
             while (valid) {
-                item += NW;
-                const bool validn = item < nchunks;
+                it += NW;
+                int partn = 0, npartsn = 1;
+                item = it < full + NW ? item_of(it, partn, npartsn) : -1;
+                const bool validn = item >= 0;
                 uint32_t n0 = 0, n1 = 0;
                 PointRec<T, 3> recn = rec;
                 if (validn) {
@@ -517,8 +541,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                     recn = sorted[min(n0 + (uint32_t)grp, n1 - 1)];
                 }
                 const bool have = p0 + (uint32_t)grp < p1;
-                if (clipz) chunk(std::true_type{}, rec, vcur, have);
-                else chunk(std::false_type{}, rec, vcur, have);
+                if (clipz) chunk(std::true_type{}, rec, vcur, have, part, nparts);
+                else chunk(std::false_type{}, rec, vcur, have, part, nparts);
+                part = partn; nparts = npartsn;
                 // (requesting the next values in the middle of the visits instead — half a chunk more slack — measured slower:
                 // 2.50 against 2.45 ms at C2; the value gather costs 0.1 ms in all, ablation 6)
                 if (validn) vcur = value_of(recn);
