@@ -499,7 +499,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         };
 
         // ---- chunks wave, wave + NW, ... of this layer; the next chunk's records are requested before the current one is
-        //      processed, its values right after ----
+        //      processed, its values right after.  (Tried, round 5: the first chunk of the NEXT layer requested before the two barriers of
+        //      the retire pass, so that no wave starts a layer waiting for records — C2 spread stage 1.89 -> 1.87 ms with the polynomial
+        //      window, 1.98 -> 2.05 with Direct(): nothing to gain, the other waves already cover that latency.) ----
         {
             // the last, incomplete round of the layer (rem < NW chunks left): 2 or 4 waves share a chunk, so that the LDS atomic pipe does not
             // idle behind a few waves — a layer of a 32 x 32 column holds ~38 chunks at C2: rounds of 16, 16 and 6.  Measured (round 5, C2
