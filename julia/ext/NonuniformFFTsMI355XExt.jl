@@ -154,7 +154,7 @@ function ensure_handle!(p::PlanNUFFT{Z, N, Nc, M, MI355XBackend}) where {Z, N, N
         throw(ArgumentError("MI355XBackend: point_transform must be identity or the AbstractNFFTs convention (closures cannot cross the C ABI); use ROCBackend()"))
     T = real(Z)
     Ls = map(length, data.ks)
-    Ns = pad3(d -> Int64(Z <: Real && d == 1 ? 2 * (Ls[1] - 1) : Ls[d]), N, Int64(0))
+    Ns = pad3(d -> Int64(Z <: Real && d == 1 ? max(1, 2 * (Ls[1] - 1)) : Ls[d]), N, Int64(0))
     Ñs = pad3(d -> Int64(Kernels.gridsize(p.kernels[d])), N, Int64(0))
     βs = pad3(d -> shape_param(p.kernels[d]), N, 0.0)
     dtype = T === Float64 ? NUFFT_F64 : NUFFT_F32
