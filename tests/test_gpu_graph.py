@@ -85,3 +85,53 @@ def test_graph_replay_matches_oracle_on_new_data(Z, dims, sigma, evalmode):
     step()
     torch.cuda.synchronize()
     assert _rel(wd.cpu().numpy(), ref2) < tol
+
+
+def test_graph_replay_on_a_plan_of_the_column_layer_sort():
+    """A captured set_points! + exec_type1! + exec_type2! on a plan whose points are sorted by column layers (binsort.hip, CoarseSort): both
+    sorts and all three interpolation kernels are part of the captured sequence, the device flags of every replay pick what runs — replayed on
+    a uniform set (column-layer sort, staged ring), then on a set concentrated in a corner (fine sort, tile kernels), then uniform again."""
+    from nufft_pkg import nufft
+    dims, Np = (256, 256, 32), 120000
+    plan = nufft.PlanNUFFT(np.float64, dims, m=4, sigma=2.0, kernel_evalmode=nufft.Direct(), backend=nufft.ROCBackend(0))
+    info = plan.info()
+    assert info.spread_method == 3 and info.ring_halo == 1 and info.sort_column[0] > 0
+    oplan = O.OraclePlan(dims, is_real=True, dtype=np.float64, M=4, sigma=2.0, evalmode=O.DIRECT)
+    dev = plan.device
+    rng = np.random.default_rng(21)
+
+    def inputs(kind):
+        xs = [rng.random(Np) * O.TWO_PI for _ in dims]
+        if kind == "corner":
+            xs = [0.05 * x for x in xs]
+        return xs, rng.standard_normal(Np)
+
+    xs0, v0 = inputs("uniform")
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs0)
+    vd = torch.from_numpy(v0).to(dev)
+    ud = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    wd = torch.empty(Np, dtype=plan.Z, device=dev)
+
+    def step():
+        nufft.set_points(plan, xd)
+        nufft.exec_type1(ud, plan, vd)
+        nufft.exec_type2(wd, plan, ud)
+
+    step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for kind in ("uniform", "corner", "uniform"):
+        xs, v = inputs(kind)
+        for d in range(3):
+            xd[d].copy_(torch.from_numpy(xs[d]))
+        vd.copy_(torch.from_numpy(v))
+        ud.zero_(); wd.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert plan.sort_columns_used() == (kind == "uniform"), kind
+        O.set_points(oplan, xs)
+        ref1 = O.exec_type1(oplan, v)
+        assert _rel(ud.cpu().numpy(), ref1) < 1e-7, kind
+        assert _rel(wd.cpu().numpy(), O.exec_type2(oplan, ref1)) < 1e-7, kind
