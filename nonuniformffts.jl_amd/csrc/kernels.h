@@ -94,6 +94,7 @@ struct TileKernelArgs {
     int fixed_tile;            // the tile (g.ip / g.sp) equals the compile-time one (kernel variant with constant strides)
     int cubes;                 // spreading with the compile-time tile: accumulate cube by cube with the FP64 matrix instruction
     void* halo;                // marching ring, halo variant: side buffer of the stencil reach (C components, SMarchPlan::halo_reals each)
+    int interp_parts;          // 2: complex data interpolated part by part by the real ring kernels (march_kernels.h, MarchGeom::parts); else 1
     int coarse;                // plan of the column-layer sort (CoarseSort): point sets with both flags nonzero are sorted that way
     const uint32_t* coarse_a;
     const uint32_t* coarse_b;

@@ -129,6 +129,7 @@ struct nufft_plan {
     uint32_t* d_patch_choice = nullptr;   // [16]: scratch of patch_split_kernel; [2] = 1: this point set is spread by the patches
     uint32_t* d_patch_cols = nullptr;     // [columns] points per patch column, then [columns + 1] first task of each column
     void* d_patch_tasks = nullptr;        // uint2[ntasks]: {column, end layer << 16 | first layer}, rebuilt by every set_points
+    int interp_parts = 1;                 // 2: ComplexF64 interpolated part by part by the real ring kernels (NUFFT_INTERP_SPLIT, latched at creation)
     int smarch_parts = 1;                 // 2: complex data part by part through the real window kernel (NUFFT_SMARCH_SPLIT, latched at creation)
     nufft::SMarchPlan smarch{};           // decomposition of the z-marching spreading ring (smarch_kernels.h); eligible = false: none
     uint32_t* d_smarch_choice = nullptr;  // [16]: scratch of the task kernels; [2] = 1: this point set is spread by the ring

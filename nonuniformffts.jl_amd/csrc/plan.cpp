@@ -611,11 +611,23 @@ static int build_device(nufft_plan* p) {
     p->interp_march_mode = env_int("NUFFT_INTERP_MARCH", 1);
     p->debug_tasks = env_int("NUFFT_DEBUG_TASKS", 0) != 0;
     p->halo_fuse = env_int("NUFFT_SMARCH_HALO_FUSE", 1) != 0;
+    // ComplexF64 part by part through the REAL ring kernels (march_setup.inc, MarchGeom::parts = 2): the complex instantiation reads 128-bit pairs
+    // from LDS at a quarter of the rate (scripts/microbench7.hip) and owns a narrower column — two passes of the real kernel are faster from
+    // m = 4 on (interpolation stage 256^3 -> 512^3, Np = 1e7: 2.76 against 2 x 1.2 ms; m = 8: 20.4 against 2 x 5.8), and the plan can then share
+    // its columns with the spreading window (column-layer sort).  ComplexF32 keeps its paired-lane kernel (1.25 ms against 2 x 1.08).
+    // NUFFT_INTERP_SPLIT=0: the complex instantiations (A/B runs, tests)
+    p->interp_parts = (p->is_complex && p->dtype == NUFFT_F64 && env_int("NUFFT_INTERP_SPLIT", 1) != 0) ? 2 : 1;
+    auto march_cplx = [&]() { return p->interp_parts == 2 ? 0 : (int)p->is_complex; };
     p->interp_march = p->interp_march_mode != 0 &&
-                      interp_march_available(p->dtype, p->is_complex, D, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
+                      interp_march_available(p->dtype, march_cplx(), D, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
+    if (!p->interp_march && p->interp_parts == 2) {
+        p->interp_parts = 1;
+        p->interp_march = p->interp_march_mode != 0 &&
+                          interp_march_available(p->dtype, p->is_complex, D, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
+    }
     if (p->interp_march) {
-        NUFFT_HIP(prepare_interp_march(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
-        p->march_ct = march_column_tasks(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p));
+        NUFFT_HIP(prepare_interp_march(p->dtype, march_cplx(), p->M, p->evalmode != NUFFT_EVAL_DIRECT));
+        p->march_ct = march_column_tasks(p->dtype, march_cplx(), p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p));
         const size_t ncols = (size_t)p->march_ct.ncolx * p->march_ct.ncoly;
         if (ncols >= 65536 || p->tile.nb[2] > 2048) p->interp_march = false;      // (beyond the task kernels' table formats)
         else {
@@ -696,7 +708,8 @@ static int build_device(nufft_plan* p) {
         const int nkeys = sc.ncolx * sc.ncoly * p->tile.nb[2];
         const bool same = sc.ncolx == mc.ncolx && sc.ncoly == mc.ncoly && p->smarch.n1 == 4 * mc.bxw && p->smarch.n2 == 4 * mc.byw &&
                           p->Nover[0] % p->smarch.n1 == 0 && p->Nover[1] % p->smarch.n2 == 0;
-        if (same && nkeys <= kCoarseMaxKeys && interp_march_staged_available(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT)) {
+        const int mcplx = p->interp_parts == 2 ? 0 : (int)p->is_complex;
+        if (same && nkeys <= kCoarseMaxKeys && interp_march_staged_available(p->dtype, mcplx, p->M, p->evalmode != NUFFT_EVAL_DIRECT)) {
             p->coarse.enabled = 1;
             p->coarse.cbx = mc.bxw; p->coarse.cby = mc.byw; p->coarse.ncx = mc.ncolx; p->coarse.ncy = mc.ncoly;
             p->coarse.nkeys = nkeys;
@@ -705,7 +718,7 @@ static int build_device(nufft_plan* p) {
             p->coarse.flag_b = p->d_march_choice + 2;
             if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->coarse.table), (size_t)p->coarse.groups * nkeys * sizeof(uint32_t)))) return rc;
             NUFFT_HIP(prepare_binsort_coarse(p->dtype, nkeys));
-            NUFFT_HIP(prepare_interp_march_staged(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
+            NUFFT_HIP(prepare_interp_march_staged(p->dtype, mcplx, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
         }
     }
 
@@ -789,6 +802,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.threads = interp ? p->interp_threads : p->spread_threads;
     a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
     a.march = interp && p->interp_march;      // (the ring applies per-point weights itself)
+    a.interp_parts = p->interp_parts;
     a.coarse = p->coarse.enabled;
     a.coarse_a = p->coarse.flag_a;
     a.coarse_b = p->coarse.flag_b;

@@ -38,7 +38,7 @@
 // Complex data through the real kernel (MarchGeom::parts = 2; round 5).  The complex instantiations accumulate (component, j1, j2)
 // faces: 128 lanes = two wave instructions per plane at M = 4, and the interleaved window halves the column (ComplexF64 m = 4: 5.06 ms
 // against 1.87 ms for real data).  Real and imaginary parts are independent real transforms of the same points, so a complex plan
-// can run the REAL kernel twice per component — blockIdx.y = 2 component + part — reading the part's half of every value (stride 2
+// can run the REAL kernel twice per component — two workgroups per task, side by side on one XCD — reading the part's half of every value (stride 2
 // reals) and storing the part's half of every cell of the interleaved grid (two 8-byte stores instead of one 16-byte store per
 // pair); the side buffer of the halo variant stays planar, one per (component, part), and its consumers add it to the real or
 // imaginary parts of the lines (fft_lines.hip).  The 8 x 8-face FAST path, the 32 x 32 column and the halo variant of real data carry over.
@@ -227,12 +227,17 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     if (*mg.flag == 0u) return;                         // spread_tile_kernel serves this point set
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);      // (wave: a scalar)
     const Geom& g = a.g;
-    const int task = xcd_remap_chunked((int)blockIdx.x, (int)gridDim.x, a.xcd_chunk);
-    if (task >= mg.ntasks) return;
-    // (complex data through this real kernel: blockIdx.y = 2 component + part, see the header)
+    // (complex data through this real kernel, see the header: the two parts of a task are workgroups 8 apart of a launch of 2 x tasks (rounded
+    // up to 8) — dispatched back to back on the SAME XCD, so that the halves they write into every 16-byte cell meet in that XCD's L2)
     const bool split = !CPLX && mg.parts == 2;
-    const int comp_id = split ? (int)blockIdx.y >> 1 : (int)blockIdx.y, part = split ? (int)blockIdx.y & 1 : 0;
+    const int comp_id = (int)blockIdx.y;
+    const int slot = (int)blockIdx.x >> 3;
+    const int part = split ? slot & 1 : 0;
     const int vgs = split ? 2 : 1;                      // reals between consecutive values / cells of this part
+    const int yrow = split ? 2 * comp_id + part : comp_id;      // planar side buffer of this (component, part)
+    const int vblock = split ? (slot >> 1) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+    const int task = xcd_remap_chunked(vblock, split ? (int)gridDim.x >> 1 : (int)gridDim.x, a.xcd_chunk);
+    if (task >= mg.ntasks) return;
     const uint2 te = mg.tasktab[task];
     const int tx = (int)te.x % mg.ntx, ty = (int)te.x / mg.ntx;
     const int zb0 = (int)(te.y & 0xffffu), zb1 = (int)(te.y >> 16);
@@ -585,8 +590,8 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                     int64_t pstride;                                               // reals between consecutive planes
                     bool to_grid = true;
                     if ((HX || HY) && (lx < 0 || lx >= neff1 || ly < 0 || ly >= neff2)) {
-                        // (one planar side buffer per launch row: blockIdx.y = component, or (component, part) for split complex data)
-                        dst0 = static_cast<T*>(mg.halo) + (int64_t)blockIdx.y * mg.halo_comp + (int64_t)(4 * zb0) * hl.plane +
+                        // (one planar side buffer per component, or per (component, part) for split complex data)
+                        dst0 = static_cast<T*>(mg.halo) + (int64_t)yrow * mg.halo_comp + (int64_t)(4 * zb0) * hl.plane +
                                ((int64_t)ty * mg.ntx + tx) * hl.rec + halo_record_offset(hl, 2 * xp, ly);
                         pstride = hl.plane;
                         to_grid = false;

@@ -382,8 +382,11 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
         if (e != hipSuccess) return e;
         if (march) {
             int lds = 0, n[4];
-            const void* mfn = march_kernel(a.dtype, a.is_complex, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
+            const int parts = (a.interp_parts == 2 && a.is_complex) ? 2 : 1;      // complex data part by part through the real kernel
+            const int mcplx = parts == 2 ? 0 : a.is_complex;
+            const void* mfn = march_kernel(a.dtype, mcplx, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
             MarchGeom mg{};
+            mg.parts = parts;
             mg.ntx = a.march_ct.ncolx;
             mg.nty = a.march_ct.ncoly;
             mg.nseg = a.march_ct.nseg;
@@ -394,14 +397,16 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
             mg.coarse_a = a.coarse ? a.coarse_a : nullptr;
             mg.coarse_b = a.coarse ? a.coarse_b : nullptr;
             void* mparams[] = {&k, &mg};
-            e = hipLaunchKernel(mfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)n[3], 1, 1), mparams, (size_t)lds, stream);
+            // (parts = 2: both parts of a task side by side on one XCD — march_setup.inc)
+            const unsigned gx = parts == 2 ? 2u * (((unsigned)mg.ntasks + 7u) & ~7u) : (unsigned)mg.ntasks;
+            e = hipLaunchKernel(mfn, dim3(gx, (unsigned)nc, 1), dim3((unsigned)n[3], 1, 1), mparams, (size_t)lds, stream);
             if (e != hipSuccess) return e;
             if (a.coarse) {
                 // plans of the column-layer sort: the staged kernel serves the point sets sorted that way (device flags), the plain one the others
                 int slds = 0, sn[4];
-                const void* sfn = march_staged_kernel(a.dtype, a.is_complex, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &slds, sn);
+                const void* sfn = march_staged_kernel(a.dtype, mcplx, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &slds, sn);
                 if (!sfn) return hipErrorInvalidValue;
-                e = hipLaunchKernel(sfn, dim3((unsigned)mg.ntasks, (unsigned)nc, 1), dim3((unsigned)sn[3], 1, 1), mparams, (size_t)slds, stream);
+                e = hipLaunchKernel(sfn, dim3(gx, (unsigned)nc, 1), dim3((unsigned)sn[3], 1, 1), mparams, (size_t)slds, stream);
                 if (e != hipSuccess) return e;
             }
         }
@@ -627,7 +632,9 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
         mg.halo_comp = sp.halo_reals;
         mg.parts = parts;
         void* params[] = {&k, &mg};
-        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)mg.ntasks, (unsigned)(nc * parts), 1), dim3((unsigned)n[4], 1, 1), params, (size_t)lds, stream);
+        // (parts = 2: both parts of a task side by side on one XCD — smarch_kernels.h)
+        const unsigned gx = parts == 2 ? 2u * (((unsigned)mg.ntasks + 7u) & ~7u) : (unsigned)mg.ntasks;
+        hipError_t e = hipLaunchKernel(fn, dim3(gx, (unsigned)nc, 1), dim3((unsigned)n[4], 1, 1), params, (size_t)lds, stream);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -408,27 +408,30 @@ def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
     dimension 3.  On a grid this small the ring's few tasks cannot fill the chip and set_points gives the point set to
     the LDS-tile kernel, so the test plans force the ring (NUFFT_INTERP_MARCH=2) and nufft_interp_engine_used confirms the
     device-side flag; a point set concentrated in a corner exercises the tasks of equal point count (quantile segments,
-    empty tasks).  ComplexF64 at M = 10 has no ring (no column fits 160 KiB): LDS tiles there, and for the plan with
-    the ring switched off at the end."""
-    has_ring = not (np.dtype(Z) == np.complex128 and M >= 10)
+    empty tasks).  ComplexF64 at M = 10 has no ring (no LDS tile of 4-cell bins fits 160 KiB, the plan bins by 2 cells and the ring
+    needs bins of 4): LDS tiles there, and for the plan with the ring switched off at the end."""
     dims, Np = (48, 40, 56), 4000
     monkeypatch.setenv("NUFFT_INTERP_MARCH", "2")
-    for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
-        nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=100 + M)
-        dev = plan.device
-        rng = np.random.default_rng(5 + M)
-        w = (rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape))
-        w = w.astype(np.complex64 if plan_real_dtype(Z) == np.float32 else np.complex128)
-        wd = torch.from_numpy(w).to(dev)
-        for name in ("uniform", "corner"):
-            pts = xs if name == "uniform" else tuple((0.3 * x * x / (2 * np.pi)).astype(x.dtype) for x in xs)
-            nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
-            O.set_points(oplan, pts)
-            out = torch.empty(Np, dtype=plan.Z, device=dev)
-            nufft.exec_type2(out, plan, wd)
-            assert plan.interp_engine_used() == ("marching_ring" if has_ring else "lds_tiles"), (name, evalmode)
-            ref = O.exec_type2(oplan, _oracle_inputs(oplan, [w])[0])
-            assert _rel(out.cpu().numpy(), ref) < _rtol(Z), (name, evalmode)
+    # ComplexF64: part by part through the real kernel (the default), and the complex instantiations (NUFFT_INTERP_SPLIT=0)
+    for split in (("1", "0") if np.dtype(Z) == np.complex128 else ("1",)):
+        monkeypatch.setenv("NUFFT_INTERP_SPLIT", split)
+        has_ring = not (np.dtype(Z) == np.complex128 and M >= 10)
+        for evalmode in (O.FAST_APPROXIMATION, O.DIRECT):
+            nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, 1, Np, seed=100 + M)
+            dev = plan.device
+            rng = np.random.default_rng(5 + M)
+            w = (rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape))
+            w = w.astype(np.complex64 if plan_real_dtype(Z) == np.float32 else np.complex128)
+            wd = torch.from_numpy(w).to(dev)
+            for name in ("uniform", "corner"):
+                pts = xs if name == "uniform" else tuple((0.3 * x * x / (2 * np.pi)).astype(x.dtype) for x in xs)
+                nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
+                O.set_points(oplan, pts)
+                out = torch.empty(Np, dtype=plan.Z, device=dev)
+                nufft.exec_type2(out, plan, wd)
+                assert plan.interp_engine_used() == ("marching_ring" if has_ring else "lds_tiles"), (name, evalmode, split)
+                ref = O.exec_type2(oplan, _oracle_inputs(oplan, [w])[0])
+                assert _rel(out.cpu().numpy(), ref) < _rtol(Z), (name, evalmode, split)
     # the same transform with the ring switched off: LDS-tile kernel, same result
     monkeypatch.setenv("NUFFT_INTERP_MARCH", "0")
     nufft, plan2, _, _, _ = _make_case(Z, dims, M, 2.0, O.DIRECT, 1, Np, seed=100 + M)
@@ -635,7 +638,9 @@ def test_forwarded_kernel_data_reproduces_the_plan(Z, dims, M, sigma, kname):
 @pytest.mark.parametrize("Z,M,C,evalmode", [(np.float64, 4, 1, O.FAST_APPROXIMATION), (np.float64, 4, 1, O.DIRECT), (np.float64, 4, 3, O.FAST_APPROXIMATION),
                                              (np.float32, 4, 1, O.DIRECT), (np.float64, 2, 1, O.DIRECT), (np.float64, 3, 2, O.FAST_APPROXIMATION),
                                              (np.float64, 5, 1, O.DIRECT), (np.float32, 6, 1, O.FAST_APPROXIMATION), (np.float64, 6, 1, O.DIRECT),
-                                             (np.float32, 7, 1, O.DIRECT)])
+                                             (np.float32, 7, 1, O.DIRECT),
+                                             # ComplexF64: both rings run the real kernels part by part, so the plan shares their columns
+                                             (np.complex128, 4, 1, O.FAST_APPROXIMATION), (np.complex128, 6, 2, O.DIRECT)])
 def test_column_layer_sort_and_staged_interpolation(Z, M, C, evalmode, monkeypatch):
     """Plans whose spreading window (halo variant) and interpolation ring own the same columns sort the points by (column, layer of
     bins) only (binsort.hip, CoarseSort: LDS histograms, no global atomics) and interpolate with interp_march_staged_kernel, which
