@@ -278,8 +278,10 @@ int nufft_get_sort_result(nufft_plan* plan, int32_t* perm_host, int64_t perm_cap
                           uint32_t* tile_offsets_host, int64_t offsets_capacity, void* stream);
 
 /* Which sort the last nufft_set_points used: 1 = by column layers (nufft_info.sort_column; the offsets returned by
- * nufft_get_sort_result then hold a column layer's points in its first bin and nothing in its other bins), 0 = by fine bins.
- * Reads two device flags back (synchronises `stream`).  Inspection only. */
+ * nufft_get_sort_result then hold a column layer's points in its first bin and nothing in its other bins), 0 = by fine bins
+ * (histogram with global atomics), 2 = by fine bins in two levels (slabs of bin rows with LDS histograms, then every slab in LDS:
+ * the same array and offsets as 0 up to the order inside a bin; 3-D plans without sort_column, point sets whose fullest slab fits
+ * a workgroup's LDS).  Reads device flags back (synchronises `stream`).  Inspection only. */
 int nufft_sort_columns_used(nufft_plan* plan, int* used_out, void* stream);
 
 /* ---- timing (TimerOutputs analogue, src/plan.jl:397-417) -------------------------------- */

@@ -228,10 +228,11 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_count_kernel(BinArgs<T,
 }
 
 // per key: exclusive prefix over the slices (in place), and the key's total into the fake fine histogram
-__global__ __launch_bounds__(64) void coarse_prefix_kernel(Geom g, CoarseGeom c, int groups, uint32_t* __restrict__ table, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(64) void coarse_prefix_kernel(Geom g, CoarseGeom c, int groups, uint32_t* __restrict__ table, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ maxout) {
     const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= c.nkeys) return;
     uint32_t run = 0u;
+    if (k < c.nkeys) {
     int w = 0;
     for (; w + 8 <= groups; w += 8) {
         uint32_t v[8];
@@ -249,6 +250,18 @@ __global__ __launch_bounds__(64) void coarse_prefix_kernel(Geom g, CoarseGeom c,
         run += v;
     }
     counts[coarse_rep_bin(g, c, k)] = run;
+    }
+    if (maxout) {                                       // (slab sort: the fullest slab decides whether level 2 can hold it)
+        uint32_t m = run;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) atomicMax(maxout, m);
+    }
+}
+// slab sort: fm[4] = 1 when the fullest slab fits a level-2 workgroup; fm[0] (the running maximum) cleared for the next set_points
+__global__ void slab_flag_kernel(uint32_t* fm, uint32_t cap) {
+    fm[4] = fm[0] <= cap ? 1u : 0u;
+    fm[0] = 0u;
 }
 
 // the fine sort takes over (a ring handed the point set to the tile kernels): the fake histogram is cleared first
@@ -295,6 +308,82 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(BinArgs<
     for (int k = w * kCoarseThreads + tid; k < c.nkeys; k += (int)gridDim.x * kCoarseThreads) counts[coarse_rep_bin(a.g, c, k)] = 0u;
 }
 
+
+// level 2 of the slab sort: one workgroup per slab — records into LDS, histogram of the slab's fine bins (the atomic's return value is the
+// record's rank inside its bin), scan, the slab's fine offsets, the inverse permutation, and the records out in order (coalesced)
+constexpr int kSlabThreads = 1024;
+constexpr int kSlabIPT = 8;                // records per thread at most (cap <= 8192)
+template <typename T>
+__global__ __launch_bounds__(kSlabThreads) void slab_sort_kernel(Geom g, CoarseGeom c, int cap, const PointRec<T, 3>* __restrict__ temp,
+                                                                 PointRec<T, 3>* __restrict__ sorted, uint32_t* __restrict__ offsets, const uint32_t* flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_smem[];
+    if (*flag == 0u) return;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(slab_smem);                                        // [kSlabMaxBins]
+    uint32_t* wsum = cnt + kSlabMaxBins;                                                           // [16] wave totals of the scan
+    uint32_t* aux = wsum + 16;                                                                     // [cap] bin << 16 | rank, then source of output j
+    PointRec<T, 3>* recs = reinterpret_cast<PointRec<T, 3>*>(aux + cap);                           // [cap]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x;
+    const int cy = (k / c.ncx) % c.ncy;
+    const int nbs = min(c.cby, g.nb[1] - cy * c.cby) * g.nb[0];                                     // fine bins of this slab: a contiguous range
+    const int64_t rep = coarse_rep_bin(g, c, k);
+    const uint32_t base = offsets[rep], n = offsets[rep + nbs] - base;
+    for (int i = tid; i < nbs; i += kSlabThreads) cnt[i] = 0u;
+    __syncthreads();
+    uint32_t av[kSlabIPT];
+#pragma unroll
+    for (int u = 0; u < kSlabIPT; ++u) {
+        const uint32_t i = (uint32_t)(u * kSlabThreads + tid);
+        av[u] = 0u;
+        if (i < n) {
+            const PointRec<T, 3> rec = temp[base + i];
+            recs[i] = rec;
+            const int b0 = cell_of(rec.r[0], g.Nover[0]) >> g.blog[0], b1 = cell_of(rec.r[1], g.Nover[1]) >> g.blog[1];
+            const uint32_t fb = (uint32_t)((b1 - cy * c.cby) * g.nb[0] + b0);
+            av[u] = fb << 16 | atomicAdd(&cnt[fb], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts: 4 consecutive bins per thread, wave scan, wave totals
+    {
+        uint32_t v[4], tsum = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * tid + j;
+            v[j] = i < nbs ? cnt[i] : 0u;
+            tsum += v[j];
+        }
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0u;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        uint32_t run = wbase + incl - tsum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * tid + j;
+            if (i < nbs) {
+                cnt[i] = run;
+                offsets[rep + i] = base + run;
+            }
+            run += v[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSlabIPT; ++u) {
+        const uint32_t i = (uint32_t)(u * kSlabThreads + tid);
+        if (i < n) aux[cnt[av[u] >> 16] + (av[u] & 0xffffu)] = i;
+    }
+    __syncthreads();
+    for (uint32_t j = (uint32_t)tid; j < n; j += kSlabThreads) sorted[base + j] = recs[aux[j]];
+}
+
 static CoarseGeom coarse_geom(const CoarseSort& cs) { return CoarseGeom{cs.cbx, cs.cby, cs.ncx, cs.ncy, cs.nkeys}; }
 
 template <typename T>
@@ -307,6 +396,21 @@ static BinArgs<T, 3> bin_args3(const SortArgs& s) {
     return a;
 }
 
+int slab_sort_lds_bytes(int dtype, int cap) {
+    return (kSlabMaxBins + 16) * 4 + cap * (4 + (int)(dtype == NUFFT_F32 ? sizeof(PointRec<float, 3>) : sizeof(PointRec<double, 3>)));
+}
+int slab_sort_capacity(int dtype, int lds_bytes) {
+    const int rb = 4 + (int)(dtype == NUFFT_F32 ? sizeof(PointRec<float, 3>) : sizeof(PointRec<double, 3>));
+    int cap = (lds_bytes - (kSlabMaxBins + 16) * 4) / rb;
+    cap &= ~63;
+    return cap > kSlabIPT * kSlabThreads ? kSlabIPT * kSlabThreads : cap;
+}
+hipError_t prepare_binsort_slab(int dtype, int lds_bytes) {
+    hipError_t e = prepare_binsort_coarse(dtype, kCoarseMaxKeys);
+    if (e != hipSuccess) return e;
+    return dtype == NUFFT_F32 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&slab_sort_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+                              : hipFuncSetAttribute(reinterpret_cast<const void*>(&slab_sort_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
 hipError_t prepare_binsort_coarse(int dtype, int nkeys) {
     const int bytes = nkeys * 4;
     hipError_t e;
@@ -329,7 +433,9 @@ static hipError_t coarse_count_t(const SortArgs& s, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((coarse_count_kernel<T>), dim3((unsigned)s.cs.groups), dim3(kCoarseThreads), (size_t)c.nkeys * 4, stream, bin_args3<T>(s), c, s.cs.table);
-    hipLaunchKernelGGL(coarse_prefix_kernel, dim3((unsigned)((c.nkeys + 63) / 64)), dim3(64), 0, stream, s.g, c, s.cs.groups, s.cs.table, s.counts);
+    hipLaunchKernelGGL(coarse_prefix_kernel, dim3((unsigned)((c.nkeys + 63) / 64)), dim3(64), 0, stream, s.g, c, s.cs.groups, s.cs.table, s.counts,
+                       s.cs.mode == 2 ? s.cs.flagmem : (uint32_t*)nullptr);
+    if (s.cs.mode == 2) hipLaunchKernelGGL(slab_flag_kernel, dim3(1), dim3(1), 0, stream, s.cs.flagmem, (uint32_t)s.cs.cap);
     size_t tmp = s.scan_tmp_bytes;
     return hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.nbins + 1, stream);
 }
@@ -350,8 +456,12 @@ static hipError_t coarse_finish_t(const SortArgs& s, hipStream_t stream) {
     size_t tmp = s.scan_tmp_bytes;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.nbins + 1, stream);
     if (e != hipSuccess) return e;
+    // (slab sort: level 1 leaves its records in the temporary array, level 2 sorts every slab by fine bin into `sorted`)
     hipLaunchKernelGGL((coarse_scatter_kernel<T>), dim3((unsigned)s.cs.groups), dim3(kCoarseThreads), (size_t)c.nkeys * 4, stream, a, c, s.cs.table, s.offsets,
-                       static_cast<PointRec<T, 3>*>(s.sorted), s.counts, fa, fb);
+                       static_cast<PointRec<T, 3>*>(s.cs.mode == 2 ? s.cs.temp : s.sorted), s.counts, fa, fb);
+    if (s.cs.mode == 2)
+        hipLaunchKernelGGL((slab_sort_kernel<T>), dim3((unsigned)c.nkeys), dim3(kSlabThreads), (size_t)s.cs.lds2, stream, s.g, c, s.cs.cap,
+                           static_cast<const PointRec<T, 3>*>(s.cs.temp), static_cast<PointRec<T, 3>*>(s.sorted), s.offsets, fa);
     if (s.np > 0) {
         int64_t blocks = (s.np + 255) / 256;
         if (blocks > 256 * 32) blocks = 256 * 32;

@@ -83,7 +83,19 @@ struct CoarseSort {
     uint32_t* table;           // [groups][nkeys]: per-slice counts, then exclusive prefixes over the slices
     const uint32_t* flag_a;    // both nonzero: this point set is column-layer sorted
     const uint32_t* flag_b;
+    // two-level sort by slabs (mode 2, below): level-1 records, what a level-2 workgroup holds, its LDS, {largest slab, flag}
+    int mode;                  // 1: column-layer sort; 2: slab sort
+    void* temp;
+    int cap, lds2;
+    uint32_t* flagmem;
 };
+// Two-level fine sort (mode 2; plans without a column-layer sort, D = 3): the same two passes with a SLAB of bins as the key — cbx = nb[0]
+// (one column along x), cby rows of bins, one layer: a contiguous range of fine bins — into a temporary array; then one workgroup per slab
+// sorts its records by fine bin in LDS and writes them, and the slab's share of the fine offsets, in order.  The result is the array and
+// the offsets of the fine sort (up to the order inside a bin) without a global atomic and with every store of level 2 coalesced; the slab
+// height is chosen per point set (set_points) so that a slab's points fit a workgroup's LDS, and point sets whose fullest slab does not
+// (clusters) take the fine sort with global atomics instead (device flag, flagmem[1]).
+constexpr int kSlabMaxBins = 4096;         // fine bins of a slab (16 KiB of LDS counters in level 2)
 constexpr int kCoarseMaxKeys = 36864;      // 144 KiB of LDS counters
 
 }  // namespace nufft

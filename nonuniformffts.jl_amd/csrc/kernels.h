@@ -32,6 +32,10 @@ hipError_t launch_binsort(const SortArgs& s, hipStream_t stream);
 // the two halves of a set_points on a plan with CoarseSort::enabled: column-layer histogram + scan (offsets valid for the task kernels
 // that decide flag_a / flag_b), then — after those kernels — the scatter of whichever sort the flags select
 hipError_t prepare_binsort_coarse(int dtype, int nkeys);
+// two-level slab sort (CoarseSort::mode = 2, column_tasks.h): records a level-2 workgroup holds in lds_bytes of LDS, and back
+int slab_sort_capacity(int dtype, int lds_bytes);
+int slab_sort_lds_bytes(int dtype, int cap);
+hipError_t prepare_binsort_slab(int dtype, int lds_bytes);
 hipError_t launch_binsort_coarse_count(const SortArgs& s, hipStream_t stream);
 hipError_t launch_binsort_coarse_finish(const SortArgs& s, hipStream_t stream);
 // zero fill by a kernel (hipGraph-safe, see binsort.hip); dst 16-byte aligned, bytes a multiple of 4

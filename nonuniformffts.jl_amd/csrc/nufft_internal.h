@@ -159,6 +159,9 @@ struct nufft_plan {
     uint32_t* d_counts = nullptr;      // [ntiles + 1]  histogram
     bool counts_clean = false;         // d_counts is all zero (plan creation; every completed set_points leaves it so)
     uint32_t* d_offsets = nullptr;     // [ntiles + 1]  exclusive scan
+    nufft::CoarseSort slab{};          // two-level slab sort (binsort.hip; D = 3 plans without a column-layer sort): table + flag words allocated,
+                                       // the slab height chosen per point set (nufft_set_points)
+    int64_t slab_min_points = 0;       // smaller point sets take the fine sort with global atomics (NUFFT_SLAB_MIN_POINTS)
     nufft::CoarseSort coarse{};        // column-layer sort (binsort.hip): enabled on plans whose two rings own the same columns; table allocated
     void* d_binrank = nullptr;         // uint2[Np]: (tile, rank)
     void* d_sorted = nullptr;          // PointRec<T, D>[Np]

@@ -722,6 +722,19 @@ static int build_device(nufft_plan* p) {
         }
     }
 
+    // every other 3-D plan: two-level slab sort (column_tasks.h) — the sorted array and offsets of the fine sort, without global atomics
+    p->slab = CoarseSort{};
+    if (D == 3 && !p->coarse.enabled && env_int("NUFFT_SLAB_SORT", 1) != 0 && p->tile.nb[0] <= kSlabMaxBins && p->tile.nb[2] <= kCoarseMaxKeys) {
+        p->slab.enabled = 1;
+        p->slab.mode = 2;
+        p->slab_min_points = env_int("NUFFT_SLAB_MIN_POINTS", 16384);
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->slab.table), (size_t)p->num_cus * kCoarseMaxKeys * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->slab.flagmem), 32))) return rc;      // [0] fullest slab (running), [4] flag
+        NUFFT_HIP(hipMemset(p->slab.flagmem, 0, 32));
+        p->slab.flag_a = p->slab.flag_b = p->slab.flagmem + 4;
+        NUFFT_HIP(prepare_binsort_slab(p->dtype, kLdsLimit - 256));
+    }
+
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->spread_method == NUFFT_SPREAD_MARCHING_RING || p->interp_march) NUFFT_HIP(prepare_column_tasks());
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
@@ -743,7 +756,7 @@ static void release(nufft_plan* p) {
         fr(p->d_coefs);
         for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
         fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks); fr(p->d_march_choice); fr(p->d_march_cols); fr(p->d_march_tasks);
-        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks); fr(p->d_smarch_halo); fr(p->coarse.table);
+        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks); fr(p->d_smarch_halo); fr(p->coarse.table); fr(p->slab.table); fr(p->slab.flagmem);
         fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
         fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
         fr(p->bal.d_slots); fr(p->bal.d_tmp);
@@ -1154,6 +1167,12 @@ int nufft_plan_get_index_map(const nufft_plan* p, int dim, int64_t* out, int64_t
     return NUFFT_OK;
 }
 
+// bytes per point of the {bin, rank} array of the fine sort; plans of the slab sort keep the records of its level 1 in the same allocation
+// (a point set takes one sort or the other)
+static int64_t binrank_bytes(const nufft_plan* p) {
+    return p->slab.enabled ? std::max<int64_t>(8, (int64_t)point_record_bytes(p->dtype, p->D)) : 8;
+}
+
 int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void* stream_) {
     int rc = require_device(p);
     if (rc) return rc;
@@ -1169,7 +1188,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     if (np > p->Np_capacity) {
         // resize_no_copy!, src/blocking/blocking.jl:55-61 (old contents are discarded).  hipFree / hipMalloc are not
         // capturable: pre-size the plan with the largest point set before capturing set_points in a hipGraph.
-        if (p->d_binrank) { (void)hipFree(p->d_binrank); p->workspace_bytes -= p->Np_capacity * 8; p->d_binrank = nullptr; }
+        if (p->d_binrank) { (void)hipFree(p->d_binrank); p->workspace_bytes -= p->Np_capacity * binrank_bytes(p); p->d_binrank = nullptr; }
         if (p->d_sorted) {
             (void)hipFree(p->d_sorted);
             p->workspace_bytes -= p->Np_capacity * (int64_t)point_record_bytes(p->dtype, p->D);
@@ -1182,7 +1201,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         }
         p->Np_capacity = 0;
         if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES && (rc = dev_alloc(p, &p->d_vsorted, (size_t)np * value_bytes(p) * p->C))) return rc;
-        if ((rc = dev_alloc(p, &p->d_binrank, (size_t)np * 8))) return rc;
+        if ((rc = dev_alloc(p, &p->d_binrank, (size_t)np * binrank_bytes(p)))) return rc;
         if ((rc = dev_alloc(p, &p->d_sorted, (size_t)np * point_record_bytes(p->dtype, p->D)))) return rc;
         p->Np_capacity = np;
     }
@@ -1204,10 +1223,43 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     s.scan_tmp_bytes = p->scan_tmp_bytes;
     s.cs = p->coarse;
     const bool coarse = p->coarse.enabled != 0;
+    bool slab = false;
+    if (p->slab.enabled && np >= std::max<int64_t>(p->slab_min_points, 1)) {
+        // slab height for this point set: the tallest slab (longest runs in level 1) whose average load is at most half of what a level-2
+        // workgroup can hold, while there are slabs enough to fill the chip
+        const int capmax = slab_sort_capacity(p->dtype, kLdsLimit - 256);
+        int best = -1;
+        for (int sby = 1; sby <= p->tile.nb[1] && (int64_t)sby * p->tile.nb[0] <= kSlabMaxBins; sby *= 2) {
+            const int64_t nkeys = (int64_t)p->tile.nb[2] * ((p->tile.nb[1] + sby - 1) / sby);
+            if (nkeys > kCoarseMaxKeys) continue;
+            if (np / nkeys > capmax / 2) break;
+            if (best > 0 && nkeys < 2048) break;
+            best = sby;
+        }
+        if (best > 0) {
+            slab = true;
+            s.cs = p->slab;
+            s.cs.cbx = p->tile.nb[0]; s.cs.ncx = 1;
+            s.cs.cby = best; s.cs.ncy = (p->tile.nb[1] + best - 1) / best;
+            s.cs.nkeys = p->tile.nb[2] * s.cs.ncy;
+            s.cs.groups = (int)std::min<int64_t>(p->num_cus, std::max<int64_t>(1, (np + 16383) / 16384));
+            const int64_t mean = np / s.cs.nkeys;
+            s.cs.cap = (int)std::min<int64_t>(capmax, (std::max<int64_t>(2 * mean, mean + 1536) + 63) / 64 * 64);
+            s.cs.lds2 = slab_sort_lds_bytes(p->dtype, s.cs.cap);
+            s.cs.temp = p->d_binrank;
+        }
+    }
     // plans of the column-layer sort: histogram by column layers first — its offsets are all the task kernels below need to decide
     // whether both rings serve this point set; the scatter pass (of whichever sort that decision selects) and the tile tables follow
     if (coarse) NUFFT_HIP(launch_binsort_coarse_count(s, stream));
-    else NUFFT_HIP(launch_binsort(s, stream));
+    else if (slab) {
+        // (nothing else decides here: the fullest slab does, on the device — both halves back to back)
+        NUFFT_HIP(launch_binsort_coarse_count(s, stream));
+        NUFFT_HIP(launch_binsort_coarse_finish(s, stream));
+    } else {
+        if (p->slab.enabled) NUFFT_HIP(launch_zero_fill(p->slab.flagmem + 4, 16, stream));      // (what nufft_sort_columns_used reports)
+        NUFFT_HIP(launch_binsort(s, stream));
+    }
     // slices per tile from the work each tile now holds (balance.hip)
     auto balance = [&]() -> int {
         const nufft_plan::Balance& b = p->bal;
@@ -1358,10 +1410,16 @@ int nufft_sort_columns_used(nufft_plan* p, int* used_out, void* stream_) {
     if (rc) return rc;
     if (!used_out) return fail(NUFFT_ERR_INVALID_ARG, "null output");
     *used_out = 0;
-    if (!p->coarse.enabled) return NUFFT_OK;
+    if (!p->coarse.enabled && !p->slab.enabled) return NUFFT_OK;
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t fa = 0, fb = 0;
+    if (p->slab.enabled) {
+        NUFFT_HIP(hipMemcpyAsync(&fa, p->slab.flag_a, sizeof(fa), hipMemcpyDeviceToHost, stream));
+        NUFFT_HIP(hipStreamSynchronize(stream));
+        *used_out = fa != 0 ? 2 : 0;
+        return NUFFT_OK;
+    }
     NUFFT_HIP(hipMemcpyAsync(&fa, p->coarse.flag_a, sizeof(fa), hipMemcpyDeviceToHost, stream));
     NUFFT_HIP(hipMemcpyAsync(&fb, p->coarse.flag_b, sizeof(fb), hipMemcpyDeviceToHost, stream));
     NUFFT_HIP(hipStreamSynchronize(stream));

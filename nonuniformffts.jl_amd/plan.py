@@ -327,7 +327,14 @@ class PlanNUFFT:
         point sets both rings serve); reads two device flags back and synchronises."""
         out = C.c_int(0)
         _check(lib.nufft_sort_columns_used(self._handle, C.byref(out), self._stream()))
-        return bool(out.value)
+        return out.value == 1
+
+    def sort_method_used(self) -> str:
+        """Sort of the last set_points: "column_layers", "fine_bins" (histogram with global atomics) or "slabs" (fine bins in two
+        levels through LDS: same array and offsets as "fine_bins"); reads device flags back and synchronises."""
+        out = C.c_int(0)
+        _check(lib.nufft_sort_columns_used(self._handle, C.byref(out), self._stream()))
+        return {0: "fine_bins", 1: "column_layers", 2: "slabs"}[out.value]
 
     def spread_engine_used(self) -> str:
         """Engine that serves the point set of the last set_points: "lds_tiles" or "mfma_patches" (plans of the

@@ -953,6 +953,51 @@ def test_bin_sort_is_a_permutation_grouped_by_bin():
     assert np.array_equal(np.diff(offs.astype(np.int64)), counts)
 
 
+@pytest.mark.parametrize("Z,dims,M", [(np.float64, (40, 36, 50), 4), (np.complex64, (64, 48, 40), 8), (np.float32, (30, 70, 36), 5),
+                                      (np.complex128, (24, 130, 20), 3)])
+def test_two_level_slab_sort_reproduces_the_fine_sort(Z, dims, M, monkeypatch):
+    """3-D plans without a column-layer sort order their points by fine bins in two levels (binsort.hip, CoarseSort::mode = 2: slabs of
+    bin rows with LDS histograms, then every slab inside a workgroup's LDS) — the offsets of the sort with global atomics exactly, the
+    same points in every bin, and the transforms against the oracle; a point set whose fullest slab does not fit a workgroup's LDS
+    (a cluster) takes the sort with global atomics (device flag)."""
+    nufft = _nufft()
+    Np = 30000
+    monkeypatch.setenv("NUFFT_COARSE_SORT", "0")
+    monkeypatch.setenv("NUFFT_SLAB_MIN_POINTS", "0")
+    _, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, O.FAST_APPROXIMATION, 1, Np, seed=77 + M)
+    monkeypatch.setenv("NUFFT_SLAB_SORT", "0")
+    _, plan0, _, _, _ = _make_case(Z, dims, M, 2.0, O.FAST_APPROXIMATION, 1, Np, seed=77 + M)
+    dev = plan.device
+    rng = np.random.default_rng(3)
+    T = plan_real_dtype(Z)
+    cluster = tuple((0.05 * rng.standard_normal(Np) + 1.0).astype(T) for _ in dims)
+    for name, pts in (("uniform", xs), ("cluster", cluster)):
+        xd = tuple(torch.from_numpy(x).to(dev) for x in pts)
+        nufft.set_points(plan, xd)
+        nufft.set_points(plan0, xd)
+        assert plan.sort_method_used() == ("slabs" if name == "uniform" else "fine_bins"), name
+        assert plan0.sort_method_used() == "fine_bins"
+        perm, offs = nufft.sort_result(plan)
+        perm0, offs0 = nufft.sort_result(plan0)
+        assert np.array_equal(np.sort(perm), np.arange(Np))
+        assert np.array_equal(offs, offs0), name
+        # the same points in every bin: sort each bin's run of the permutation
+        binid = np.repeat(np.arange(len(offs) - 1), np.diff(offs.astype(np.int64)))
+        assert np.array_equal(perm[np.lexsort((perm, binid))], perm0[np.lexsort((perm0, binid))]), name
+        O.set_points(oplan, pts)
+        u = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+        nufft.exec_type1(u, plan, torch.from_numpy(vs[0]).to(dev))
+        ref = O.exec_type1(oplan, _oracle_inputs(oplan, vs))
+        assert _rel(u.cpu().numpy(), ref[0]) < _rtol(Z), (name, "type 1")
+        out = torch.empty(Np, dtype=plan.Z, device=dev)
+        nufft.exec_type2(out, plan, u)
+        ref2 = O.exec_type2(oplan, _oracle_inputs(oplan, [u.cpu().numpy()])[0])
+        assert _rel(out.cpu().numpy(), ref2) < _rtol(Z), (name, "type 2")
+    # and back: a uniform set after the cluster (the running maximum of the slab loads is cleared by every set_points)
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    assert plan.sort_method_used() == "slabs"
+
+
 def test_edge_points_and_empty_input():
     """prevfloat(2π), prevfloat(π), 0, negative and shifted points (test/near_2pi.jl); Np = 0."""
     nufft = _nufft()
