@@ -188,6 +188,30 @@ __device__ __forceinline__ uint32_t coarse_key(const BinArgs<T, 3>& a, const Coa
     }
     return (uint32_t)((b[2] * c.ncy + b[1] / c.cby) * c.ncx + b[0] / c.cbx);
 }
+// the same from coordinates already in registers (the passes below load a batch ahead of the one they work on)
+template <typename T>
+__device__ __forceinline__ uint32_t coarse_key_of(const BinArgs<T, 3>& a, const CoarseGeom& c, const T (&x)[3], T (&r)[3]) {
+    int b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const T xf = transform_and_fold(x[d], a.point_transform);
+        r[d] = to_grid_units(xf, a.g.Nover[d]);
+        b[d] = cell_of(r[d], a.g.Nover[d]) >> a.g.blog[d];
+    }
+    return (uint32_t)((b[2] * c.ncy + b[1] / c.cby) * c.ncx + b[0] / c.cbx);
+}
+// coordinates of points p0 + u THREADS + tid (u < U) of a slice that ends at hi
+template <typename T, int U>
+__device__ __forceinline__ void coarse_load(const BinArgs<T, 3>& a, int64_t p0, int64_t hi, int tid, T (&x)[U][3]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t p = p0 + u * 1024 + tid;
+        if (p < hi) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) x[u][d] = a.x[d][p];
+        }
+    }
+}
 // first fine bin of a column layer: where its total sits in the fake fine histogram
 __device__ __forceinline__ int64_t coarse_rep_bin(const Geom& g, const CoarseGeom& c, int k) {
     const int cx = k % c.ncx, t = k / c.ncx, cy = t % c.ncy, bz = t / c.ncy;
@@ -210,17 +234,28 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_count_kernel(BinArgs<T,
     __syncthreads();
     int64_t lo, hi;
     coarse_slice(a.np, (int)gridDim.x, w, lo, hi);
-    for (int64_t p0 = lo; p0 < hi; p0 += 4 * kCoarseThreads) {
-        uint32_t key[4];
+    // two batches of 4 points per thread in registers: the loads of one are in flight while the other is counted (0.71 -> see DESIGN 4.10)
+    constexpr int U = 4;
+    constexpr int64_t S = (int64_t)U * kCoarseThreads;
+    static_assert(kCoarseThreads == 1024, "coarse_load strides by 1024");
+    T xa[U][3], xb[U][3];
+    auto consume = [&](int64_t p0, const T (&x)[U][3]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t p = p0 + u * kCoarseThreads + tid;
+        for (int u = 0; u < U; ++u) {
             T r[3];
-            key[u] = p < hi ? coarse_key<T>(a, c, p, r) : 0xffffffffu;
+            if (p0 + u * kCoarseThreads + tid < hi) atomicAdd(&hist[coarse_key_of<T>(a, c, x[u], r)], 1u);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (key[u] != 0xffffffffu) atomicAdd(&hist[key[u]], 1u);
+    };
+    int64_t p0 = lo;
+    if (p0 < hi) coarse_load<T, U>(a, p0, hi, tid, xa);
+    while (p0 < hi) {
+        if (p0 + S < hi) coarse_load<T, U>(a, p0 + S, hi, tid, xb);
+        consume(p0, xa);
+        p0 += S;
+        if (p0 >= hi) break;
+        if (p0 + S < hi) coarse_load<T, U>(a, p0 + S, hi, tid, xa);
+        consume(p0, xb);
+        p0 += S;
     }
     __syncthreads();
     uint32_t* row = table + (size_t)w * c.nkeys;
@@ -287,21 +322,35 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(BinArgs<
     __syncthreads();
     int64_t lo, hi;
     coarse_slice(a.np, (int)gridDim.x, w, lo, hi);
-    for (int64_t p0 = lo; p0 < hi; p0 += 2 * kCoarseThreads) {
-        PointRec<T, 3> rec[2];
-        uint32_t key[2];
+    constexpr int U = 2;
+    constexpr int64_t S = (int64_t)U * kCoarseThreads;
+    T xa[U][3], xb[U][3];
+    auto consume = [&](int64_t p0, const T (&x)[U][3]) __attribute__((always_inline)) {
+        PointRec<T, 3> rec[U];
+        uint32_t key[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int64_t p = p0 + u * kCoarseThreads + tid;
             key[u] = 0xffffffffu;
             if (p < hi) {
-                key[u] = coarse_key<T>(a, c, p, rec[u].r);
+                key[u] = coarse_key_of<T>(a, c, x[u], rec[u].r);
                 rec[u].idx = (int32_t)p;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
             if (key[u] != 0xffffffffu) sorted[atomicAdd(&cursor[key[u]], 1u)] = rec[u];
+    };
+    int64_t p0 = lo;
+    if (p0 < hi) coarse_load<T, U>(a, p0, hi, tid, xa);
+    while (p0 < hi) {
+        if (p0 + S < hi) coarse_load<T, U>(a, p0 + S, hi, tid, xb);
+        consume(p0, xa);
+        p0 += S;
+        if (p0 >= hi) break;
+        if (p0 + S < hi) coarse_load<T, U>(a, p0 + S, hi, tid, xa);
+        consume(p0, xb);
+        p0 += S;
     }
     // the histogram has been scanned: clear it for the next set_points (only the first bins of the column layers hold anything)
     __syncthreads();

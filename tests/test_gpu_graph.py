@@ -135,3 +135,53 @@ def test_graph_replay_on_a_plan_of_the_column_layer_sort():
         ref1 = O.exec_type1(oplan, v)
         assert _rel(ud.cpu().numpy(), ref1) < 1e-7, kind
         assert _rel(wd.cpu().numpy(), O.exec_type2(oplan, ref1)) < 1e-7, kind
+
+
+def test_graph_replay_on_a_plan_of_the_slab_sort():
+    """A captured set_points! + exec_type1! + exec_type2! on a plan that orders its points by fine bins in two levels (binsort.hip, slab sort):
+    both sorts are part of the captured sequence and the fullest slab of every replay decides which one runs — replayed on a uniform set
+    (slabs), on a tight cluster (global atomics), and on a uniform set again."""
+    from nufft_pkg import nufft
+    dims, Np = (48, 40, 36), 40000
+    plan = nufft.PlanNUFFT(np.complex64, dims, m=5, sigma=2.0, kernel_evalmode=nufft.Direct(), backend=nufft.ROCBackend(0))
+    assert plan.info().sort_column[0] == 0
+    oplan = O.OraclePlan(dims, is_real=False, dtype=np.float32, M=5, sigma=2.0, evalmode=O.DIRECT)
+    dev = plan.device
+    rng = np.random.default_rng(22)
+
+    def inputs(kind):
+        if kind == "cluster":
+            xs = [(1.0 + 0.02 * rng.standard_normal(Np)).astype(np.float32) for _ in dims]
+        else:
+            xs = [(rng.random(Np) * O.TWO_PI).astype(np.float32) for _ in dims]
+        return xs, (rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(np.complex64)
+
+    xs0, v0 = inputs("uniform")
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs0)
+    vd = torch.from_numpy(v0).to(dev)
+    ud = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    wd = torch.empty(Np, dtype=plan.Z, device=dev)
+
+    def step():
+        nufft.set_points(plan, xd)
+        nufft.exec_type1(ud, plan, vd)
+        nufft.exec_type2(wd, plan, ud)
+
+    step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for kind in ("uniform", "cluster", "uniform"):
+        xs, v = inputs(kind)
+        for d in range(3):
+            xd[d].copy_(torch.from_numpy(xs[d]))
+        vd.copy_(torch.from_numpy(v))
+        ud.zero_(); wd.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert plan.sort_method_used() == ("slabs" if kind == "uniform" else "fine_bins"), kind
+        O.set_points(oplan, xs)
+        ref1 = O.exec_type1(oplan, v)
+        assert _rel(ud.cpu().numpy(), ref1) < 2e-5, kind
+        assert _rel(wd.cpu().numpy(), O.exec_type2(oplan, ref1)) < 2e-5, kind
