@@ -422,7 +422,7 @@ def main():
             "workspace_bytes": int(plan.info().workspace_bytes),       # plan-owned device memory with this point set in place
             "ring_column": [int(info.ring_column[0]), int(info.ring_column[1])], "ring_segments": int(info.ring_segments),
             "ring_halo": int(info.ring_halo), "fft_plain_ms": fft_plain_ms,
-            "sort_columns": bool(plan.sort_columns_used()), "sort_column_bins": [int(info.sort_column[0]), int(info.sort_column[1])],
+            "sort_columns": bool(plan.sort_columns_used()), "sort_method": plan.sort_method_used(), "sort_column_bins": [int(info.sort_column[0]), int(info.sort_column[1])],
             "spread_engine": engine_used, "patch_f32acc": int(info.patch_f32acc), "patch_dims": [int(info.patch_dims[0]), int(info.patch_dims[1])], "patch_planar": int(info.patch_planar),
             "oversampled": [int(x) for x in plan.oversampled_dims], "size": [int(x) for x in plan.size],
             "spread_tile": [int(info.spread_tile[d]) for d in range(3)], "interp_tile": [int(info.interp_tile[d]) for d in range(3)],
@@ -538,7 +538,7 @@ def main():
             "protocol": "set_points! + exec_type1! per step, inputs resident in HBM (reference benchmark protocol)",
             "spread_engine": head["spread_engine"], "spread_tile": head["spread_tile"], "interp_tile": head["interp_tile"],
             "ring_column": head["ring_column"], "ring_segments": head["ring_segments"], "ring_halo": head["ring_halo"], "workspace_bytes": head["workspace_bytes"],
-            "sort_columns": head["sort_columns"], "sort_column_bins": head["sort_column_bins"],
+            "sort_columns": head["sort_columns"], "sort_method": head["sort_method"], "sort_column_bins": head["sort_column_bins"],
             "set_points_ms": st1["set_points"], "spread_ms": st1["spread"], "fft_ms": st1["fft"], "deconv_ms": st1["deconv"], "interp_ms": st2["interp"],
             "type2_value": head["type2"]["with_set_points_pts_per_s"],
             "parallelism": (f"ntransforms = {C_total} components of one transform sharded over {world} GPU(s) (component c on rank c mod N, same points)"
@@ -590,7 +590,7 @@ def main():
                     "roofline_frac_own_traffic": abo["spread_kernel_min"] / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "interp_roofline_frac": abo["interp_kernel"] / (ip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "workspace_bytes": r["workspace_bytes"],
-                    "set_points_ms": r["type1"]["stages_ms"]["set_points"], "sort_columns": r["sort_columns"],
+                    "set_points_ms": r["type1"]["stages_ms"]["set_points"], "sort_columns": r["sort_columns"], "sort_method": r["sort_method"],
                     "direct_value": rd["value"], "direct_type2_value": rd["type2"]["with_set_points_pts_per_s"],
                     "direct_spread_ms": rd["type1"]["stages_ms"]["spread"], "direct_interp_ms": rd["type2"]["stages_ms"]["interp"],
                 }
@@ -617,7 +617,7 @@ def main():
                 result["config"][f"{name}_error"] = r["error"]
                 continue
             for k in ("value", "ms_per_step", "type2_value", "type2_ms_per_step", "spread_ms", "interp_ms", "spread_engine", "roofline_frac",
-                      "ring_halo", "fft_ms", "fft_plain_ms", "set_points_ms", "sort_columns", "direct_value", "direct_type2_value", "direct_spread_ms", "direct_interp_ms",
+                      "ring_halo", "fft_ms", "fft_plain_ms", "set_points_ms", "sort_columns", "sort_method", "direct_value", "direct_type2_value", "direct_spread_ms", "direct_interp_ms",
                       "roofline_frac_own_traffic", "interp_roofline_frac", "workspace_bytes", "fp32_achieved_tflops", "fp32_frac",
                       "interp_fp32_achieved_tflops", "interp_fp32_frac"):
                 if k in r:

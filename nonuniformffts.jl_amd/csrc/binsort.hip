@@ -293,9 +293,11 @@ __global__ __launch_bounds__(64) void coarse_prefix_kernel(Geom g, CoarseGeom c,
         if (threadIdx.x == 0) atomicMax(maxout, m);
     }
 }
-// slab sort: fm[4] = 1 when the fullest slab fits a level-2 workgroup; fm[0] (the running maximum) cleared for the next set_points
-__global__ void slab_flag_kernel(uint32_t* fm, uint32_t cap) {
-    fm[4] = fm[0] <= cap ? 1u : 0u;
+// slab sort: fm[4] = 1 while the fullest slab stays within `limit` records (kSlabOverfill capacities of a level-2 workgroup: fuller slabs are
+// sorted by two passes over global memory, which one workgroup should not do for a large part of the point set); fm[0] (the running
+// maximum) cleared for the next set_points
+__global__ void slab_flag_kernel(uint32_t* fm, uint32_t limit) {
+    fm[4] = fm[0] <= limit ? 1u : 0u;
     fm[0] = 0u;
 }
 
@@ -379,22 +381,8 @@ __global__ __launch_bounds__(kSlabThreads) void slab_sort_kernel(Geom g, CoarseG
     const uint32_t base = offsets[rep], n = offsets[rep + nbs] - base;
     for (int i = tid; i < nbs; i += kSlabThreads) cnt[i] = 0u;
     __syncthreads();
-    uint32_t av[kSlabIPT];
-#pragma unroll
-    for (int u = 0; u < kSlabIPT; ++u) {
-        const uint32_t i = (uint32_t)(u * kSlabThreads + tid);
-        av[u] = 0u;
-        if (i < n) {
-            const PointRec<T, 3> rec = temp[base + i];
-            recs[i] = rec;
-            const int b0 = cell_of(rec.r[0], g.Nover[0]) >> g.blog[0], b1 = cell_of(rec.r[1], g.Nover[1]) >> g.blog[1];
-            const uint32_t fb = (uint32_t)((b1 - cy * c.cby) * g.nb[0] + b0);
-            av[u] = fb << 16 | atomicAdd(&cnt[fb], 1u);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the bin counts: 4 consecutive bins per thread, wave scan, wave totals
-    {
+    // block-wide exclusive scan of cnt[0 .. nbs) in place (4 consecutive bins per thread, wave scan, wave totals) + the slab's fine offsets
+    auto scan_bins = [&]() __attribute__((always_inline)) {
         uint32_t v[4], tsum = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -422,8 +410,38 @@ __global__ __launch_bounds__(kSlabThreads) void slab_sort_kernel(Geom g, CoarseG
             }
             run += v[j];
         }
+        __syncthreads();
+    };
+    auto bin_of = [&](const PointRec<T, 3>& rec) __attribute__((always_inline)) -> uint32_t {
+        const int b0 = cell_of(rec.r[0], g.Nover[0]) >> g.blog[0], b1 = cell_of(rec.r[1], g.Nover[1]) >> g.blog[1];
+        return (uint32_t)((b1 - cy * c.cby) * g.nb[0] + b0);
+    };
+    if (n > (uint32_t)cap) {
+        // a slab fuller than the LDS holds (denser regions of a non-uniform set): two passes over its records instead — histogram, scan, then
+        // every record to the cursor of its bin (scattered stores, but inside the slab's own range and all from this workgroup: they meet in L2)
+        for (uint32_t i = (uint32_t)tid; i < n; i += kSlabThreads) atomicAdd(&cnt[bin_of(temp[base + i])], 1u);
+        __syncthreads();
+        scan_bins();
+        for (uint32_t i = (uint32_t)tid; i < n; i += kSlabThreads) {
+            const PointRec<T, 3> rec = temp[base + i];
+            sorted[base + atomicAdd(&cnt[bin_of(rec)], 1u)] = rec;
+        }
+        return;
+    }
+    uint32_t av[kSlabIPT];
+#pragma unroll
+    for (int u = 0; u < kSlabIPT; ++u) {
+        const uint32_t i = (uint32_t)(u * kSlabThreads + tid);
+        av[u] = 0u;
+        if (i < n) {
+            const PointRec<T, 3> rec = temp[base + i];
+            recs[i] = rec;
+            const uint32_t fb = bin_of(rec);
+            av[u] = fb << 16 | atomicAdd(&cnt[fb], 1u);
+        }
     }
     __syncthreads();
+    scan_bins();
 #pragma unroll
     for (int u = 0; u < kSlabIPT; ++u) {
         const uint32_t i = (uint32_t)(u * kSlabThreads + tid);
@@ -484,7 +502,7 @@ static hipError_t coarse_count_t(const SortArgs& s, hipStream_t stream) {
     hipLaunchKernelGGL((coarse_count_kernel<T>), dim3((unsigned)s.cs.groups), dim3(kCoarseThreads), (size_t)c.nkeys * 4, stream, bin_args3<T>(s), c, s.cs.table);
     hipLaunchKernelGGL(coarse_prefix_kernel, dim3((unsigned)((c.nkeys + 63) / 64)), dim3(64), 0, stream, s.g, c, s.cs.groups, s.cs.table, s.counts,
                        s.cs.mode == 2 ? s.cs.flagmem : (uint32_t*)nullptr);
-    if (s.cs.mode == 2) hipLaunchKernelGGL(slab_flag_kernel, dim3(1), dim3(1), 0, stream, s.cs.flagmem, (uint32_t)s.cs.cap);
+    if (s.cs.mode == 2) hipLaunchKernelGGL(slab_flag_kernel, dim3(1), dim3(1), 0, stream, s.cs.flagmem, (uint32_t)s.cs.cap * (uint32_t)kSlabOverfill);
     size_t tmp = s.scan_tmp_bytes;
     return hipcub::DeviceScan::ExclusiveSum(s.scan_tmp, tmp, s.counts, s.offsets, s.g.nbins + 1, stream);
 }

@@ -93,9 +93,11 @@ struct CoarseSort {
 // (one column along x), cby rows of bins, one layer: a contiguous range of fine bins — into a temporary array; then one workgroup per slab
 // sorts its records by fine bin in LDS and writes them, and the slab's share of the fine offsets, in order.  The result is the array and
 // the offsets of the fine sort (up to the order inside a bin) without a global atomic and with every store of level 2 coalesced; the slab
-// height is chosen per point set (set_points) so that a slab's points fit a workgroup's LDS, and point sets whose fullest slab does not
-// (clusters) take the fine sort with global atomics instead (device flag, flagmem[1]).
+// height is chosen per point set (set_points) so that a slab's points fit a workgroup's LDS on average with room to spare; fuller slabs (denser
+// regions) are sorted by the same workgroup in two passes over global memory, and point sets whose fullest slab exceeds kSlabOverfill
+// capacities (clusters) take the fine sort with global atomics instead (device flag, flagmem[4]).
 constexpr int kSlabMaxBins = 4096;         // fine bins of a slab (16 KiB of LDS counters in level 2)
+constexpr int kSlabOverfill = 8;           // a slab may hold this many LDS capacities (level 2 then sorts it through global memory)
 constexpr int kCoarseMaxKeys = 36864;      // 144 KiB of LDS counters
 
 }  // namespace nufft

@@ -161,6 +161,7 @@ struct nufft_plan {
     uint32_t* d_offsets = nullptr;     // [ntiles + 1]  exclusive scan
     nufft::CoarseSort slab{};          // two-level slab sort (binsort.hip; D = 3 plans without a column-layer sort): table + flag words allocated,
                                        // the slab height chosen per point set (nufft_set_points)
+    int slab_fill = 85;                // a slab's average load, percent of what a level-2 workgroup holds, at most (NUFFT_SLAB_FILL)
     int64_t slab_min_points = 0;       // smaller point sets take the fine sort with global atomics (NUFFT_SLAB_MIN_POINTS)
     nufft::CoarseSort coarse{};        // column-layer sort (binsort.hip): enabled on plans whose two rings own the same columns; table allocated
     void* d_binrank = nullptr;         // uint2[Np]: (tile, rank)

@@ -958,8 +958,9 @@ def test_bin_sort_is_a_permutation_grouped_by_bin():
 def test_two_level_slab_sort_reproduces_the_fine_sort(Z, dims, M, monkeypatch):
     """3-D plans without a column-layer sort order their points by fine bins in two levels (binsort.hip, CoarseSort::mode = 2: slabs of
     bin rows with LDS histograms, then every slab inside a workgroup's LDS) — the offsets of the sort with global atomics exactly, the
-    same points in every bin, and the transforms against the oracle; a point set whose fullest slab does not fit a workgroup's LDS
-    (a cluster) takes the sort with global atomics (device flag)."""
+    same points in every bin, and the transforms against the oracle; slabs fuller than a workgroup's LDS are sorted in two passes over
+    global memory (the "dense" set), and a point set whose fullest slab exceeds eight capacities (a cluster) takes the sort with global atomics
+    (device flag)."""
     nufft = _nufft()
     Np = 30000
     monkeypatch.setenv("NUFFT_COARSE_SORT", "0")
@@ -971,11 +972,12 @@ def test_two_level_slab_sort_reproduces_the_fine_sort(Z, dims, M, monkeypatch):
     rng = np.random.default_rng(3)
     T = plan_real_dtype(Z)
     cluster = tuple((0.05 * rng.standard_normal(Np) + 1.0).astype(T) for _ in dims)
-    for name, pts in (("uniform", xs), ("cluster", cluster)):
+    dense = tuple((0.3 * rng.standard_normal(Np) + 2.0).astype(T) for _ in dims)       # slabs fuller than a workgroup's LDS: level 2 in two passes
+    for name, pts in (("uniform", xs), ("dense", dense), ("cluster", cluster)):
         xd = tuple(torch.from_numpy(x).to(dev) for x in pts)
         nufft.set_points(plan, xd)
         nufft.set_points(plan0, xd)
-        assert plan.sort_method_used() == ("slabs" if name == "uniform" else "fine_bins"), name
+        assert plan.sort_method_used() == ("fine_bins" if name == "cluster" else "slabs"), name
         assert plan0.sort_method_used() == "fine_bins"
         perm, offs = nufft.sort_result(plan)
         perm0, offs0 = nufft.sort_result(plan0)
