@@ -177,18 +177,7 @@ struct CoarseGeom {
 };
 constexpr int kCoarseThreads = 1024;
 
-template <typename T>
-__device__ __forceinline__ uint32_t coarse_key(const BinArgs<T, 3>& a, const CoarseGeom& c, int64_t p, T (&r)[3]) {
-    int b[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const T xf = transform_and_fold(a.x[d][p], a.point_transform);
-        r[d] = to_grid_units(xf, a.g.Nover[d]);
-        b[d] = cell_of(r[d], a.g.Nover[d]) >> a.g.blog[d];
-    }
-    return (uint32_t)((b[2] * c.ncy + b[1] / c.cby) * c.ncx + b[0] / c.cbx);
-}
-// the same from coordinates already in registers (the passes below load a batch ahead of the one they work on)
+// key of a point from its coordinates (the passes below load a batch ahead of the one they work on)
 template <typename T>
 __device__ __forceinline__ uint32_t coarse_key_of(const BinArgs<T, 3>& a, const CoarseGeom& c, const T (&x)[3], T (&r)[3]) {
     int b[3];
