@@ -151,7 +151,7 @@ def test_graph_replay_on_a_plan_of_the_slab_sort():
 
     def inputs(kind):
         if kind == "cluster":
-            xs = [(1.0 + 0.02 * rng.standard_normal(Np)).astype(np.float32) for _ in dims]
+            xs = [(1.0 + 0.01 * rng.standard_normal(Np)).astype(np.float32) for _ in dims]
         else:
             xs = [(rng.random(Np) * O.TWO_PI).astype(np.float32) for _ in dims]
         return xs, (rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(np.complex64)

@@ -971,7 +971,7 @@ def test_two_level_slab_sort_reproduces_the_fine_sort(Z, dims, M, monkeypatch):
     dev = plan.device
     rng = np.random.default_rng(3)
     T = plan_real_dtype(Z)
-    cluster = tuple((0.05 * rng.standard_normal(Np) + 1.0).astype(T) for _ in dims)
+    cluster = tuple((0.01 * rng.standard_normal(Np) + 1.0).astype(T) for _ in dims)      # nearly all points in one slab
     dense = tuple((0.3 * rng.standard_normal(Np) + 2.0).astype(T) for _ in dims)       # slabs fuller than a workgroup's LDS: level 2 in two passes
     for name, pts in (("uniform", xs), ("dense", dense), ("cluster", cluster)):
         xd = tuple(torch.from_numpy(x).to(dev) for x in pts)
