@@ -442,6 +442,27 @@ def test_interpolation_ring_every_instantiation(Z, M, monkeypatch):
     assert _rel(out2.cpu().numpy(), ref) < _rtol(Z)
 
 
+@pytest.mark.parametrize("M,C", [(4, 2), (7, 3)])
+def test_interpolation_ring_complex128_components_part_by_part(M, C, monkeypatch):
+    """ComplexF64 with ntransforms > 1 through the real ring kernels: a launch of 2 x tasks workgroups per component (the two parts of a
+    task side by side, march_setup.inc), type 2 against the oracle per component."""
+    monkeypatch.setenv("NUFFT_INTERP_MARCH", "2")
+    dims, Np = (48, 40, 56), 5000
+    nufft, plan, oplan, xs, vs = _make_case(np.complex128, dims, M, 2.0, O.DIRECT, C, Np, seed=300 + M)
+    dev = plan.device
+    rng = np.random.default_rng(M)
+    ws = [(rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)) for _ in range(C)]
+    wd = tuple(torch.from_numpy(w).to(dev) for w in ws)
+    nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+    O.set_points(oplan, xs)
+    outs = tuple(torch.empty(Np, dtype=plan.Z, device=dev) for _ in range(C))
+    nufft.exec_type2(outs, plan, wd)
+    assert plan.interp_engine_used() == "marching_ring"
+    ref = O.exec_type2(oplan, ws)
+    for c in range(C):
+        assert _rel(outs[c].cpu().numpy(), ref[c]) < _rtol(np.complex128), c
+
+
 @pytest.mark.parametrize("M", range(2, 11))
 @pytest.mark.parametrize("Z", [np.float32, np.complex64, np.float64, np.complex128])
 def test_spreading_ring_every_instantiation(Z, M, monkeypatch):
@@ -640,7 +661,7 @@ def test_forwarded_kernel_data_reproduces_the_plan(Z, dims, M, sigma, kname):
                                              (np.float64, 5, 1, O.DIRECT), (np.float32, 6, 1, O.FAST_APPROXIMATION), (np.float64, 6, 1, O.DIRECT),
                                              (np.float32, 7, 1, O.DIRECT),
                                              # ComplexF64: both rings run the real kernels part by part, so the plan shares their columns
-                                             (np.complex128, 4, 1, O.FAST_APPROXIMATION), (np.complex128, 6, 2, O.DIRECT)])
+                                             (np.complex128, 4, 1, O.FAST_APPROXIMATION), (np.complex128, 4, 2, O.DIRECT), (np.complex128, 6, 2, O.DIRECT)])
 def test_column_layer_sort_and_staged_interpolation(Z, M, C, evalmode, monkeypatch):
     """Plans whose spreading window (halo variant) and interpolation ring own the same columns sort the points by (column, layer of
     bins) only (binsort.hip, CoarseSort: LDS histograms, no global atomics) and interpolate with interp_march_staged_kernel, which
