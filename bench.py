@@ -721,8 +721,8 @@ def cpu_baseline(cfg):
                                                 "device": rows["header"].get("Device"), "sigma": 1.5,
                                                 "source": "benchmark/CPU+AMDGPU/results.MI300A_adastra/" + rows["file"],
                                                 "note": "the reference's own CPU backend on its machine (other hardware, sigma = 1.5, denser "
-                                                        "points): 4-5x this port's figure, which merges 13.8k-cell padded blocks holding "
-                                                        "~300 points each at C2's density"}}
+                                                        "points); this port merges 13.8k-cell padded blocks holding ~300 points each at "
+                                                        "C2's density"}}
     try:
         from oracle import c_oracle as CO, nufft_oracle as O
         if cfg["Z"] != "float64" or cfg["C"] != 1:
@@ -752,7 +752,8 @@ def cpu_baseline(cfg):
         return dict({"value": Np_s / t, "unit": "NU-points/s", "cores": cores, "kind": "port",
                      "sample": f"one set_points+type-1 transform, same grid ({n}^3, sigma={sigma}, m={m}), "
                                f"Np={Np_s} of {Np_full} points, {t:.1f} s wall; C/OpenMP blocked spreading (plain adds under a lock, "
-                               f"the reference's default) + scipy pocketfft, polynomial window (the reference's CPU default); threads = CPUs "
+                               f"the reference's default) + scipy pocketfft + C/OpenMP truncation and deconvolution, plan-owned work arrays "
+                               f"(third transform of the plan), polynomial window (the reference's CPU default); threads = CPUs "
                                f"available to the process (affinity capped by the cgroup quota: {CO.available_cpus()} of {os.cpu_count()} logical CPUs)",
                      "seconds": t}, **note)
     except Exception as exc:  # the baseline is informative only

@@ -362,6 +362,38 @@ int oracle_interp_blocked(int D, const int64_t* N, int M, int evalmode, int ncom
     return 0;
 }
 
+/* Type-1 epilogue: out[k3][k2][k1] = uhat[i3[k3]][i2[k2]][i1[k1]] * norm / (phihat1[k1] phihat2[k2] phihat3[k3]) — truncation to the
+ * requested modes + deconvolution + normalisation in one threaded pass (exec_type1!, src/NonuniformFFTs.jl:372-379,394-401: the
+ * reference does the same copy per output index inside its threaded loop).  Arrays in C order with dimension 1 fastest;
+ * ns[d] = size of the oversampled spectrum, no[d] = modes kept, idx[d][k] = source index, inv[d][k] = 1 / phihat_d[k]. */
+int oracle_deconv_truncate(int D, const int64_t* ns, const int64_t* no, const int64_t* const* idx, const double* const* inv,
+                           double norm, const double* uhat, double* out) {
+    const int64_t n1 = no[0], n2 = D >= 2 ? no[1] : 1, n3 = D >= 3 ? no[2] : 1;
+    const int64_t s1 = ns[0], s2 = D >= 2 ? ns[1] : 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t k3 = 0; k3 < n3; ++k3) {
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            const int64_t i3 = D >= 3 ? idx[2][k3] : 0, i2 = D >= 2 ? idx[1][k2] : 0;
+            const double f23 = norm * (D >= 3 ? inv[2][k3] : 1.0) * (D >= 2 ? inv[1][k2] : 1.0);
+            const double* src = uhat + 2 * ((i3 * s2 + i2) * s1);
+            double* dst = out + 2 * ((k3 * n2 + k2) * n1);
+            for (int64_t k1 = 0; k1 < n1; ++k1) {
+                const double f = f23 * inv[0][k1];
+                const int64_t i1 = idx[0][k1];
+                dst[2 * k1] = src[2 * i1] * f;
+                dst[2 * k1 + 1] = src[2 * i1 + 1] * f;
+            }
+        }
+    }
+    return 0;
+}
+
+/* threaded zero fill of a plan-owned work array (the reference's fill!(us, 0) at the start of exec_type1!, src/NonuniformFFTs.jl:161-167) */
+void oracle_zero(double* p, int64_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) p[i] = 0.0;
+}
+
 void oracle_set_num_threads(int n) {
     if (n > 0) omp_set_num_threads(n);
 }
