@@ -975,7 +975,7 @@ def test_bin_sort_is_a_permutation_grouped_by_bin():
 
 
 @pytest.mark.parametrize("Z,dims,M", [(np.float64, (40, 36, 50), 4), (np.complex64, (64, 48, 40), 8), (np.float32, (30, 70, 36), 5),
-                                      (np.complex128, (24, 130, 20), 3)])
+                                      (np.complex128, (24, 130, 20), 3), (np.complex128, (32, 48, 32), 10)])      # (M = 10: bins of 2 cells)
 def test_two_level_slab_sort_reproduces_the_fine_sort(Z, dims, M, monkeypatch):
     """3-D plans without a column-layer sort order their points by fine bins in two levels (binsort.hip, CoarseSort::mode = 2: slabs of
     bin rows with LDS histograms, then every slab inside a workgroup's LDS) — the offsets of the sort with global atomics exactly, the
