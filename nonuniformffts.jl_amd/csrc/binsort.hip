@@ -468,7 +468,10 @@ hipError_t prepare_binsort_slab(int dtype, int lds_bytes) {
                               : hipFuncSetAttribute(reinterpret_cast<const void*>(&slab_sort_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
 hipError_t prepare_binsort_coarse(int dtype, int nkeys) {
-    const int bytes = nkeys * 4;
+    // (the attribute belongs to the kernel, not to the plan: always the largest table, so that a plan created later cannot lower it
+    // under what an earlier plan launches with)
+    if (nkeys > kCoarseMaxKeys) return hipErrorInvalidValue;
+    const int bytes = kCoarseMaxKeys * 4;
     hipError_t e;
     if (dtype == NUFFT_F32) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_count_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -293,6 +293,10 @@ bool needs_other_eval(int kernel, int evalmode) {
 }
 
 static hipError_t prepare(bool interp, int dtype, int is_complex, int D, int M, int lds_bytes, bool other) {
+    // The attribute belongs to the kernel, not to the plan: another plan of the same instantiation with a smaller tile must not lower it
+    // under what this plan launches with — always the whole LDS of a gfx950 workgroup (the launch itself asks for the plan's bytes).
+    if (lds_bytes > 163840) return hipErrorInvalidValue;
+    lds_bytes = 163840;
     for (int wrap = 0; wrap < 2; ++wrap) {
         const void* fn = pick(interp, dtype, is_complex, D, M, wrap != 0, other);
         if (!fn && interp && wrap) continue;       // no compile-time tile for this instantiation

@@ -70,3 +70,41 @@ def test_side_stream_and_interleaved_plans():
     nufft.set_points(pa, xs)
     nufft.exec_type1(ua, pa, v)
     assert float((ua - ref_a).norm() / ref_a.norm()) < 1e-12
+
+
+def test_a_later_plan_does_not_lower_an_earlier_plans_lds_allowance(monkeypatch):
+    """hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to the plan: a plan with a small tile (or few sort keys)
+    created after a plan with a large one — same kernel instantiation — must leave the earlier plan launchable.  2-D tile kernels with
+    a large and a tiny tile; and the LDS histograms of the two sorts: a slab-sorted plan with 34 560 keys (135 KiB), then a column-layer
+    plan (fewer keys), then the first plan's set_points."""
+    from nufft_pkg import nufft
+    g = torch.Generator(device="cuda").manual_seed(9)
+    big = nufft.PlanNUFFT(torch.float64, (256, 256), m=4, backend=nufft.ROCBackend(0))
+    small = nufft.PlanNUFFT(torch.float64, (16, 16), m=4, backend=nufft.ROCBackend(0))
+    assert big.info().lds_bytes_spread > small.info().lds_bytes_spread
+    xs = tuple(torch.rand(20000, dtype=torch.float64, device="cuda", generator=g) * (2 * np.pi) for _ in range(2))
+    v = torch.randn(20000, dtype=torch.float64, device="cuda", generator=g)
+    k = torch.tensor([7.0, -11.0], dtype=torch.float64, device="cuda")
+    exact = (v * torch.polar(torch.ones_like(v), -(k[0] * xs[0] + k[1] * xs[1]))).sum()
+    for p in (small, big):
+        u = torch.empty(p.shape, dtype=torch.complex128, device="cuda")
+        nufft.set_points(p, xs)
+        nufft.exec_type1(u, p, v)
+        if p is big:
+            assert float((u[256 - 11, 7] - exact).abs() / exact.abs()) < 1e-6     # (axes reversed: [k2, k1])
+    # sorts: slabs of one bin row on a 64 x 768 x 720 grid = 180 x 192 keys (a small NUFFT_SLAB_FILL keeps the slabs that low)
+    monkeypatch.setenv("NUFFT_SLAB_FILL", "5")
+    Np = 8_000_000
+    xs3 = tuple(torch.rand(Np, dtype=torch.float32, device="cuda", generator=g) * (2 * np.pi) for _ in range(3))
+    v3 = torch.randn(Np, dtype=torch.float32, device="cuda", generator=g)
+    slab = nufft.PlanNUFFT(torch.float32, (32, 384, 360), m=4, backend=nufft.ROCBackend(0))
+    col = nufft.PlanNUFFT(torch.float64, (256, 256, 32), m=4, backend=nufft.ROCBackend(0))
+    nufft.set_points(col, tuple(x[:100000].double() for x in xs3))
+    nufft.set_points(slab, xs3)
+    assert slab.sort_method_used() == "slabs"
+    u3 = torch.empty(slab.shape, dtype=torch.complex64, device="cuda")
+    nufft.exec_type1(u3, slab, v3)
+    k3 = torch.tensor([3.0, -2.0, 5.0], dtype=torch.float64, device="cuda")
+    x64 = [x.double() for x in xs3]
+    exact3 = (v3.double() * torch.polar(torch.ones_like(x64[0]), -(k3[0] * x64[0] + k3[1] * x64[1] + k3[2] * x64[2]))).sum()
+    assert float((u3[5, 384 - 2, 3].to(torch.complex128) - exact3).abs() / exact3.abs()) < 2e-3
