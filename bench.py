@@ -25,6 +25,7 @@ issued on a side stream and overlapped with the next step.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -106,15 +107,34 @@ def algorithmic_bytes(Np, Nover, Nout, is_complex, real_bytes, C):
     }
 
 
-def pmc_traffic(kernel_substr, config):
-    """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/*_traffic.json,
-    written by scripts/summarize_profile.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-    passes of this same command, with the gfx950 FETCH_SIZE correction).  Counters cannot be collected
-    inside the timed run; None if no summary is present."""
+def profile_files(config, suffix, evalmode=None):
+    """Committed profile summaries of one configuration, oldest first: profiles/round<N>_<letter>_bench_<config>[_direct]<suffix>.
+    The profiles are collected per window mode (`..._<config>_direct_*` = Direct(), `..._<config>_*` = the polynomial window);
+    with `evalmode` ("Direct" / "FastApproximation") only that mode's files are returned, so a kernel whose name does not
+    carry the mode (the interpolation ring) is never looked up in the other mode's profile."""
     import glob
-    # round<N>_<letter>_bench_<config>_traffic.json: newest last; only summaries of the same configuration
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if f"_{config}_" in os.path.basename(f))
-    for f in reversed(files):
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix))):
+        b = os.path.basename(f)
+        if f"_{config}_" not in b and f"_{config}." not in b:
+            continue
+        is_direct = f"_{config}_direct" in b
+        if evalmode is not None and is_direct != (evalmode == "Direct"):
+            continue
+        out.append(f)
+    # newest round / letter last: round10 sorts behind round9
+    def key(f):
+        mm = re.match(r"round(\d+)_([a-z]+)_", os.path.basename(f))
+        return (int(mm.group(1)), mm.group(2)) if mm else (0, "")
+    return sorted(out, key=key)
+
+
+def pmc_traffic(kernel_substr, config, evalmode=None):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary of this configuration AND window mode
+    (profiles/*_traffic.json, written by scripts/summarize_profile.py from separate `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` passes of this same command, with the gfx950 FETCH_SIZE correction).  Counters cannot be collected
+    inside the timed run; None if no summary is present."""
+    for f in reversed(profile_files(config, "_traffic.json", evalmode)):
         try:
             ks = json.load(open(f))["kernels"]
         except Exception:
@@ -125,13 +145,11 @@ def pmc_traffic(kernel_substr, config):
     return None, None, None
 
 
-def sq_counters(kernel_substr, config):
-    """SQ counters per launch of a kernel from the newest committed profiles/*_sq.json of this configuration (written by
+def sq_counters(kernel_substr, config, evalmode=None):
+    """SQ counters per launch of a kernel from the newest committed profiles/*_sq.json of this configuration and window mode (written by
     scripts/summarize_profile.py from the SQ passes of scripts/profile_bench.sh), with the derived figures that name the binding
     resource; None if no such profile is committed.  Nothing here is typed in by hand."""
-    import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")) if f"_{config}_" in os.path.basename(f) or f"_{config}." in os.path.basename(f))
-    for f in reversed(files):
+    for f in reversed(profile_files(config, "_sq.json", evalmode)):
         try:
             ks = json.load(open(f))["kernels"]
         except Exception:
@@ -139,13 +157,9 @@ def sq_counters(kernel_substr, config):
         for name, v in ks.items():
             if kernel_substr in name:
                 d = {"source": os.path.basename(f), "kernel": name, "counters": v}
-                busy = v.get("SQ_BUSY_CYCLES")
-                if busy:
-                    # SQ_BUSY_CYCLES counts per shader engine (x4 per XCD quadrant on gfx950): ratios between SQ counters of one
-                    # pass are what is meaningful; report instruction mix and active / wait shares of the wave cycles
-                    pass
                 wc = v.get("SQ_WAVE_CYCLES")
                 if wc:
+                    # (ratios between SQ counters of one pass are what is meaningful: instruction mix, active / wait shares of the wave cycles)
                     for key, label in (("SQ_ACTIVE_INST_VALU", "valu_active_share_of_wave_cycles"), ("SQ_ACTIVE_INST_LDS", "lds_active_share_of_wave_cycles"),
                                        ("SQ_WAIT_INST_LDS", "wait_lds_share_of_wave_cycles")):
                         if key in v:
@@ -158,6 +172,27 @@ def sq_counters(kernel_substr, config):
                     d["valu_instructions_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
                 return d
     return None
+
+
+# The driver's parser keeps the first 20 SCALAR keys of `config` (lists and records are skipped).  These lead, in this order, so that the
+# other single-GPU BASELINE configurations (C3, C4), the two window modes and the reference protocol are part of the driver-observed line
+# (round 5 lost c3_* / c4_* behind stage times and sort keys; tests/test_bench_cli.py pins this list).
+CONFIG_LEAD_KEYS = ("workload", "direct_value", "fast_value", "type2_value",
+                    "c3_value", "c3_type2_value", "c3_spread_ms", "c3_interp_ms", "c3_set_points_ms", "c3_fp32_frac", "c3_direct_value",
+                    "c4_value", "c4_type2_value", "c4_spread_ms", "c4_interp_ms", "c4_direct_value",
+                    "refproto_f64_type1_value", "refproto_f64_type2_value", "refproto_c128_type1_value", "workspace_bytes")
+
+
+def lead_config(config):
+    """`config` with CONFIG_LEAD_KEYS first (those that are present), everything else behind in its original order."""
+    out = {k: config[k] for k in CONFIG_LEAD_KEYS if k in config}
+    out.update((k, v) for k, v in config.items() if k not in out)
+    return out
+
+
+def first_scalar_keys(config, n=20):
+    """What the driver's parser keeps of `config`: its first n scalar-valued keys."""
+    return [k for k, v in config.items() if not isinstance(v, (dict, list, tuple))][:n]
 
 
 def launch_ranks(a):
@@ -472,9 +507,12 @@ def main():
         n1c, n2c, mm = head["ring_column"][0], head["ring_column"][1], cfg["m"]
         xr, yr = (mm - 1) + ((mm - 1) & 1) + mm, 2 * mm - 1
         ab["spread_kernel_min"] += Cn * ab["G"] * ((n1c + xr) * (n2c + yr) / float(n1c * n2c) - 1.0)
-    traffic_b, traffic_src, profile_us = pmc_traffic(kname, a.config)
-    sq = sq_counters(kname, a.config)
-    interp_kname = "interp_march_staged_kernel" if head.get("sort_columns") else "interp_march_kernel"
+    traffic_b, traffic_src, profile_us = pmc_traffic(kname, a.config, head["evalmode"])
+    sq = sq_counters(kname, a.config, head["evalmode"])
+    # (the interpolation ring's name carries the window mode as its last template argument; the lookup is restricted to this mode's profiles as well)
+    interp_kname = (("interp_march_staged_kernel" if head.get("sort_columns") else "interp_march_kernel")
+                    + f"<{tname}, {'true' if is_complex and cfg['Z'] != 'complex128' else 'false'}, {cfg['m']}, {'false' if head['evalmode'] == 'Direct' else 'true'}>")
+    interp_traffic_b, interp_traffic_src, interp_profile_us = pmc_traffic(interp_kname, a.config, head["evalmode"])
     probe = hbm_probe(dev) if full else None
     peak_m = probe["peak_measured_GBs"] if probe else None
     achieved = ab["spread_kernel"] / spread_s / 1e9
@@ -506,9 +544,11 @@ def main():
         "interp": {"kernel_ms": st2["interp"], "algorithmic_bytes_per_stage": ab["interp_kernel"],
                    "achieved": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9, "frac": ab["interp_kernel"] / (st2["interp"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "kernel": interp_kname,
-                   "traffic": (lambda t: t[0] / 1e9 if t[0] is not None else None)(pmc_traffic(interp_kname, a.config)),
-                   "profile_kernel_us": pmc_traffic(interp_kname, a.config)[2],
-                   "binding_resource_counters": sq_counters(interp_kname, a.config),
+                   "traffic": (interp_traffic_b / 1e9) if interp_traffic_b is not None else None, "traffic_source": interp_traffic_src,
+                   "profile_kernel_us": interp_profile_us,
+                   # the interpolation stage is one launch of this kernel (+ a stand-by launch of the tile kernel that exits on the device flag)
+                   "profile_matches_run": (abs(interp_profile_us / 1e3 - st2["interp"]) < 0.1 * st2["interp"]) if interp_profile_us else None,
+                   "binding_resource_counters": sq_counters(interp_kname, a.config, head["evalmode"]),
                    "note": "type-2 gather stage (R(G) + R(points) + W(values)); z-marching LDS ring where the point set is not sliced"},
         "type1_exec_frac": ab["type1_exec"] / (exec1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "type2_exec_frac": ab["type2_exec"] / (exec2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -637,6 +677,7 @@ def main():
         result["config"]["refproto_f64_type2_value"] = rp["type2_pts_per_s"]
     if rank == 0 and full and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg)
+    result["config"] = lead_config(result["config"])
     if rank == 0:
         print(json.dumps(result), flush=True)
     if distributed:
