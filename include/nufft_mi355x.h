@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define NUFFT_MI355X_VERSION 103 /* 0.1.3: nufft_params grew (kernel_param_dim, N_over; nufft_info: sort_column: what a binding that already holds the reference's
+#define NUFFT_MI355X_VERSION 104 /* 0.1.4: nufft_params.struct_size (was reserved[0]) and .options (appended); the library no longer reads NUFFT_*
+                                    environment variables; nufft_plan_options, nufft_workspace_breakdown added;
+                                    0.1.3: nufft_params grew (kernel_param_dim, N_over; nufft_info: sort_column: what a binding that already holds the reference's
                                     per-dimension kernel data forwards verbatim), NUFFT_METHOD_GLOBAL_MEMORY accepted, nufft_copy_grid
                                     takes a non-const plan since 102;
                                     0.1.2: nufft_spread_deferred added, nufft_info.reserved_info became ring_halo (same layout) since 101;
@@ -113,7 +115,10 @@ typedef struct nufft_params {
     int32_t spread_method;   /* NUFFT_SPREAD_* (0 = automatic: MFMA patches where they apply)       */
     double  kernel_param;    /* KaiserBesselKernel(β) / BackwardsKaiserBesselKernel(β) / GaussianKernel(ℓ):
                                 explicit shape parameter; 0 -> the optimal one for (M, σ)              */
-    int32_t reserved[2];
+    int32_t struct_size;     /* sizeof(nufft_params) of the CALLER's header (ABI >= 104; the slot was reserved[0]): the library reads only
+                                that many bytes and treats the rest as zero.  0 = the layout of ABI <= 102, which ends here: every field
+                                below is then ignored — a caller that fills them must set struct_size                              */
+    int32_t reserved;
     double  kernel_param_dim[3]; /* per-dimension shape parameter, as the reference's kernel data holds it (the field β of
                                     BackwardsKaiserBesselKernelData / KaiserBesselKernelData, kaiser_bessel_backwards.jl:84,
                                     kaiser_bessel.jl:112; σ / Δx of GaussianKernelData, gaussian.jl:67,76-78): an entry > 0 overrides
@@ -121,6 +126,10 @@ typedef struct nufft_params {
     int64_t N_over[3];       /* oversampled grid size Ñ_d (gridsize(p.kernels[d]), src/Kernels/Kernels.jl:87): an entry > 0 replaces the
                                 size rule of src/plan.jl:485-498 for that dimension (it must be even in dimension 1 of a real plan
                                 and >= N_d); sigma is then only reported */
+    const char* options;     /* development switches of this plan, "NUFFT_NAME=value;NUFFT_OTHER=value" (DESIGN.md section 4.3 lists them;
+                                A/B experiments and tests of rarely taken paths — the defaults are the measured optimum), or NULL.
+                                The library reads no environment variable: what changes a plan is in this struct.  Copied at
+                                plan creation; nufft_plan_options() returns the canonical form the plan holds                  */
 } nufft_params;
 
 /* What show(::PlanNUFFT) prints (src/plan.jl:362-392) plus sizes a caller needs. */
@@ -233,6 +242,12 @@ int nufft_exec_type2_cb(nufft_plan* plan, void* const* values_out, const void* c
 
 /* ---- stage-level entry points (the backend-dispatched generic functions) -- */
 
+/* The callback menu (above) for the stage-level entry points below: `callbacks.nonuniform` is read by nufft_spread[_deferred] and
+ * nufft_interpolate, `callbacks.uniform` by nufft_deconvolve_truncate and nufft_deconvolve_pad — the arguments the reference passes
+ * to spread_from_points! / interpolate! / copy_deconvolve_to_*! (src/NonuniformFFTs.jl:170,183,270,280).  In force until the next call;
+ * NULL (or two NULL pointers) = none.  The pointers are read while a stage enqueues its kernels, not later. */
+int nufft_set_callbacks(nufft_plan* plan, const nufft_callbacks* callbacks);
+
 /* fill_with_zeros_kernel!(us), src/NonuniformFFTs.jl:116-122,161-167. */
 int nufft_fill_zeros(nufft_plan* plan, void* stream);
 /* spread_from_points!(::GPU, ...), src/spreading/gpu.jl:134-214 (adds onto the plan's grids). */
@@ -309,6 +324,15 @@ int nufft_interp_engine_used(nufft_plan* plan, int* engine_out, void* stream);
 /* ---- misc ----------------------------------------------------------------------------- */
 /* sizeof(nufft_params) / sizeof(nufft_info) of the library build: a binding that mirrors the structs by hand
  * (ctypes, Julia) compares them with its own layout before the first call. */
+/* Plan-owned device memory right now, buffer by buffer: "name=bytes;name=bytes;..." (NUL-terminated) into `out`; the values sum to
+ * nufft_info.workspace_bytes.  Names: us, uhat, tmp2 (oversampled grids / spectra / intermediate of the pruned FFT passes), sorted
+ * (bin-sorted point records), sort_scratch, sort_slice_table, bin_counts, bin_offsets, vsorted (values in sorted order: MFMA-patch
+ * plans), ring_side_buffer (halo variant of the spreading window), rocfft_work, tables (everything small).  The reference's plan holds
+ * us + ûs (src/plan.jl:37-60) and blockidx + pointperm + offsets (src/blocking/gpu.jl:41-69) and aliases the caller's points. */
+int nufft_workspace_breakdown(const nufft_plan* plan, char* out, int64_t capacity);
+/* The development switches the plan was created with (nufft_params.options), canonical form "NAME=value;..." sorted by name; "" if none.
+ * The pointer stays valid until the plan is destroyed. */
+const char* nufft_plan_options(const nufft_plan* plan);
 int64_t nufft_sizeof_params(void);
 int64_t nufft_sizeof_info(void);
 const char* nufft_strerror(int code);

@@ -36,6 +36,7 @@ const NUFFT_METHOD_GLOBAL_MEMORY = Int32(1)
 const NUFFT_POINT_TRANSFORM_IDENTITY = Int32(0)
 const NUFFT_POINT_TRANSFORM_NFFT = Int32(1)
 const NUFFT_SPREAD_AUTO = Int32(0)
+const NUFFT_MI355X_VERSION = Int32(104)             # the ABI this file was written against (nufft_params.struct_size / .options, nufft_set_callbacks)
 const NUFFT_ERR_INVALID_ARG = Int32(1)
 const NUFFT_ERR_SIZE_TOO_SMALL = Int32(2)
 const NUFFT_ERR_DIM_MISMATCH = Int32(3)
@@ -75,6 +76,12 @@ end
 function NonuniformFFTs.BlockDataGPU(::Type{Z}, backend::MI355XBackend, block_dims::Dims{D}, Ñs::Dims{D}, h::HalfSupport{M},
                                      sort_points::StaticBool; method::Symbol, batch_size::Val) where {Z <: Number, D, M}
     method ∈ (:global_memory, :shared_memory) || throw(ArgumentError("expected gpu_method ∈ (:global_memory, :shared_memory)"))   # src/blocking/gpu.jl:26
+    # Plan-time errors at plan time: the reference throws from PlanNUFFT(…) when the LDS cannot hold a tile (src/gpu_common.jl:55-78) and
+    # for sizes below 2M (src/plan.jl:545-556).  The device handle is only built at the first set_points! (the kernel data, evaluation
+    # mode and point transform are not visible from the functions _PlanNUFFT dispatches on the backend), so what decides those errors
+    # here — element type, D, M, Ñs — goes through the library's own parameter checks now, on a HOST-ONLY plan (device = -1: no GPU
+    # call, no allocation): D > 3 or M outside 2:10 (NUFFT_ERR_UNSUPPORTED), Ñ < 2M, an LDS budget no tile fits.
+    probe_parameters(Z, Ñs, Val(M), method)
     MI355XBlockData(method, block_dims, sort_points, batch_size)
 end
 NonuniformFFTs.gpu_method(bd::MI355XBlockData) = bd.method                 # show(::PlanNUFFT), src/plan.jl:381
@@ -134,11 +141,35 @@ struct CParams
     dtype::Int32; is_complex::Int32; ndim::Int32; N::NTuple{3, Int64}; half_support::Int32; sigma::Float64
     kernel::Int32; evalmode::Int32; ntransforms::Int32; fftshift::Int32; point_transform::Int32; gpu_method::Int32
     device::Int32; tile_dims::NTuple{3, Int32}; lds_budget_bytes::Int32; spread_threads::Int32; interp_threads::Int32
-    interp_tile_dims::NTuple{3, Int32}; bin_log2::Int32; spread_method::Int32; kernel_param::Float64; reserved::NTuple{2, Int32}
-    kernel_param_dim::NTuple{3, Float64}; N_over::NTuple{3, Int64}
+    interp_tile_dims::NTuple{3, Int32}; bin_log2::Int32; spread_method::Int32; kernel_param::Float64; struct_size::Int32; reserved::Int32
+    kernel_param_dim::NTuple{3, Float64}; N_over::NTuple{3, Int64}; options::Ptr{UInt8}
 end
 
 pad3(f, N, z) = ntuple(d -> d ≤ N ? f(d) : z, Val(3))
+
+function check_library()
+    ccall((:nufft_version, libnufft), Cint, ()) ≥ NUFFT_MI355X_VERSION || error("libnufft_mi355x.so is older than ABI $NUFFT_MI355X_VERSION")
+    ccall((:nufft_sizeof_params, libnufft), Int64, ()) == sizeof(CParams) || error("nufft_params layout differs from the library's")
+    nothing
+end
+
+function probe_parameters(::Type{Z}, Ñs::Dims{D}, ::Val{M}, method::Symbol) where {Z <: Number, D, M}
+    D ≤ 3 || throw(ArgumentError("MI355XBackend: transforms of more than 3 dimensions are not supported (got $D); use ROCBackend()"))
+    check_library()
+    T = real(Z)
+    zero3 = (Int32(0), Int32(0), Int32(0))
+    Ns = pad3(d -> Int64(cld(Ñs[d], 2)), D, Int64(0))          # any N ≤ Ñ: the checks in question depend on Ñ, M, D and the element type only
+    probe = CParams(T === Float64 ? NUFFT_F64 : NUFFT_F32, Int32(Z <: Complex), Int32(D), Ns, Int32(M), 0.0,
+                  NUFFT_KERNEL_BACKWARDS_KAISER_BESSEL, NUFFT_EVAL_DIRECT, Int32(1), Int32(0), NUFFT_POINT_TRANSFORM_IDENTITY,
+                  method === :shared_memory ? NUFFT_METHOD_SHARED_MEMORY : NUFFT_METHOD_GLOBAL_MEMORY,
+                  Int32(-1),
+                  zero3, Int32(0), Int32(0), Int32(0), zero3, Int32(0), NUFFT_SPREAD_AUTO, 0.0, Int32(sizeof(CParams)), Int32(0),
+                  (0.0, 0.0, 0.0), pad3(d -> Int64(Ñs[d]), D, Int64(0)), Ptr{UInt8}(C_NULL))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:nufft_plan_create_ex, libnufft), Cint, (Ref{Ptr{Cvoid}}, Ref{CParams}), h, Ref(probe)))
+    ccall((:nufft_plan_destroy, libnufft), Cint, (Ptr{Cvoid},), h[])
+    nothing
+end
 
 # The handle is built from the plan's own fields: the oversampled sizes and shape parameters the reference has already resolved
 # go over verbatim (N_over, kernel_param_dim), so the library repeats nothing of src/plan.jl:485-506.  For real data only
@@ -147,7 +178,7 @@ pad3(f, N, z) = ntuple(d -> d ≤ N ? f(d) : z, Val(3))
 function ensure_handle!(p::PlanNUFFT{Z, N, Nc, M, MI355XBackend}) where {Z, N, Nc, M}
     data = p.data
     data.handle == C_NULL || return data.handle
-    ccall((:nufft_sizeof_params, libnufft), Int64, ()) == sizeof(CParams) || error("nufft_params layout differs from the library's")
+    check_library()
     fold = p.point_transform_fold                     # closure of generate_point_transform_fold_function, src/plan.jl:459-464
     pt = fold.point_transform                         # its captured `point_transform`: identity or _transform_point_convention
     pt === identity || pt === NonuniformFFTs._transform_point_convention ||
@@ -165,7 +196,8 @@ function ensure_handle!(p::PlanNUFFT{Z, N, Nc, M, MI355XBackend}) where {Z, N, N
     prm = CParams(dtype, Int32(Z <: Complex), Int32(N), Ns, Int32(M), Float64(p.σ),
                   kernel_id(first(p.kernels)), evalmode, Int32(Nc), Int32(p.fftshift), ptrans, method,
                   Int32(AMDGPU.device_id(AMDGPU.device()) - 1),
-                  zero3, Int32(0), Int32(0), Int32(0), zero3, Int32(0), NUFFT_SPREAD_AUTO, 0.0, (Int32(0), Int32(0)), βs, Ñs)
+                  zero3, Int32(0), Int32(0), Int32(0), zero3, Int32(0), NUFFT_SPREAD_AUTO, 0.0, Int32(sizeof(CParams)), Int32(0), βs, Ñs,
+                  Ptr{UInt8}(C_NULL))                 # (no development switches: the library reads no environment either)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:nufft_plan_create_ex, libnufft), Cint, (Ref{Ptr{Cvoid}}, Ref{CParams}), h, Ref(prm)))
     data.handle = h[]
@@ -215,19 +247,54 @@ end
 
 # ---- exec_type1! / exec_type2!  (src/NonuniformFFTs.jl:148-195, 237-291) ---------------------------------------------
 # (again the reference's signatures with the plan narrowed; T is the plan's non-uniform element type, Z the uniform one)
+# The stages are enqueued one by one through the stage-level entry points, each under the reference's own timer label and followed
+# by maybe_synchronise(p) (src/NonuniformFFTs.jl:157-186, 246-283): p.timer shows the same tree as a ROCBackend plan, and with
+# synchronise = true the same per-stage times.  nufft_exec_type1 is exactly this sequence (csrc/plan.cpp), so nothing is lost by
+# not calling it.  The callback menu is put in force around the stages (nufft_set_callbacks) — the arguments the reference passes
+# to spread_from_points! / copy_deconvolve_to_non_oversampled! / copy_deconvolve_to_oversampled! / interpolate!.
+# (one literal ccall per stage: the (symbol, library) pair of a ccall must be a constant expression)
+spread_deferred(h, a, s) = check(ccall((:nufft_spread_deferred, libnufft), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}), h, a, s))
+fft_forward(h, s) = check(ccall((:nufft_fft_forward, libnufft), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, s))
+deconvolve_truncate(h, a, s) = check(ccall((:nufft_deconvolve_truncate, libnufft), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}), h, a, s))
+deconvolve_pad(h, a, s) = check(ccall((:nufft_deconvolve_pad, libnufft), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}), h, a, s))
+fft_backward(h, s) = check(ccall((:nufft_fft_backward, libnufft), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, s))
+interpolate_points(h, a, s) = check(ccall((:nufft_interpolate, libnufft), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}), h, a, s))
+set_callbacks(h, cb) = check(ccall((:nufft_set_callbacks, libnufft), Cint, (Ptr{Cvoid}, Ref{CCallbacks}), h, cb))
+const no_callbacks = CCallbacks(C_NULL, C_NULL)
+
 function NonuniformFFTs.exec_type1!(ûs_k::NTuple{C, AbstractArray{Z}}, p::PlanNUFFT{T, N, Nc, M, MI355XBackend},
                                     vp::NTuple{C, AbstractVector{T}};
                                     callbacks::NUFFTCallbacks = NUFFTCallbacks()) where {T, Z, C, N, Nc, M}
     Z === complex(T) || throw(ArgumentError(lazy"uniform data must have the same accuracy as the created plan (got $Z values for a $T plan)"))   # :154
     cb = ccallbacks(callbacks)
-    @timeit NonuniformFFTs.get_timer_nowarn(p) "Execute type 1" begin
+    timer = NonuniformFFTs.get_timer_nowarn(p)
+    @timeit timer "Execute type 1" begin
         NonuniformFFTs.check_nufft_uniform_data(p, ûs_k)          # :92-103
         NonuniformFFTs.check_nufft_nonuniform_data(p, vp)         # :105-114
         on_device(ûs_k); on_device(vp)
-        GC.@preserve ûs_k vp callbacks check(ccall((:nufft_exec_type1_cb, libnufft), Cint,
-            (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ref{CCallbacks}, Ptr{Cvoid}),
-            p.data.handle, ptrs(ûs_k), ptrs(vp), cb, stream_ptr()))
-        NonuniformFFTs.maybe_synchronise(p)
+        h, s = p.data.handle, stream_ptr()
+        GC.@preserve ûs_k vp callbacks begin
+            set_callbacks(h, cb)
+            try
+                @timeit timer "(0) Fill with zeros" begin      # (nothing to enqueue: the spreading kernels store every cell of `us` once)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+                @timeit timer "(1) Spreading" begin
+                    spread_deferred(h, ptrs(vp), s)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+                @timeit timer "(2) Forward FFT" begin
+                    fft_forward(h, s)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+                @timeit timer "(3) Deconvolution" begin
+                    deconvolve_truncate(h, ptrs(ûs_k), s)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+            finally
+                set_callbacks(h, Ref(no_callbacks))
+            end
+        end
     end
     ûs_k
 end
@@ -237,14 +304,34 @@ function NonuniformFFTs.exec_type2!(vp::NTuple{C, AbstractVector{T}}, p::PlanNUF
                                     callbacks::NUFFTCallbacks = NUFFTCallbacks()) where {T, Z, C, N, Nc, M}
     Z === complex(T) || throw(ArgumentError(lazy"uniform data must have the same accuracy as the created plan (got $Z values for a $T plan)"))   # :243
     cb = ccallbacks(callbacks)
-    @timeit NonuniformFFTs.get_timer_nowarn(p) "Execute type 2" begin
+    timer = NonuniformFFTs.get_timer_nowarn(p)
+    @timeit timer "Execute type 2" begin
         NonuniformFFTs.check_nufft_uniform_data(p, ûs_k)
         NonuniformFFTs.check_nufft_nonuniform_data(p, vp)
         on_device(ûs_k); on_device(vp)
-        GC.@preserve ûs_k vp callbacks check(ccall((:nufft_exec_type2_cb, libnufft), Cint,
-            (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ref{CCallbacks}, Ptr{Cvoid}),
-            p.data.handle, ptrs(vp), ptrs(ûs_k), cb, stream_ptr()))
-        NonuniformFFTs.maybe_synchronise(p)
+        h, s = p.data.handle, stream_ptr()
+        GC.@preserve ûs_k vp callbacks begin
+            set_callbacks(h, cb)
+            try
+                @timeit timer "(0) Fill with zeros" begin      # (fused into the next stage: every element of the spectrum is written once)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+                @timeit timer "(1) Deconvolution" begin
+                    deconvolve_pad(h, ptrs(ûs_k), s)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+                @timeit timer "(2) Backward FFT" begin
+                    fft_backward(h, s)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+                @timeit timer "(3) Interpolation" begin
+                    interpolate_points(h, ptrs(vp), s)
+                    NonuniformFFTs.maybe_synchronise(p)
+                end
+            finally
+                set_callbacks(h, Ref(no_callbacks))
+            end
+        end
     end
     vp
 end

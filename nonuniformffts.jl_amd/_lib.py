@@ -44,9 +44,10 @@ class NufftParams(C.Structure):
         ("interp_tile_dims", C.c_int32 * 3), ("bin_log2", C.c_int32),
         ("spread_method", C.c_int32),
         ("kernel_param", C.c_double),
-        ("reserved", C.c_int32 * 2),
+        ("struct_size", C.c_int32), ("reserved", C.c_int32),
         ("kernel_param_dim", C.c_double * 3),
         ("N_over", C.c_int64 * 3),
+        ("options", C.c_char_p),
     ]
 
 
@@ -91,6 +92,7 @@ SYMBOLS = {
     "nufft_exec_type2": (C.c_int, [_P, _PP, _PP, _P]),
     "nufft_exec_type1_cb": (C.c_int, [_P, _PP, _PP, _P, _P]),
     "nufft_exec_type2_cb": (C.c_int, [_P, _PP, _PP, _P, _P]),
+    "nufft_set_callbacks": (C.c_int, [_P, _P]),
     "nufft_fill_zeros": (C.c_int, [_P, _P]),
     "nufft_spread": (C.c_int, [_P, _PP, _P]),
     "nufft_spread_deferred": (C.c_int, [_P, _PP, _P]),
@@ -108,6 +110,8 @@ SYMBOLS = {
     "nufft_get_stage_times": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "nufft_spread_engine_used": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "nufft_interp_engine_used": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "nufft_plan_options": (C.c_char_p, [_P]),
+    "nufft_workspace_breakdown": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "nufft_sizeof_params": (C.c_int64, []),
     "nufft_sizeof_info": (C.c_int64, []),
     "nufft_strerror": (C.c_char_p, [C.c_int]),

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(1024) void patch_task_counts_kernel(int ncols, int 
         const double mean = (double)np / (double)ntasks;
         const uint32_t heaviest = choice[6];
         choice[6] = 0u;                                    // the next set_points starts its maximum from zero
+        choice[kHaloStateWord] = 0u;                       // spreading ring: a side buffer of the previous point set is void
         uniform_mode = (double)heaviest <= 1.1 * mean + 5.0 * sqrt(mean) + 8.0;
         choice[3] = uniform_mode ? 1u : 0u;
         if (uniform_mode) {

@@ -194,7 +194,7 @@ template <typename T, int U>
 __device__ __forceinline__ void coarse_load(const BinArgs<T, 3>& a, int64_t p0, int64_t hi, int tid, T (&x)[U][3]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int64_t p = p0 + u * 1024 + tid;
+        const int64_t p = p0 + u * kCoarseThreads + tid;
         if (p < hi) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) x[u][d] = a.x[d][p];
@@ -226,7 +226,6 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_count_kernel(BinArgs<T,
     // two batches of 4 points per thread in registers: the loads of one are in flight while the other is counted (0.71 -> see DESIGN 4.10)
     constexpr int U = 4;
     constexpr int64_t S = (int64_t)U * kCoarseThreads;
-    static_assert(kCoarseThreads == 1024, "coarse_load strides by 1024");
     T xa[U][3], xb[U][3];
     auto consume = [&](int64_t p0, const T (&x)[U][3]) __attribute__((always_inline)) {
 #pragma unroll

@@ -97,6 +97,7 @@ struct CoarseSort {
 // regions) are sorted by the same workgroup in two passes over global memory, and point sets whose fullest slab exceeds kSlabOverfill
 // capacities (clusters) take the fine sort with global atomics instead (device flag, flagmem[4]).
 constexpr int kSlabMaxBins = 4096;         // fine bins of a slab (16 KiB of LDS counters in level 2)
+constexpr int kHaloStateWord = 12;         // word of the spreading ring's 16-word device record: 1 = side buffer written, not yet added to the grid
 constexpr int kSlabOverfill = 8;           // a slab may hold this many LDS capacities (level 2 then sorts it through global memory)
 constexpr int kCoarseMaxKeys = 36864;      // 144 KiB of LDS counters
 

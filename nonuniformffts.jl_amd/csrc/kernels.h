@@ -1,6 +1,7 @@
 // Host-callable launchers of the HIP kernels (one translation unit per kernel family).
 #pragma once
 
+#include "options.h"
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -166,7 +167,7 @@ hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* so
 SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo, int parts = 1);
 hipError_t prepare_spread_march(int dtype, int is_complex, int M, int halo);
 // flag: device flag of set_points (1: the ring serves this point set); tasktab: its task table
-hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream);
+hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, hipStream_t stream);
 // halo variant: grid += side buffer (a.halo); the dimension-1 FFT pass of real plans does the same while it loads its lines (launch_real_lines)
 hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, hipStream_t stream);
 // set_points: tasks of the ring for this point set and whether it serves it (advantage <= 0: always)

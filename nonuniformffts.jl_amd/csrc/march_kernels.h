@@ -45,6 +45,9 @@ struct MarchGeom {
                                     // parts of the interleaved grid (value and cell stride 2 reals); 0 / 1: plain components
     const uint32_t* coarse_a;       // interpolation ring on plans of the column-layer sort (CoarseSort, kernels.h): both nonzero = this point set
     const uint32_t* coarse_b;       // is column-layer sorted — interp_march_staged_kernel serves it, interp_march_kernel returns (null: no such plan)
+    uint32_t* halo_state;           // spreading ring, halo variant: device word the kernel sets to 1 when it has written the side buffer (0 when the
+                                    // tile kernel served the point set): "the reach has not been added to the grid yet" — the consumers are gated on it,
+                                    // so the state travels with the stream / a replayed hipGraph, not with the host (plan.cpp: halo_hint)
 };
 
 constexpr int kMarchMaxRows = 16;   // rows of bins of a column (n2 <= 64)

@@ -2,8 +2,11 @@
 // translation units of libnufft_mi355x.so.
 #pragma once
 
+#include "options.h"
 #include <cstdint>
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "column_tasks.h"
@@ -76,6 +79,9 @@ bool choose_tiles(int D, int M, int ncomp, int real_bytes, const int64_t* Nover,
 // The plan
 // -------------------------------------------------------------------------------------------
 struct nufft_plan {
+    std::map<void*, std::pair<std::string, int64_t>> allocs;      // device buffers of the plan: pointer -> (bytes)
+    std::string opts_text;             // (storage of nufft_plan_options)
+    nufft::Options opts;               // development switches of this plan (nufft_params.options; options.h)
     // parameters
     int dtype = NUFFT_F64;
     bool is_complex = false;
@@ -98,6 +104,8 @@ struct nufft_plan {
     double beta[3] = {0, 0, 0};
     const void* cb_point_weights = nullptr;   // set for the duration of nufft_exec_type{1,2}_cb
     const void* cb_mode_factors = nullptr;
+    const void* cb_sticky_weights = nullptr;  // nufft_set_callbacks: in force for the stage-level entry points until reset
+    const void* cb_sticky_factors = nullptr;
     int kernel = 0;                    // NUFFT_KERNEL_*
     int point_transform = 0;           // NUFFT_POINT_TRANSFORM_*
     double tau[3] = {0, 0, 0};         // Gaussian: 2 (ℓ Δx)²
@@ -136,7 +144,12 @@ struct nufft_plan {
     uint32_t* d_smarch_cols = nullptr;    // [columns] points per column, then [columns + 1] first task of each column
     void* d_smarch_tasks = nullptr;       // uint2[table entries]: {column, end layer << 16 | first layer}, rebuilt by every set_points
     void* d_smarch_halo = nullptr;        // halo variant: side buffer of the stencil reach, C x smarch.halo_reals reals
-    bool halo_pending = false;            // inside exec_type1: the side buffer has not been added yet, the first FFT pass does it
+    // Halo variant of the spreading ring: whether the side buffer still has to be added to `us` is DEVICE state (d_smarch_choice[kHaloStateWord],
+    // written by the spreading kernel, cleared by whoever adds or voids it), so it follows the stream and a replayed hipGraph.  The host
+    // keeps a hint that is exact while every call on the plan is eager, and is used only to skip launches that would find the word 0;
+    // once any call on the plan has been captured into a hipGraph (halo_sticky) nothing is skipped any more.
+    bool halo_hint = false;
+    bool halo_sticky = false;
     bool halo_fuse = true;                // NUFFT_SMARCH_HALO_FUSE (latched at creation): 0 = always the separate add pass
     int wave_slots = 2048;             // resident waves of the patch kernel on this device (CUs x 4 SIMDs x its waves per SIMD)
     void* d_vsorted = nullptr;         // C value vectors in sorted order (MFMA-patch spreading)
@@ -163,6 +176,7 @@ struct nufft_plan {
                                        // the slab height chosen per point set (nufft_set_points)
     int slab_fill = 85;                // a slab's average load, percent of what a level-2 workgroup holds, at most (NUFFT_SLAB_FILL)
     int64_t slab_min_points = 0;       // smaller point sets take the fine sort with global atomics (NUFFT_SLAB_MIN_POINTS)
+    int slab_max_keys = 0;             // keys the level-1 table was allocated for: min(kCoarseMaxKeys, nb[1] * nb[2])
     nufft::CoarseSort coarse{};        // column-layer sort (binsort.hip): enabled on plans whose two rings own the same columns; table allocated
     void* d_binrank = nullptr;         // uint2[Np]: (tile, rank)
     void* d_sorted = nullptr;          // PointRec<T, D>[Np]

@@ -86,15 +86,27 @@ struct DeviceGuard {
     }
 };
 
-static int dev_alloc(nufft_plan* p, void** ptr, size_t bytes) {
+// Every device allocation of a plan goes through here: workspace_bytes and the per-buffer breakdown (nufft_workspace_breakdown) are
+// what the registry holds, so they cannot drift apart.  `name`: the row of DESIGN.md section 3 the buffer belongs to.
+static int dev_alloc(nufft_plan* p, void** ptr, size_t bytes, const char* name = "tables") {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(ptr, bytes);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         *ptr = nullptr;
-        return fail(NUFFT_ERR_ALLOC, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+        return fail(NUFFT_ERR_ALLOC, std::string("hipMalloc(") + std::to_string(bytes) + ", " + name + "): " + hipGetErrorString(e));
     }
+    p->allocs[*ptr] = {name, (int64_t)bytes};
     p->workspace_bytes += (int64_t)bytes;
     return NUFFT_OK;
+}
+template <typename P>
+static void dev_free(nufft_plan* p, P*& ptr) {
+    if (!ptr) return;
+    auto it = p->allocs.find(static_cast<void*>(ptr));
+    if (it != p->allocs.end()) { p->workspace_bytes -= it->second.second; p->allocs.erase(it); }
+    (void)hipFree(ptr);
+    ptr = nullptr;
 }
 
 template <typename T>
@@ -135,10 +147,8 @@ struct StageTimer {
 // ------------------------------------------------------------------------------------------
 // plan construction
 // ------------------------------------------------------------------------------------------
-static int env_int(const char* name, int fallback) {
-    const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : fallback;
-}
+// development switches: nufft_params.options of the plan at hand (options.h) — never the environment in a release build
+static int env_int(const char* name, int fallback) { return option_int(name, fallback); }
 
 // Default of the spreading ring's halo variant for this plan (0: clipped columns, 2: halo variant); see DESIGN.md section 4.9.
 // Measured (256^3 -> 512^3, Np = 1e7; spread + FFT stages, ms; scripts/r4_halo_matrix.sh): Float64 m = 2 ... 7: 2.08 / 2.57 / 3.03 / 5.72 /
@@ -165,6 +175,8 @@ static int ring_max_half_support(const nufft_plan* p) {
 }
 
 static int build_host(nufft_plan* p, const nufft_params* in) {
+    p->opts.parse(in->options);
+    set_current_options(&p->opts);
     p->dtype = in->dtype;
     p->is_complex = in->is_complex != 0;
     p->D = in->ndim;
@@ -297,7 +309,7 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
     int forced_sp[3] = {in->tile_dims[0], in->tile_dims[1], in->tile_dims[2]};
     int forced_ip[3] = {in->interp_tile_dims[0], in->interp_tile_dims[1], in->interp_tile_dims[2]};
     auto env_tile = [](const char* name, int* out) {
-        const char* e = std::getenv(name);
+        const char* e = option_str(name);
         if (e && *e && out[0] <= 0) {
             int a = 0, b = 0, c = 0;
             const int n = std::sscanf(e, "%d,%d,%d", &a, &b, &c);
@@ -429,6 +441,12 @@ static int build_device(nufft_plan* p) {
     if (p->device >= ndev) return fail(NUFFT_ERR_INVALID_ARG, "device ordinal out of range");
     DeviceGuard guard(p->device);
     std::call_once(g_rocfft_once, [] { (void)rocfft_setup(); });
+    {
+        // every engine set-up below (ring launch models, sort slices) sizes itself for this device — not for the default of 256 CUs
+        hipDeviceProp_t prop;
+        NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
+        p->num_cus = prop.multiProcessorCount;
+    }
 
     int rc;
     const int D = p->D, L = 2 * p->M;
@@ -470,15 +488,15 @@ static int build_device(nufft_plan* p) {
         p->grid_elems *= p->Nover[d];
         p->spec_elems *= p->Nspec[d];
     }
-    if ((rc = dev_alloc(p, &p->d_us, (size_t)p->grid_elems * value_bytes(p) * p->C))) return rc;
+    if ((rc = dev_alloc(p, &p->d_us, (size_t)p->grid_elems * value_bytes(p) * p->C, "us"))) return rc;
     if (!p->is_complex) {
-        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->spec_elems * 2 * real_bytes(p) * p->C))) return rc;
+        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->spec_elems * 2 * real_bytes(p) * p->C, "uhat"))) return rc;
     }
 
     // bin-sort scratch that does not depend on Np
     const size_t nt1 = (size_t)p->tile.nbins + 1;
-    if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_counts), nt1 * sizeof(uint32_t)))) return rc;
-    if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_offsets), nt1 * sizeof(uint32_t)))) return rc;
+    if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_counts), nt1 * sizeof(uint32_t), "bin_counts"))) return rc;
+    if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_offsets), nt1 * sizeof(uint32_t), "bin_offsets"))) return rc;
     p->scan_tmp_bytes = binsort_scan_tmp_bytes((int)p->tile.nbins);
     if ((rc = dev_alloc(p, &p->d_scan_tmp, p->scan_tmp_bytes))) return rc;
     // load balance: slot tables for tiles + a budget of extra slices (a quarter of the tiles, at least 1024)
@@ -521,7 +539,7 @@ static int build_device(nufft_plan* p) {
     p->fft_work_bytes = std::max(wf, wb);
     NUFFT_ROCFFT(rocfft_execution_info_create(&p->fft_info));
     if (p->fft_work_bytes > 0) {
-        if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes))) return rc;
+        if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes, "rocfft_work"))) return rc;
         NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
     }
 
@@ -534,7 +552,7 @@ static int build_device(nufft_plan* p) {
         // spectrum (N1 kept modes per line of dimension 1)
         p->pspec_elems = p->Nout[0];
         for (int d = 1; d < D; ++d) p->pspec_elems *= p->Nover[d];
-        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->pspec_elems * 2 * real_bytes(p) * p->C))) return rc;
+        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->pspec_elems * 2 * real_bytes(p) * p->C, "uhat"))) return rc;
     }
     if (p->pruned_fft && !p->is_complex) {
         size_t len1[1] = {(size_t)p->Nover[0]};
@@ -546,9 +564,9 @@ static int build_device(nufft_plan* p) {
         NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft1_fw, &w1));
         NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft1_bw, &w2));
         if (std::max(w1, w2) > p->fft_work_bytes) {
-            if (p->d_fft_work) { (void)hipFree(p->d_fft_work); p->workspace_bytes -= (int64_t)p->fft_work_bytes; p->d_fft_work = nullptr; }
+            dev_free(p, p->d_fft_work);
             p->fft_work_bytes = std::max(w1, w2);
-            if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes))) return rc;
+            if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes, "rocfft_work"))) return rc;
             NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
         }
     }
@@ -592,7 +610,7 @@ static int build_device(nufft_plan* p) {
         }
         if (D == 3) {
             const size_t elems = (size_t)(p->compact_dim1 ? p->spec_row : p->Nout[0]) * p->Nout[1] * p->Nover[2];
-            if ((rc = dev_alloc(p, &p->d_tmp2, elems * 2 * real_bytes(p)))) return rc;
+            if ((rc = dev_alloc(p, &p->d_tmp2, elems * 2 * real_bytes(p), "tmp2"))) return rc;
         }
     }
 
@@ -635,16 +653,10 @@ static int build_device(nufft_plan* p) {
             NUFFT_HIP(hipMemset(p->d_march_choice, 0, 16 * sizeof(uint32_t)));
             if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_march_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
             if ((rc = dev_alloc(p, &p->d_march_tasks, (size_t)column_task_table_entries(p->march_ct, p->tile.nb[2]) * 8))) return rc;
-            hipDeviceProp_t prop;
-            NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
-            p->num_cus = prop.multiProcessorCount;
         }
     }
 
     if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
-        hipDeviceProp_t prop;
-        NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
-        p->num_cus = prop.multiProcessorCount;
         const bool other = needs_other_eval(p->kernel, p->evalmode);
         int want_halo = p->smarch.halo;
         if (want_halo == 2 && !(p->pruned_fft && p->compact_dim1) && env_int("NUFFT_SMARCH_HALO", 0) != 2) want_halo = 0;   // no fused consumer: not worth it
@@ -657,8 +669,7 @@ static int build_device(nufft_plan* p) {
             if (!p->smarch.eligible || p->smarch.halo != 2) break;
             const size_t bytes = (size_t)p->smarch.halo_reals * real_bytes(p) * p->C * p->smarch.parts;
             // (NUFFT_TEST_HALO_ALLOC_FAIL=1: the test of this fallback)
-            if (!env_int("NUFFT_TEST_HALO_ALLOC_FAIL", 0) && hipMalloc(&p->d_smarch_halo, bytes) == hipSuccess) { p->workspace_bytes += (int64_t)bytes; break; }
-            (void)hipGetLastError();
+            if (!env_int("NUFFT_TEST_HALO_ALLOC_FAIL", 0) && dev_alloc(p, &p->d_smarch_halo, bytes, "ring_side_buffer") == NUFFT_OK) break;
             p->d_smarch_halo = nullptr;
             want_halo = 0;
         }
@@ -669,7 +680,7 @@ static int build_device(nufft_plan* p) {
         if (!keep) {
             if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING)
                 return fail(NUFFT_ERR_UNSUPPORTED, "marching-ring spreading: no decomposition for this device");
-            if (p->d_smarch_halo) { (void)hipFree(p->d_smarch_halo); p->d_smarch_halo = nullptr; }
+            dev_free(p, p->d_smarch_halo);
             p->smarch.eligible = false;
             const bool prefer_patches = p->is_complex || p->M >= 5 || p->patch.planar != 0;
             p->spread_method = (p->patch.eligible && prefer_patches) ? NUFFT_SPREAD_MFMA_PATCHES : NUFFT_SPREAD_LDS_TILES;
@@ -693,9 +704,7 @@ static int build_device(nufft_plan* p) {
         const size_t ncols = (size_t)p->patch.npx * p->patch.npy;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_patch_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
         if ((rc = dev_alloc(p, &p->d_patch_tasks, ((size_t)p->patch.ntasks + 2 * ncols) * 8))) return rc;      // patch_task_table_entries
-        hipDeviceProp_t prop;
-        NUFFT_HIP(hipGetDeviceProperties(&prop, p->device));
-        p->wave_slots = prop.multiProcessorCount * 4 * p->patch.occ;      // 4 SIMDs per CU
+        p->wave_slots = p->num_cus * 4 * p->patch.occ;      // 4 SIMDs per CU
     }
 
     // Column-layer sort (binsort.hip, CoarseSort): where the spreading window (halo variant: a column visits its own points only) and
@@ -716,7 +725,7 @@ static int build_device(nufft_plan* p) {
             p->coarse.groups = p->num_cus;
             p->coarse.flag_a = p->d_smarch_choice + 2;
             p->coarse.flag_b = p->d_march_choice + 2;
-            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->coarse.table), (size_t)p->coarse.groups * nkeys * sizeof(uint32_t)))) return rc;
+            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->coarse.table), (size_t)p->coarse.groups * nkeys * sizeof(uint32_t), "sort_slice_table"))) return rc;
             NUFFT_HIP(prepare_binsort_coarse(p->dtype, nkeys));
             NUFFT_HIP(prepare_interp_march_staged(p->dtype, mcplx, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
         }
@@ -729,7 +738,10 @@ static int build_device(nufft_plan* p) {
         p->slab.mode = 2;
         p->slab_min_points = env_int("NUFFT_SLAB_MIN_POINTS", 16384);
         p->slab_fill = std::min(95, std::max(5, env_int("NUFFT_SLAB_FILL", 85)));
-        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->slab.table), (size_t)p->num_cus * kCoarseMaxKeys * sizeof(uint32_t)))) return rc;
+        // [slices][keys] table of level 1: at most one slice per CU; the keys are (rows of bins / slab height) x layers — never more than
+        // nb[1] x nb[2], whatever height set_points picks (a 16^3 plan used to pay the 37.7 MB of the largest grid: ADVICE round 5)
+        p->slab_max_keys = (int)std::min<int64_t>(kCoarseMaxKeys, (int64_t)p->tile.nb[1] * p->tile.nb[2]);
+        if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->slab.table), (size_t)p->num_cus * p->slab_max_keys * sizeof(uint32_t), "sort_slice_table"))) return rc;
         if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->slab.flagmem), 32))) return rc;      // [0] fullest slab (running), [4] flag
         NUFFT_HIP(hipMemset(p->slab.flagmem, 0, 32));
         p->slab.flag_a = p->slab.flag_b = p->slab.flagmem + 4;
@@ -750,18 +762,12 @@ static int build_device(nufft_plan* p) {
 
 static void release(nufft_plan* p) {
     if (!p) return;
+    if (current_options() == &p->opts) set_current_options(nullptr);
     if (p->device >= 0) {
         DeviceGuard guard(p->device);
         (void)hipDeviceSynchronize();
-        auto fr = [](void* q) { if (q) (void)hipFree(q); };
-        fr(p->d_coefs);
-        for (int d = 0; d < 3; ++d) { fr(p->d_phihat[d]); fr(p->d_index_map[d]); fr(p->d_inv_map[d]); }
-        fr(p->d_us); fr(p->d_uhat); fr(p->d_counts); fr(p->d_offsets); fr(p->d_binrank); fr(p->d_sorted); fr(p->d_vsorted); fr(p->d_patch_choice); fr(p->d_patch_cols); fr(p->d_patch_tasks); fr(p->d_march_choice); fr(p->d_march_cols); fr(p->d_march_tasks);
-        fr(p->d_smarch_choice); fr(p->d_smarch_cols); fr(p->d_smarch_tasks); fr(p->d_smarch_halo); fr(p->coarse.table); fr(p->slab.table); fr(p->slab.flagmem);
-        fr(p->d_scan_tmp); fr(p->d_fft_work); fr(p->d_tmp2); fr(p->d_one);
-        fr(p->bal.d_work); fr(p->bal.d_nslices); fr(p->bal.d_desc_off); fr(p->bal.d_desc);
-        fr(p->bal.d_slots); fr(p->bal.d_tmp);
-        for (int d = 0; d < 3; ++d) { fr(p->d_tw_fw[d]); fr(p->d_tw_bw[d]); fr(p->d_invphi[d]); }
+        for (auto& al : p->allocs) (void)hipFree(al.first);      // every device buffer of the plan (dev_alloc)
+        p->allocs.clear();
         if (p->fft1_fw) (void)rocfft_plan_destroy(p->fft1_fw);
         if (p->fft1_bw) (void)rocfft_plan_destroy(p->fft1_bw);
         if (p->fft_fw) (void)rocfft_plan_destroy(p->fft_fw);
@@ -777,6 +783,7 @@ static void release(nufft_plan* p) {
 
 static int require_device(const nufft_plan* p) {
     if (!p) return fail(NUFFT_ERR_INVALID_ARG, "null plan");
+    set_current_options(&p->opts);      // the development switches any code below may consult are this plan's (options.h)
     if (p->device < 0) return fail(NUFFT_ERR_NO_DEVICE, "host-only plan (device = -1) has no device path");
     return NUFFT_OK;
 }
@@ -835,6 +842,36 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     return a;
 }
 
+// ---- halo variant of the spreading ring: the state "side buffer written, reach not yet added to us" (nufft_internal.h: halo_hint) ----
+static bool halo_plan(const nufft_plan* p) { return p->spread_method == NUFFT_SPREAD_MARCHING_RING && p->smarch.halo == 2 && p->d_smarch_halo && p->d_smarch_choice; }
+// any call on the plan that is being captured into a hipGraph makes the host hint unreliable from then on (a replay changes the device
+// state behind the host's back): every consumer / voiding launch is enqueued unconditionally afterwards, gated on the device word
+static void note_capture(nufft_plan* p, hipStream_t stream) {
+    if (p->halo_sticky || !halo_plan(p)) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (st != hipStreamCaptureStatusNone) p->halo_sticky = true;
+}
+static bool halo_maybe_pending(const nufft_plan* p) { return halo_plan(p) && (p->halo_hint || p->halo_sticky); }
+// the grids are about to be overwritten: an unconsumed side buffer is void
+static int void_halo(nufft_plan* p, hipStream_t stream) {
+    if (halo_maybe_pending(p)) NUFFT_HIP(launch_zero_fill(p->d_smarch_choice + kHaloStateWord, 4, stream));
+    p->halo_hint = false;
+    return NUFFT_OK;
+}
+
+// The halo variant's side buffer has not been added to the grid yet (nufft_spread_deferred): do it now, unless the caller is
+// the FFT pass that adds it on the fly.
+static int complete_halo(nufft_plan* p, hipStream_t stream) {
+    if (!halo_maybe_pending(p)) return NUFFT_OK;
+    TileKernelArgs a = tile_args(p, false);
+    NUFFT_HIP(launch_smarch_halo_add(a, p->smarch, p->d_smarch_choice + kHaloStateWord, stream));      // (returns at once where the word is 0)
+    NUFFT_HIP(launch_zero_fill(p->d_smarch_choice + kHaloStateWord, 4, stream));
+    p->halo_hint = false;
+    return NUFFT_OK;
+}
+
+
 static DeconvArgs deconv_args(const nufft_plan* p) {
     DeconvArgs a{};
     a.dtype = p->dtype;
@@ -881,12 +918,11 @@ static int ilog2(int64_t n) {
 
 // ---- pruned FFT path (see fft_lines.hip) ---------------------------------------------------------
 // type 1, stage "FFT": rocFFT r2c along dim 1 and, for D = 3, the pruned pass along dim 2 into tmp2.
-static int pruned_forward_fft(nufft_plan* p, hipStream_t stream) {
+static int pruned_forward_fft(nufft_plan* p, hipStream_t stream, bool fuse) {
     // behind the halo variant of the spreading ring (nufft_spread_deferred): the pass adds the side buffer while it loads its lines
     RealLineHalo hh{};
-    const bool fuse = p->halo_pending && p->D == 3;
     if (fuse) {
-        hh.flag = p->d_smarch_choice + 2;
+        hh.flag = p->d_smarch_choice + kHaloStateWord;      // (1 implies that the ring served the point set)
         hh.ny = (int)p->Nover[1];
         hh.layout = make_halo_layout(p->smarch.n1, p->smarch.n2, p->M, (p->is_complex && p->smarch.parts != 2) ? 2 : 1, p->smarch.ct.ncolx, p->smarch.ct.ncoly);
     }
@@ -1054,6 +1090,16 @@ const char* nufft_strerror(int code) {
 int nufft_plan_create_ex(nufft_plan** out, const nufft_params* params) {
     if (!out || !params) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
+    // The caller says how much of the struct it knows (struct_size = sizeof(nufft_params) of ITS header; 0 = the layout of ABI <= 102, which
+    // ended before kernel_param_dim): only that prefix is read, the rest counts as zero — a binding built against an older header can
+    // never make the library read past its struct.
+    nufft_params prm;
+    std::memset(&prm, 0, sizeof(prm));
+    size_t known = params->struct_size > 0 ? (size_t)params->struct_size : offsetof(nufft_params, kernel_param_dim);
+    if (known < offsetof(nufft_params, kernel_param_dim)) return fail(NUFFT_ERR_INVALID_ARG, "nufft_params.struct_size is smaller than any published layout");
+    if (known > sizeof(prm)) known = sizeof(prm);
+    std::memcpy(&prm, params, known);
+    params = &prm;
     nufft_plan* p = new (std::nothrow) nufft_plan();
     if (!p) return fail(NUFFT_ERR_ALLOC, "out of host memory");
     int rc = build_host(p, params);
@@ -1088,7 +1134,25 @@ int nufft_plan_create(nufft_plan** out, int dtype, int is_complex, int ndim, con
     prm.point_transform = point_transform;
     prm.gpu_method = NUFFT_METHOD_SHARED_MEMORY;
     prm.device = device;
+    prm.struct_size = (int32_t)sizeof(prm);
     return nufft_plan_create_ex(out, &prm);
+}
+
+const char* nufft_plan_options(const nufft_plan* p) {
+    if (!p) return "";
+    const_cast<nufft_plan*>(p)->opts_text = p->opts.str();
+    return p->opts_text.c_str();
+}
+
+int nufft_workspace_breakdown(const nufft_plan* p, char* out, int64_t capacity) {
+    if (!p || !out || capacity < 1) return fail(NUFFT_ERR_INVALID_ARG, "null argument");
+    std::map<std::string, int64_t> sums;
+    for (const auto& a : p->allocs) sums[a.second.first] += a.second.second;
+    std::string text;
+    for (const auto& e : sums) text += e.first + "=" + std::to_string(e.second) + ";";
+    if ((int64_t)text.size() + 1 > capacity) return fail(NUFFT_ERR_DIM_MISMATCH, "buffer too small for the breakdown");
+    std::memcpy(out, text.c_str(), text.size() + 1);
+    return NUFFT_OK;
 }
 
 int nufft_plan_destroy(nufft_plan* plan) {
@@ -1180,7 +1244,6 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     if (np < 0) return fail(NUFFT_ERR_INVALID_ARG, "negative number of points");
     if (np >= ((int64_t)1 << 31) - 1) return fail(NUFFT_ERR_UNSUPPORTED, "number of points exceeds 2^31 - 2");
     if (!coords) return fail(NUFFT_ERR_INVALID_ARG, "null coordinate table");
-    p->halo_pending = false;           // a deferred spread of the previous point set that was never consumed is void
     for (int d = 0; d < p->D; ++d)
         if (np > 0 && !coords[d]) return fail(NUFFT_ERR_INVALID_ARG, "null coordinate vector");
     DeviceGuard guard(p->device);
@@ -1189,23 +1252,18 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     if (np > p->Np_capacity) {
         // resize_no_copy!, src/blocking/blocking.jl:55-61 (old contents are discarded).  hipFree / hipMalloc are not
         // capturable: pre-size the plan with the largest point set before capturing set_points in a hipGraph.
-        if (p->d_binrank) { (void)hipFree(p->d_binrank); p->workspace_bytes -= p->Np_capacity * binrank_bytes(p); p->d_binrank = nullptr; }
-        if (p->d_sorted) {
-            (void)hipFree(p->d_sorted);
-            p->workspace_bytes -= p->Np_capacity * (int64_t)point_record_bytes(p->dtype, p->D);
-            p->d_sorted = nullptr;
-        }
-        if (p->d_vsorted) {
-            (void)hipFree(p->d_vsorted);
-            p->workspace_bytes -= p->Np_capacity * (int64_t)value_bytes(p) * p->C;
-            p->d_vsorted = nullptr;
-        }
+        dev_free(p, p->d_binrank);
+        dev_free(p, p->d_sorted);
+        dev_free(p, p->d_vsorted);
         p->Np_capacity = 0;
-        if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES && (rc = dev_alloc(p, &p->d_vsorted, (size_t)np * value_bytes(p) * p->C))) return rc;
-        if ((rc = dev_alloc(p, &p->d_binrank, (size_t)np * binrank_bytes(p)))) return rc;
-        if ((rc = dev_alloc(p, &p->d_sorted, (size_t)np * point_record_bytes(p->dtype, p->D)))) return rc;
+        if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES && (rc = dev_alloc(p, &p->d_vsorted, (size_t)np * value_bytes(p) * p->C, "vsorted"))) return rc;
+        if ((rc = dev_alloc(p, &p->d_binrank, (size_t)np * binrank_bytes(p), "sort_scratch"))) return rc;
+        if ((rc = dev_alloc(p, &p->d_sorted, (size_t)np * point_record_bytes(p->dtype, p->D), "sorted"))) return rc;
         p->Np_capacity = np;
     }
+    note_capture(p, stream);
+    p->halo_hint = false;              // a deferred spread of the previous point set that was never consumed is void (the ring's task kernel
+                                       // below clears the device word with the rest of its per-point-set record)
     StageTimer tm(p, NUFFT_STAGE_SET_POINTS, stream);
     SortArgs s{};
     s.dtype = p->dtype;
@@ -1233,7 +1291,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         int best = -1;
         for (int sby = 1; sby <= p->tile.nb[1] && (int64_t)sby * p->tile.nb[0] <= kSlabMaxBins; sby *= 2) {
             const int64_t nkeys = (int64_t)p->tile.nb[2] * ((p->tile.nb[1] + sby - 1) / sby);
-            if (nkeys > kCoarseMaxKeys) continue;
+            if (nkeys > p->slab_max_keys) continue;
             if (np / nkeys > (int64_t)capmax * p->slab_fill / 100) break;
             if (best > 0 && nkeys < 2048) break;
             best = sby;
@@ -1314,7 +1372,7 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         // (halo variant: 1.87 instead of 2.44 ms at C2, + 0.15 ms in the FFT pass: 3.67 / 2.62 = 1.4 against the tiles, stage + FFT; the
         // reference's benchmark distribution — folded N(0, 1), sigma = 1.5, Np = 1.68e7 — sits at the threshold: tiles 6.78 + 0.32 ms
         // below 1.19, window 6.18 + 0.38 ms from 1.3 on, hence 0.93 instead of 0.85 here)
-        static const double adv_env = [] { const char* e = std::getenv("NUFFT_SMARCH_ADVANTAGE"); return e && *e ? std::atof(e) : 0.0; }();
+        const double adv_env = option_double("NUFFT_SMARCH_ADVANTAGE", 0.0);
         double advantage = p->smarch.halo == 2 ? 0.93 * 1.4 : 0.85 * 1.3;
         if (adv_env > 0.0) advantage = adv_env;       // (experiments)
         if (p->spread_method_req == NUFFT_SPREAD_MARCHING_RING) advantage = 0.0;
@@ -1453,7 +1511,8 @@ int nufft_fill_zeros(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_ZERO, stream);
-    p->halo_pending = false;
+    note_capture(p, stream);
+    if ((rc = void_halo(p, stream))) return rc;
     NUFFT_HIP(launch_zero_fill(p->d_us, (size_t)p->grid_elems * value_bytes(p) * p->C, stream));
     return NUFFT_OK;
 }
@@ -1468,6 +1527,7 @@ static int spread_impl(nufft_plan* p, const void* const* values_in, void* stream
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T1_SPREAD, stream);
+    note_capture(p, stream);
     TileKernelArgs a = tile_args(p, false);
     a.values_in = values_in;
     // LDS-tile engine.  On plans of the MFMA-patch engine set_points has decided on the device which of the two serves
@@ -1477,11 +1537,12 @@ static int spread_impl(nufft_plan* p, const void* const* values_in, void* stream
                                           p->grid_elems * (p->is_complex ? 2 : 1), stream));
     NUFFT_HIP(launch_spread(a, stream));
     if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
-        NUFFT_HIP(launch_spread_march(a, p->smarch, p->d_smarch_choice + 2, static_cast<const uint2*>(p->d_smarch_tasks), stream));
+        // (halo variant: the kernel sets the device word "side buffer pending")
+        NUFFT_HIP(launch_spread_march(a, p->smarch, p->d_smarch_choice + 2, static_cast<const uint2*>(p->d_smarch_tasks), p->d_smarch_choice + kHaloStateWord, stream));
         // halo variant: the grid is complete once the side buffer has been added — here, or by the first FFT pass
-        if (p->smarch.halo == 2) {
-            if (!defer_halo) NUFFT_HIP(launch_smarch_halo_add(a, p->smarch, p->d_smarch_choice + 2, stream));
-            p->halo_pending = defer_halo;
+        if (halo_plan(p)) {
+            p->halo_hint = true;
+            if (!defer_halo && (rc = complete_halo(p, stream))) return rc;
         }
     }
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES) {
@@ -1506,16 +1567,6 @@ static int spread_impl(nufft_plan* p, const void* const* values_in, void* stream
 int nufft_spread(nufft_plan* p, const void* const* values_in, void* stream_) { return spread_impl(p, values_in, stream_, false); }
 int nufft_spread_deferred(nufft_plan* p, const void* const* values_in, void* stream_) { return spread_impl(p, values_in, stream_, true); }
 
-// The halo variant's side buffer has not been added to the grid yet (nufft_spread_deferred): do it now, unless the caller is
-// the FFT pass that adds it on the fly.
-static int complete_halo(nufft_plan* p, hipStream_t stream) {
-    if (!p->halo_pending) return NUFFT_OK;
-    p->halo_pending = false;
-    TileKernelArgs a = tile_args(p, false);
-    NUFFT_HIP(launch_smarch_halo_add(a, p->smarch, p->d_smarch_choice + 2, stream));
-    return NUFFT_OK;
-}
-
 int nufft_fft_forward(nufft_plan* p, void* stream_) {
     int rc = require_device(p);
     if (rc) return rc;
@@ -1526,10 +1577,11 @@ int nufft_fft_forward(nufft_plan* p, void* stream_) {
     // every other FFT path gets the completed grid
     // (the fused pass adds the buffer to the lines it has loaded, not to us: halo_pending stays set — us still lacks the reach, the
     // side buffer stays valid until the next spread / set_points — and nufft_complete_grid / _copy_grid / _interpolate add it on demand)
-    const bool fuse_halo = p->halo_pending && p->pruned_fft && p->compact_dim1 && p->D == 3 && p->halo_fuse;      // (compact_dim1: true for complex plans)
-    if (p->halo_pending && !fuse_halo && (rc = complete_halo(p, stream))) return rc;
+    note_capture(p, stream);
+    const bool fuse_halo = halo_maybe_pending(p) && p->pruned_fft && p->compact_dim1 && p->D == 3 && p->halo_fuse;      // (compact_dim1: true for complex plans)
+    if (!fuse_halo && (rc = complete_halo(p, stream))) return rc;
     if (p->pruned_fft) {
-        if ((rc = pruned_forward_fft(p, stream))) return rc;
+        if ((rc = pruned_forward_fft(p, stream, fuse_halo))) return rc;
         if (p->D == 3 && p->C == 1) return pruned_forward_pass(p, 0, 1, nullptr, stream);
         return NUFFT_OK;      // C > 1: tmp2 is reused per component, both passes run in the deconvolution stage
     }
@@ -1568,6 +1620,8 @@ int nufft_deconvolve_pad(nufft_plan* p, const void* const* uhat_in, void* stream
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_DECONV, stream);
+    note_capture(p, stream);
+    if ((rc = void_halo(p, stream))) return rc;      // type 2 starts: the grids will be overwritten (complex plans of the general path: by this stage)
     if (p->pruned_fft) {
         // zero-padding + deconvolution are fused into the pruned inverse passes; tmp2 is reused per component
         for (int c = 0; c < p->C; ++c) {
@@ -1587,7 +1641,8 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_FFT, stream);
-    p->halo_pending = false;           // the grids are overwritten: an unconsumed deferred spread is void
+    note_capture(p, stream);
+    if ((rc = void_halo(p, stream))) return rc;      // the grids are overwritten: an unconsumed deferred spread is void
     if (p->pruned_fft && p->is_complex) {
         int64_t per = 1;
         for (int d = 1; d < p->D; ++d) per *= p->Nover[d];
@@ -1629,6 +1684,7 @@ int nufft_interpolate(nufft_plan* p, void* const* values_out, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer tm(p, NUFFT_STAGE_T2_INTERP, stream);
+    note_capture(p, stream);
     if ((rc = complete_halo(p, stream))) return rc;
     if (p->Np == 0) return NUFFT_OK;
     TileKernelArgs a = tile_args(p, true);
@@ -1658,9 +1714,19 @@ struct CallbackScope {
         p->cb_point_weights = cb ? cb->point_weights : nullptr;
         p->cb_mode_factors = cb ? cb->mode_factors : nullptr;
     }
-    ~CallbackScope() { p->cb_point_weights = nullptr; p->cb_mode_factors = nullptr; }
+    ~CallbackScope() { p->cb_point_weights = p->cb_sticky_weights; p->cb_mode_factors = p->cb_sticky_factors; }
 };
 }  // namespace
+
+// The callback menu for the STAGE-level entry points (nufft_spread[_deferred], nufft_deconvolve_truncate, nufft_deconvolve_pad,
+// nufft_interpolate): in force until the next call (NULL: none).  A binding that enqueues the stages one by one — as the reference's
+// exec_type1! / exec_type2! do, each under its own timer label (src/NonuniformFFTs.jl:157-186, 246-283) — brackets them with this.
+int nufft_set_callbacks(nufft_plan* p, const nufft_callbacks* cb) {
+    if (!p) return fail(NUFFT_ERR_INVALID_ARG, "null plan");
+    p->cb_sticky_weights = p->cb_point_weights = cb ? cb->point_weights : nullptr;
+    p->cb_sticky_factors = p->cb_mode_factors = cb ? cb->mode_factors : nullptr;
+    return NUFFT_OK;
+}
 
 int nufft_exec_type1_cb(nufft_plan* p, void* const* uhat_out, const void* const* values_in, const nufft_callbacks* cb,
                         void* stream) {
@@ -1690,7 +1756,7 @@ int nufft_grid_ptr(const nufft_plan* p, int which, int component, void** out_ptr
     if (rc) return rc;
     if (!out_ptr || component < 0 || component >= p->C) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
     if (which == 0) {
-        if (p->halo_pending)
+        if (halo_maybe_pending(p))
             return fail(NUFFT_ERR_INVALID_ARG, "us lacks the side buffer of a deferred spread (nufft_spread_deferred / nufft_exec_type1 on a "
                                                "ring_halo plan): call nufft_complete_grid first, or use nufft_copy_grid");
         const size_t bytes = (size_t)p->grid_elems * value_bytes(p);
@@ -1710,23 +1776,27 @@ int nufft_complete_grid(nufft_plan* p, void* stream_) {
     int rc = require_device(p);
     if (rc) return rc;
     DeviceGuard guard(p->device);
+    note_capture(p, static_cast<hipStream_t>(stream_));
     return complete_halo(p, static_cast<hipStream_t>(stream_));
 }
 
 int nufft_copy_grid(nufft_plan* p, int which, int component, void* dst, int64_t capacity_bytes, void* stream_) {
-    void* src = nullptr;
-    int64_t bytes = 0;
     int rc = require_device(p);
     if (rc) return rc;
-    if (which == 0) {
-        DeviceGuard guard(p->device);
-        if ((rc = complete_halo(p, static_cast<hipStream_t>(stream_)))) return rc;
-    }
-    if ((rc = nufft_grid_ptr(p, which, component, &src, &bytes))) return rc;
+    // every argument is checked before anything is enqueued or any plan state changes
+    if (component < 0 || component >= p->C) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
+    if (which != 0 && !(which == 1 && !p->is_complex)) return fail(NUFFT_ERR_INVALID_ARG, "which must be 0 (us) or 1 (ûs, real plans only)");
     if (!dst) return fail(NUFFT_ERR_INVALID_ARG, "null destination");
-    if (capacity_bytes < bytes) return fail(NUFFT_ERR_DIM_MISMATCH, "destination buffer too small");
+    const size_t bytes = which == 0 ? (size_t)p->grid_elems * value_bytes(p) : (size_t)p->spec_elems * 2 * real_bytes(p);
+    if (capacity_bytes < (int64_t)bytes) return fail(NUFFT_ERR_DIM_MISMATCH, "destination buffer too small");
     DeviceGuard guard(p->device);
-    NUFFT_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream_)));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (which == 0) {
+        note_capture(p, stream);
+        if ((rc = complete_halo(p, stream))) return rc;
+    }
+    const char* src = static_cast<const char*>(which == 0 ? p->d_us : p->d_uhat) + bytes * (size_t)component;
+    NUFFT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
     return NUFFT_OK;
 }
 

@@ -226,7 +226,7 @@ static void edge_candidates(int64_t N, int b, int M, int cap, std::vector<int>& 
 // touches consecutive rows with `stencil_inner` contiguous reals each; the rows land on disjoint banks
 // when the stride is congruent to the stencil width modulo the 128-byte bank period.
 int lds_row_stride(int inner_elems, int stencil_inner, int real_bytes) {
-    static const bool no_pad = std::getenv("NUFFT_LDS_NO_PAD") != nullptr;
+    const bool no_pad = option_present("NUFFT_LDS_NO_PAD");
     return no_pad ? inner_elems : padded_row_stride(inner_elems, stencil_inner, real_bytes);
 }
 

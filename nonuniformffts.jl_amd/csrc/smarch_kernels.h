@@ -224,6 +224,8 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     constexpr bool FAST = C::FAST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+    if ((HX || HY) && mg.halo_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *mg.halo_state = *mg.flag != 0u ? 1u : 0u;      // the side buffer this launch writes is pending (no side buffer: the tiles serve the set)
     if (*mg.flag == 0u) return;                         // spread_tile_kernel serves this point set
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);      // (wave: a scalar)
     const Geom& g = a.g;

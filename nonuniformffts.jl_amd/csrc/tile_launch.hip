@@ -150,10 +150,8 @@ SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, b
     if (8 + L - 1 > g.Nover[0] || 8 + L - 1 > g.Nover[1] || g.nb[2] < 2 * (hlo + hhi) || g.nb[2] > 2048) return sp;
     // input-driven dimensions: the window (column + 2M) must not wrap onto itself
     if ((hx && 8 + 2 * L > g.Nover[0]) || (hy && 8 + 2 * L > g.Nover[1])) return sp;
-    static const int xcd_chunk = [] { const char* e = std::getenv("NUFFT_XCD_CHUNK"); return e && *e ? std::atoi(e) : 8; }();
-    static const int force_n1 = [] { const char* e = std::getenv("NUFFT_SMARCH_N1"); return e && *e ? std::atoi(e) : 0; }();
-    static const int force_n2 = [] { const char* e = std::getenv("NUFFT_SMARCH_N2"); return e && *e ? std::atoi(e) : 0; }();
-    static const int force_nseg = [] { const char* e = std::getenv("NUFFT_SMARCH_NSEG"); return e && *e ? std::atoi(e) : 0; }();
+    const int xcd_chunk = option_int("NUFFT_XCD_CHUNK", 8);
+    const int force_n1 = option_int("NUFFT_SMARCH_N1", 0), force_n2 = option_int("NUFFT_SMARCH_N2", 0), force_nseg = option_int("NUFFT_SMARCH_NSEG", 0);
     const double cz = 0.5 * (hlo + hhi);               // a halo layer's points are visited, but add about half their planes
     const double fixed = 0.15;                         // per task, in layers: ring zero fill, first table, launch
     double best = 1e300;
@@ -468,7 +466,7 @@ PatchPlan patch_plan(int dtype, int is_complex, int D, int M, const Geom& g, boo
     // segments along dimension 3: enough tasks for ~4 rounds of the 2048 resident waves, at least 8 cube layers each
     // (a segment visits ncb - 1 bin layers beyond its own)
     const int cols = pp.npx * pp.npy;
-    static const int task_target = [] { const char* e = std::getenv("NUFFT_PATCH_TASKS"); return e && *e ? std::atoi(e) : 8192; }();
+    const int task_target = option_int("NUFFT_PATCH_TASKS", 8192);
     int nseg = (task_target + cols - 1) / cols;
     const int max_seg = g.nb[2] / 8 > 0 ? g.nb[2] / 8 : 1;
     if (nseg > max_seg) nseg = max_seg;
@@ -613,7 +611,7 @@ hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np
 }
 
 template <typename T>
-static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
+static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, hipStream_t stream) {
     int lds = 0, n[5];
     const int parts = (sp.parts == 2 && a.is_complex) ? 2 : 1;      // complex data part by part through the real kernel
     const void* fn = smarch_kernel(a.dtype, parts == 2 ? 0 : a.is_complex, a.M, sp.halo, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
@@ -635,6 +633,7 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
         mg.halo = sp.halo == 2 ? static_cast<void*>(static_cast<T*>(a.halo) + (int64_t)c0 * parts * sp.halo_reals) : nullptr;
         mg.halo_comp = sp.halo_reals;
         mg.parts = parts;
+        mg.halo_state = sp.halo == 2 ? halo_state : nullptr;
         void* params[] = {&k, &mg};
         // (parts = 2: both parts of a task side by side on one XCD — smarch_kernels.h)
         const unsigned gx = parts == 2 ? 2u * (((unsigned)mg.ntasks + 7u) & ~7u) : (unsigned)mg.ntasks;
@@ -643,8 +642,8 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
     }
     return hipSuccess;
 }
-hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, hipStream_t stream) {
-    return a.dtype == NUFFT_F32 ? launch_smarch_t<float>(a, sp, flag, tasktab, stream) : launch_smarch_t<double>(a, sp, flag, tasktab, stream);
+hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_smarch_t<float>(a, sp, flag, tasktab, halo_state, stream) : launch_smarch_t<double>(a, sp, flag, tasktab, halo_state, stream);
 }
 hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, hipStream_t stream) {
     if (sp.halo != 2) return hipSuccess;
@@ -656,7 +655,7 @@ hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp,
         return launch_halo_add_lines(a.dtype, a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g.Nover[0], a.g.Nover[1], a.g.Nover[2], a.C, h, flag, stream, true);
     }
     // line by line through LDS (fft_lines.hip: 0.6 ms at C2); the element-wise gather kernel (1.5 ms) where a line does not fit
-    static const bool gather = [] { const char* e = std::getenv("NUFFT_SMARCH_HALO_ADD_GATHER"); return e && *e && std::atoi(e) != 0; }();
+    const bool gather = option_int("NUFFT_SMARCH_HALO_ADD_GATHER", 0) != 0;
     if (!gather) {
         const HaloLayout h = make_halo_layout(sp.n1, sp.n2, a.M, ncr, sp.ct.ncolx, sp.ct.ncoly);
         hipError_t e = launch_halo_add_lines(a.dtype, a.grid, a.halo, a.grid_stride * ncr, sp.halo_reals, a.g.Nover[0], a.g.Nover[1], a.g.Nover[2], a.C, h, flag, stream);

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple, Union
 
@@ -25,6 +26,9 @@ import torch
 
 from . import _lib
 from ._lib import lib
+
+# NUFFT_* variables that belong to the Python / test harness itself, not to the library's development switches
+_HARNESS_ENV = frozenset({"NUFFT_LIB_PATH", "NUFFT_BENCH_SHARE_GPU", "NUFFT_TEST_ERRLOG", "NUFFT_TEST_EXTRA_SEEDS"})
 
 
 class DimensionMismatch(ValueError):
@@ -206,7 +210,8 @@ class PlanNUFFT:
                  tile_dims: Optional[Sequence[int]] = None, interp_tile_dims: Optional[Sequence[int]] = None,
                  bin_log2: int = 0, lds_budget_bytes: int = 0, spread_threads: int = 0, interp_threads: int = 0,
                  spread_method: Union[str, int] = "auto",
-                 kernel_param_dim: Optional[Sequence[float]] = None, oversampled_dims: Optional[Sequence[int]] = None):
+                 kernel_param_dim: Optional[Sequence[float]] = None, oversampled_dims: Optional[Sequence[int]] = None,
+                 options: Optional[dict] = None):
         if dims is None:           # PlanNUFFT(dims; ...) form: ComplexF64 by default (src/plan.jl:597-599)
             Z, dims = torch.complex128, Z
         if isinstance(dims, int):
@@ -298,11 +303,35 @@ class PlanNUFFT:
         prm.spread_threads = int(spread_threads)
         prm.interp_threads = int(interp_threads)
         prm.spread_method = spread_method if isinstance(spread_method, int) else _SPREAD_METHODS[spread_method]
+        prm.struct_size = C.sizeof(_lib.NufftParams)
+        # development switches (nufft_params.options): the library reads no environment variable.  This module is the development
+        # harness, so it forwards the NUFFT_* variables of its own process (helper scripts and tests keep their command lines);
+        # explicit `options` win.  `plan.options` returns what the plan holds.
+        opts = {k: v for k, v in os.environ.items() if k.startswith("NUFFT_") and k not in _HARNESS_ENV and v != ""}
+        opts.update({str(k): str(v) for k, v in (options or {}).items()})
+        self._options_text = ";".join(f"{k}={v}" for k, v in sorted(opts.items())).encode()      # (kept alive for the call)
+        prm.options = self._options_text if opts else None
         _check(lib.nufft_plan_create_ex(C.byref(self._handle), C.byref(prm)))
         self._info = _lib.NufftInfo()
         _check(lib.nufft_plan_info(self._handle, C.byref(self._info)))
         if self.synchronise:
             _check(lib.nufft_set_timing(self._handle, 1))
+
+    @property
+    def options(self) -> str:
+        """The development switches this plan was created with ("NUFFT_NAME=value;...", empty by default)."""
+        return lib.nufft_plan_options(self._handle).decode()
+
+    def workspace_breakdown(self) -> dict:
+        """Plan-owned device bytes right now, buffer by buffer (sums to info().workspace_bytes)."""
+        buf = C.create_string_buffer(4096)
+        _check(lib.nufft_workspace_breakdown(self._handle, buf, len(buf)))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, v = item.split("=")
+                out[k] = int(v)
+        return out
 
     # ---- lifetime ----------------------------------------------------------------------------
     def close(self):

@@ -37,6 +37,7 @@ static int host_only(void) {
     }
     nufft_params prm;
     memset(&prm, 0, sizeof prm);
+    prm.struct_size = (int32_t)sizeof prm;      /* ABI >= 104: how much of the struct this caller knows */
     prm.dtype = NUFFT_F64; prm.ndim = 3; prm.N[0] = 24; prm.N[1] = 20; prm.N[2] = 16; prm.device = -1;
     nufft_plan* plan = NULL;
     CHECK(nufft_plan_create_ex(&plan, &prm));
@@ -45,6 +46,31 @@ static int host_only(void) {
     if (info.N_over[0] != 48 || info.N_over[1] != 40 || info.N_over[2] != 32 || info.N_out[0] != 13 || info.half_support != 4) {
         fprintf(stderr, "unexpected plan geometry\n");
         return 1;
+    }
+    /* a caller of the ABI <= 102 layout (struct_size = 0, a SHORTER struct in its own memory): the library must not read past it.
+       The fields behind `reserved` are poisoned here; a library that read them would refuse N_over = -1 / take the options pointer. */
+    {
+        nufft_params old = prm;
+        old.struct_size = 0;
+        old.N_over[0] = -1; old.kernel_param_dim[1] = -5.0; old.options = (const char*)(uintptr_t)0x10;
+        nufft_plan* po = NULL;
+        CHECK(nufft_plan_create_ex(&po, &old));
+        nufft_info io;
+        CHECK(nufft_plan_info(po, &io));
+        if (io.N_over[0] != 48) { fprintf(stderr, "legacy-size caller: trailing fields were read\n"); return 1; }
+        CHECK(nufft_plan_destroy(po));
+    }
+    /* development switches travel in the struct, not in the environment */
+    {
+        nufft_params sw = prm;
+        sw.options = "NUFFT_BIN_LOG2=3;NUFFT_X=1";
+        nufft_plan* ps = NULL;
+        CHECK(nufft_plan_create_ex(&ps, &sw));
+        nufft_info is;
+        CHECK(nufft_plan_info(ps, &is));
+        if (is.bin_dims[0] != 8 || strcmp(nufft_plan_options(ps), "NUFFT_BIN_LOG2=3;NUFFT_X=1") != 0) { fprintf(stderr, "options not honoured: %s\n", nufft_plan_options(ps)); return 1; }
+        CHECK(nufft_plan_destroy(ps));
+        if (info.bin_dims[0] != 4 || strcmp(nufft_plan_options(plan), "") != 0) { fprintf(stderr, "default plan carries options\n"); return 1; }
     }
     double phi[32];
     CHECK(nufft_plan_get_phi_hat(plan, 1, phi, 32));

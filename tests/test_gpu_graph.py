@@ -185,3 +185,93 @@ def test_graph_replay_on_a_plan_of_the_slab_sort():
         ref1 = O.exec_type1(oplan, v)
         assert _rel(ud.cpu().numpy(), ref1) < 2e-5, kind
         assert _rel(wd.cpu().numpy(), O.exec_type2(oplan, ref1)) < 2e-5, kind
+
+
+@pytest.mark.parametrize("consumer", ["eager_fft", "eager_interpolate", "second_graph", "eager_copy", "voided_by_type2"])
+def test_deferred_spread_captured_alone_is_consumed_correctly(consumer):
+    """The state "side buffer written, stencil reach not yet added to `us`" of the spreading window's halo variant is a device word that
+    the spreading kernel sets and its consumers clear (plan.cpp: halo_hint / kHaloStateWord), not host state: a nufft_spread_deferred
+    captured ALONE in a hipGraph and replayed later is completed by whatever consumes the grid next — an eager FFT, an eager
+    interpolation, a copy, another graph — exactly once; and a type-2 transform in between voids it."""
+    import ctypes as Ct
+    from nufft_pkg import nufft
+    from nonuniformffts_jl_amd.plan import _check, _ptr_table
+    dims, Np, M = (64, 48, 64), 6000, 4
+    plan = nufft.PlanNUFFT(np.float64, dims, m=M, sigma=2.0, kernel_evalmode=nufft.Direct(), spread_method="marching_ring", backend=nufft.ROCBackend(0))
+    info = plan.info()
+    assert info.spread_method == 3 and info.ring_halo == 1
+    oplan = O.OraclePlan(dims, is_real=True, dtype=np.float64, M=M, sigma=2.0, evalmode=O.DIRECT)
+    dev = plan.device
+    lib, h = nufft.lib, plan._handle
+    rng = np.random.default_rng(77)
+    xs = [rng.random(Np) * O.TWO_PI for _ in dims]
+    v1, v2 = rng.standard_normal(Np), rng.standard_normal(Np)
+    xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
+    vd = torch.from_numpy(v1).to(dev)
+    ud = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    wd = torch.empty(Np, dtype=torch.float64, device=dev)
+    nufft.set_points(plan, xd)
+    O.set_points(oplan, xs)
+    nufft.exec_type1(ud, plan, vd)          # warm-up: everything allocated, an eager deferred spread consumed by the fused pass
+    torch.cuda.synchronize()
+    scale = 2.0 ** sum(info.window_scale_log2[d] for d in range(3))
+
+    def stream():
+        return Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    g_spread = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_spread):
+        _check(lib.nufft_spread_deferred(h, _ptr_table((vd,)), stream()))
+    vd.copy_(torch.from_numpy(v2))          # new values: the replay spreads v2
+    ref_grid = O.spread(oplan, [v2])[0]
+    ref1 = O.exec_type1(oplan, v2)
+
+    if consumer == "eager_fft":
+        g_spread.replay()
+        _check(lib.nufft_fft_forward(h, stream()))
+        _check(lib.nufft_deconvolve_truncate(h, _ptr_table((ud,)), stream()))
+        torch.cuda.synchronize()
+        assert _rel(ud.cpu().numpy(), ref1) < 1e-7
+        # `us` still lacks the reach after the fused pass: a copy completes it, once
+        g = nufft.oversampled_grid(plan, 0).cpu().numpy() / scale
+        assert _rel(g, ref_grid) < 1e-12
+        assert np.array_equal(nufft.oversampled_grid(plan, 0).cpu().numpy() / scale, g)
+    elif consumer == "eager_interpolate":
+        g_spread.replay()
+        nufft.interpolate(plan, wd)
+        torch.cuda.synchronize()
+        assert _rel(wd.cpu().numpy(), O.interpolate(oplan, [ref_grid.copy()])[0]) < 1e-7
+    elif consumer == "eager_copy":
+        for _ in range(3):                  # replays back to back: each spread overwrites grid and side buffer, nothing accumulates
+            g_spread.replay()
+        g = nufft.oversampled_grid(plan, 0).cpu().numpy() / scale
+        assert _rel(g, ref_grid) < 1e-12
+    elif consumer == "second_graph":
+        g_rest = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_rest):
+            _check(lib.nufft_fft_forward(h, stream()))
+            _check(lib.nufft_deconvolve_truncate(h, _ptr_table((ud,)), stream()))
+        for _ in range(2):
+            ud.zero_()
+            g_spread.replay()
+            g_rest.replay()
+            torch.cuda.synchronize()
+            assert _rel(ud.cpu().numpy(), ref1) < 1e-7
+        # the second graph on a grid that an eager, complete nufft_spread left (nothing pending): the reach must not be added twice
+        _check(lib.nufft_spread(h, _ptr_table((vd,)), stream()))
+        ud.zero_()
+        g_rest.replay()
+        torch.cuda.synchronize()
+        assert _rel(ud.cpu().numpy(), ref1) < 1e-7
+    else:
+        # a type-2 transform overwrites the grids: the pending side buffer of the replayed spread is void, not added to the new field
+        g_spread.replay()
+        spec = torch.from_numpy(ref1).to(dev)
+        nufft.exec_type2(wd, plan, spec)
+        torch.cuda.synchronize()
+        assert _rel(wd.cpu().numpy(), O.exec_type2(oplan, ref1)) < 1e-7
+        g = nufft.oversampled_grid(plan, 0)          # (a copy after it must find nothing to add either)
+        nufft.interpolate(plan, wd)
+        torch.cuda.synchronize()
+        assert _rel(wd.cpu().numpy(), O.exec_type2(oplan, ref1)) < 1e-7
+        del g

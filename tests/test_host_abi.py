@@ -28,7 +28,8 @@ def test_library_exports_every_symbol_in_the_header(nufft):
     raw = C.CDLL(nufft.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert nufft.lib.nufft_version() == 103
+    header_version = int(re.search(r"#define NUFFT_MI355X_VERSION (\d+)", header).group(1))
+    assert nufft.lib.nufft_version() == header_version == 104
     assert b"success" in nufft.lib.nufft_strerror(0)
 
 
@@ -273,3 +274,85 @@ def test_work_item_tables_hold_every_run_a_tile_can_see(nufft, Z, dims, M, kw):
         rows *= -(-i.interp_tile[d] // i.bin_dims[d])
     assert rows <= i.interp_max_items
     assert i.lds_bytes_spread <= 163840 and i.lds_bytes_interp <= 163840
+
+
+def test_params_struct_size_guards_the_trailing_fields(nufft):
+    """ABI 104: the caller states how much of nufft_params it knows; struct_size = 0 is the layout of ABI <= 102, whose
+    callers own a SHORTER struct — the library must ignore (never read) everything from kernel_param_dim on."""
+    L = nufft._lib
+
+    def make(**kw):
+        prm = L.NufftParams()
+        prm.dtype, prm.ndim, prm.device = L.F64, 2, -1
+        prm.N[0], prm.N[1] = 20, 24
+        for k, v in kw.items():
+            setattr(prm, k, v)
+        h = C.c_void_p()
+        rc = nufft.lib.nufft_plan_create_ex(C.byref(h), C.byref(prm))
+        info = L.NufftInfo()
+        if rc == 0:
+            nufft.lib.nufft_plan_info(h, C.byref(info))
+            nufft.lib.nufft_plan_destroy(h)
+        return rc, info
+
+    full = C.sizeof(L.NufftParams)
+    prm_over = (C.c_int64 * 3)(64, 0, 0)
+    rc, info = make(struct_size=full, N_over=prm_over)
+    assert rc == 0 and info.N_over[0] == 64                       # known: honoured
+    rc, info = make(struct_size=0, N_over=prm_over)
+    assert rc == 0 and info.N_over[0] == 40                       # legacy caller: not read (the size rule applies: 2 * nextprod(20))
+    rc, info = make(struct_size=0, N_over=(C.c_int64 * 3)(-7, 0, 0))
+    assert rc == 0                                                # ... not even validated
+    rc, _ = make(struct_size=full, N_over=(C.c_int64 * 3)(-7, 0, 0))
+    assert rc == L.ERR_INVALID_ARG
+    rc, _ = make(struct_size=16)
+    assert rc == L.ERR_INVALID_ARG                                # smaller than any published layout
+    rc, info = make(struct_size=full + 64)                        # a newer caller: the library reads what it knows
+    assert rc == 0 and info.N_over[0] == 40
+
+
+def test_development_switches_travel_in_the_params_not_in_the_environment(nufft, monkeypatch):
+    """the library reads no NUFFT_* environment variable.  A switch set in the process environment does nothing
+    to a plan created through the C ABI; the same switch in nufft_params.options does, and the plan reports it."""
+    L = nufft._lib
+    src = ""
+    csrc = os.path.join(ROOT, "nonuniformffts.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".cpp", ".hip", ".h", ".inc")):
+            src += open(os.path.join(csrc, f)).read()
+    sites = re.findall(r"getenv\s*\(", re.sub(r"//[^\n]*", "", src))
+    assert len(sites) == 1                                        # options.cpp, behind #if NUFFT_ENV_SWITCHES (development builds only)
+    opt = open(os.path.join(csrc, "options.cpp")).read()
+    assert re.search(r"#if defined\(NUFFT_ENV_SWITCHES\) && NUFFT_ENV_SWITCHES\s+const char\* v = std::getenv", opt)
+    assert "NUFFT_ENV_SWITCHES" not in open(os.path.join(csrc, "Makefile")).read()      # the shipped build has it off
+
+    def bins(options, env):
+        if env is not None:
+            monkeypatch.setenv("NUFFT_BIN_LOG2", env)
+        else:
+            monkeypatch.delenv("NUFFT_BIN_LOG2", raising=False)
+        prm = L.NufftParams()
+        prm.struct_size = C.sizeof(L.NufftParams)
+        prm.dtype, prm.ndim, prm.device = L.F64, 3, -1
+        prm.N[0], prm.N[1], prm.N[2] = 32, 32, 32
+        prm.options = options
+        h = C.c_void_p()
+        assert nufft.lib.nufft_plan_create_ex(C.byref(h), C.byref(prm)) == 0
+        info = L.NufftInfo()
+        nufft.lib.nufft_plan_info(h, C.byref(info))
+        text = nufft.lib.nufft_plan_options(h).decode()
+        nufft.lib.nufft_plan_destroy(h)
+        return info.bin_dims[0], text
+
+    assert bins(None, None) == (4, "")
+    assert bins(None, "3") == (4, "")                             # the environment alone: ignored by the library
+    assert bins(b"NUFFT_BIN_LOG2=3", None) == (8, "NUFFT_BIN_LOG2=3")
+    assert bins(b"NUFFT_BIN_LOG2=3;NUFFT_BIN_LOG2=1", "3")[0] == 2      # later entries win
+    # the Python development harness forwards its own environment as that string (and says so), explicit options win
+    monkeypatch.setenv("NUFFT_BIN_LOG2", "3")
+    p = nufft.PlanNUFFT(np.float64, (32, 32, 32), backend=None)
+    assert p.info().bin_dims[0] == 8 and "NUFFT_BIN_LOG2=3" in p.options
+    p = nufft.PlanNUFFT(np.float64, (32, 32, 32), backend=None, options={"NUFFT_BIN_LOG2": 1})
+    assert p.info().bin_dims[0] == 2
+    monkeypatch.setenv("NUFFT_LIB_PATH", nufft.LIB_PATH)          # harness variables are not switches
+    assert "NUFFT_LIB_PATH" not in nufft.PlanNUFFT(np.float64, (32, 32, 32), backend=None).options

@@ -73,7 +73,10 @@ def _header_prototypes():
 
 def _header_enums():
     hdr = _strip_c_comments(open(HEADER).read())
-    return {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(NUFFT_\w+)\s*=\s*(-?\d+)", hdr)}
+    out = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(NUFFT_\w+)\s*=\s*(-?\d+)", hdr)}
+    # ... and the ABI version macro: the shim refuses an older library
+    out.update({m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(NUFFT_MI355X_VERSION)\s+(\d+)", open(HEADER).read())})
+    return out
 
 
 # C type (normalised) -> the Julia types a ccall may legitimately use for it
@@ -106,8 +109,11 @@ def test_every_ccall_matches_its_prototype():
     protos = _header_prototypes()
     calls = _shim_ccalls()
     assert len(calls) >= 7, calls
-    assert {"nufft_plan_create_ex", "nufft_plan_destroy", "nufft_set_points", "nufft_exec_type1_cb", "nufft_exec_type2_cb",
-            "nufft_sizeof_params", "nufft_last_error_message"} <= {c[0] for c in calls}
+    assert {"nufft_plan_create_ex", "nufft_plan_destroy", "nufft_set_points", "nufft_set_callbacks", "nufft_spread_deferred", "nufft_fft_forward",
+            "nufft_deconvolve_truncate", "nufft_deconvolve_pad", "nufft_fft_backward", "nufft_interpolate",
+            "nufft_sizeof_params", "nufft_version", "nufft_last_error_message"} <= {c[0] for c in calls}
+    # a ccall's (symbol, library) pair must be a literal: none through a variable
+    assert not re.search(r"ccall\(\(\s*[a-z]\w*\s*,", open(SHIM).read())
     for name, ret, args in calls:
         assert name in protos, f"{name}: not declared in include/nufft_mi355x.h"
         cret, cargs = protos[name]
@@ -150,7 +156,7 @@ def _julia_struct(name, text=None):
 
 
 _CT = {"int32_t": ("Int32", C.c_int32), "int64_t": ("Int64", C.c_int64), "double": ("Float64", C.c_double),
-       "const void*": ("Ptr{Cvoid}", C.c_void_p)}
+       "const void*": ("Ptr{Cvoid}", C.c_void_p), "const char*": ("Ptr{UInt8}", C.c_char_p)}
 
 
 def _check_struct(cname, jname):
@@ -245,6 +251,21 @@ def test_enum_slots_of_cparams_are_filled_from_constants_only():
             assert b.startswith(fam), f"CParams.{field}: `{b}` is not a {fam}* constant"
     assert byname["spread_method"] == "NUFFT_SPREAD_AUTO"
     assert byname["kernel"].startswith("kernel_id(")
+    # ABI 104: the caller states how much of the struct it knows; no development switches from a Julia process
+    assert byname["struct_size"] == "Int32(sizeof(CParams))" and byname["reserved"] == "Int32(0)" and byname["options"] == "Ptr{UInt8}(C_NULL)"
+    # the host-only probe of BlockDataGPU (plan-time errors at plan time): same struct, every enum slot a constant or a ternary of
+    # constants of the right family, device = -1 (no GPU call), the reference's own Ñs forwarded
+    mp = re.search(r"probe = CParams\(", text)
+    pargs = _split_top(_balanced(text, mp.end() - 1))
+    assert len(pargs) == len(fields), (len(pargs), len(fields))
+    pb = dict(zip(fields, pargs))
+    for field, fam in dict(family, kernel="NUFFT_KERNEL_", spread_method="NUFFT_SPREAD_").items():
+        toks = re.findall(r"NUFFT_\w+", pb[field])
+        assert toks and all(tk.startswith(fam) for tk in toks), (field, pb[field])
+        assert not re.search(r"(?<![\w.])\d+(?![\w.])", re.sub(r"NUFFT_\w+", "", pb[field]).replace("Float64", "")), (field, pb[field])
+    assert pb["device"] == "Int32(-1)" and pb["struct_size"] == "Int32(sizeof(CParams))" and pb["options"] == "Ptr{UInt8}(C_NULL)"
+    assert "Ñs[d]" in pb["N_over"] and pb["half_support"] == "Int32(M)" and pb["ndim"] == "Int32(D)"
+    assert re.search(r"probe_parameters\(Z, Ñs, Val\(M\), method\)", text)
     # the semantic pairing of each ternary: Float64 -> F64, Direct -> DIRECT, identity -> IDENTITY, :shared_memory -> SHARED_MEMORY
     assert re.search(r"dtype = T === Float64 \? NUFFT_F64 : NUFFT_F32", text)
     assert re.search(r"evalmode = p\.kernel_evalmode isa Direct \? NUFFT_EVAL_DIRECT : NUFFT_EVAL_FAST_APPROXIMATION", text)
@@ -523,3 +544,38 @@ def test_integration_md_points_to_the_file_and_walks_the_constructor():
                    "KA.allocate", "BlockDataGPU", "init_plan_data", "output_field", "non_oversampled_indices!",
                    "generate_point_transform_fold_function", "to_unit_cell"):
         assert needle in md, needle
+
+
+@needs_reference
+def test_stage_timer_labels_are_the_references():
+    """exec_type1! / exec_type2! nest the reference's own TimerOutputs labels, in its order, each stage followed by maybe_synchronise(p)
+    (src/NonuniformFFTs.jl:157-186, 246-283): p.timer shows the same tree whichever backend runs (missing 2)."""
+    ref = open(os.path.join(REFERENCE, "src", "NonuniformFFTs.jl")).read()
+    shim = _shim_text()
+
+    def labels(src, fname, first_arg):
+        m = re.search(r"function (?:NonuniformFFTs\.)?%s\(\s*\S+::NTuple" % re.escape(fname), src)      # (the tuple form: the one with the stages)
+        assert m, fname
+        end = re.search(r"\n    \S+\nend\n", src[m.start():])
+        body = src[m.start():m.start() + end.end()]
+        return re.findall(r'@timeit timer "([^"]+)"', body), body
+
+    for fname, first in (("exec_type1!", None), ("exec_type2!", None)):
+        want, _ = labels(ref, fname, first)
+        got, body = labels(shim, fname, first)
+        assert len(want) == 5 and got == want, (fname, got, want)
+        # one stage call and one maybe_synchronise per label below the outer one
+        assert body.count("NonuniformFFTs.maybe_synchronise(p)") == 4, fname
+        assert "set_callbacks(h, cb)" in body and "set_callbacks(h, Ref(no_callbacks))" in body
+    b1 = labels(shim, "exec_type1!", None)[1]
+    assert re.search(r'"\(1\) Spreading" begin\s+spread_deferred\(', b1) and re.search(r'"\(2\) Forward FFT" begin\s+fft_forward\(', b1)
+    assert re.search(r'"\(3\) Deconvolution" begin\s+deconvolve_truncate\(', b1)
+    b2 = labels(shim, "exec_type2!", None)[1]
+    assert re.search(r'"\(1\) Deconvolution" begin\s+deconvolve_pad\(', b2) and re.search(r'"\(2\) Backward FFT" begin\s+fft_backward\(', b2)
+    assert re.search(r'"\(3\) Interpolation" begin\s+interpolate_points\(', b2)
+    # the stage sequence IS nufft_exec_type1 / nufft_exec_type2 (csrc/plan.cpp): nothing is lost by not calling them
+    plan = open(os.path.join(ROOT, "nonuniformffts.jl_amd", "csrc", "plan.cpp")).read()
+    e1 = plan[plan.index("int nufft_exec_type1(nufft_plan* p"):plan.index("// Fused callback menu")]
+    assert re.findall(r"nufft_(\w+)\(p,", e1) == ["spread_deferred", "fft_forward", "deconvolve_truncate"]
+    e2 = plan[plan.index("int nufft_exec_type2(nufft_plan* p"):plan.index("int nufft_grid_ptr(")]
+    assert re.findall(r"nufft_(\w+)\(p,", e2) == ["deconvolve_pad", "fft_backward", "interpolate"]
