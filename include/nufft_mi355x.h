@@ -140,8 +140,12 @@ typedef struct nufft_params {
  *                  multiple of 8 cells — v_mfma_f32_16x16x4 with Float32 accumulators (nufft_info.patch_f32acc)
  *   marching ring — a workgroup owns a column of the grid and marches along dimension 3 with a ring of 2M - 1 + 4 planes in
  *                  LDS (ds_add_f64 as for the tiles, 1.4 - 1.5 point visits per point instead of 2.1, finished planes leave with
- *                  coalesced stores while the ring moves on): 3-D grids of 4-cell bins; the automatic choice for real data, M <= 4 */
-enum { NUFFT_SPREAD_AUTO = 0, NUFFT_SPREAD_LDS_TILES = 1, NUFFT_SPREAD_MFMA_PATCHES = 2, NUFFT_SPREAD_MARCHING_RING = 3 };
+ *                  coalesced stores while the ring moves on): 3-D grids of 4-cell bins; the automatic choice for real data, M <= 4
+ *   marching ring, dense — the same window for dense point sets (mean load of the 4^3-cell bins above a threshold per M, decided per point
+ *                  set by nufft_set_points): the points of a bin are accumulated in registers by v_mfma_f64_16x16x4 and flushed to the
+ *                  window once per bin.  Reported by nufft_spread_engine_used only (never a plan parameter). */
+enum { NUFFT_SPREAD_AUTO = 0, NUFFT_SPREAD_LDS_TILES = 1, NUFFT_SPREAD_MFMA_PATCHES = 2, NUFFT_SPREAD_MARCHING_RING = 3,
+       NUFFT_SPREAD_MARCHING_RING_DENSE = 4 };
 
 typedef struct nufft_info {
     int32_t dtype, is_complex, ndim, half_support, ntransforms, evalmode, fftshift, device;

@@ -114,10 +114,10 @@ bool spread_cubes_available(int dtype, int is_complex, int D, int M);
 bool interp_march_available(int dtype, int is_complex, int D, int M, bool poly, const Geom& g, bool other);
 hipError_t prepare_interp_march(int dtype, int is_complex, int M, bool poly);
 // ... its variant for column-layer sorted point sets (same columns and tasks)
-bool interp_march_staged_available(int dtype, int is_complex, int M, bool poly);
+bool interp_march_staged_available(int dtype, int is_complex, int M, bool poly, int n1, int n2);
 hipError_t prepare_interp_march_staged(int dtype, int is_complex, int M, bool poly);
 // columns (the kernel's compile-time column) and evenly cut tasks of the ring for this grid
-ColumnTasks march_column_tasks(int dtype, int is_complex, int M, bool poly, const Geom& g);
+ColumnTasks march_column_tasks(int dtype, int is_complex, int M, bool poly, const Geom& g, int n1 = 0, int n2 = 0);
 hipError_t launch_spread(const TileKernelArgs& a, hipStream_t stream);
 hipError_t launch_interp(const TileKernelArgs& a, hipStream_t stream);
 // Sets the dynamic-LDS attribute of every instantiation that may be launched for this configuration.
@@ -167,7 +167,9 @@ hipError_t launch_gather_values(int dtype, int is_complex, int D, const void* so
 SMarchPlan smarch_plan(int dtype, int is_complex, int D, int M, const Geom& g, bool other, int cus, int C, int halo, int parts = 1);
 hipError_t prepare_spread_march(int dtype, int is_complex, int M, int halo);
 // flag: device flag of set_points (1: the ring serves this point set); tasktab: its task table
-hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, hipStream_t stream);
+hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, bool dense, hipStream_t stream);
+bool spread_dense_available(int dtype, int is_complex, int M, bool poly, const SMarchPlan& sp);
+hipError_t prepare_spread_dense(int dtype, int M, bool poly);
 // halo variant: grid += side buffer (a.halo); the dimension-1 FFT pass of real plans does the same while it loads its lines (launch_real_lines)
 hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, hipStream_t stream);
 // set_points: tasks of the ring for this point set and whether it serves it (advantage <= 0: always)

@@ -19,12 +19,12 @@ static void march_entry(bool poly, const void** fn, int* lds_bytes, int* n) {
     else march_entry_p<M, false>(fn, lds_bytes, n);
 }
 
-// staged variant (column-layer sorted point sets): real data, the half-supports the spreading window's halo variant serves
+// staged variant (column-layer sorted point sets): every element type, the half-supports the spreading window's halo variant serves.
+// Its compile-time column (the largest that fits beside the stage) bounds the column the plan may give both rings (plan.cpp).
 template <int M, bool POLY>
 static void march_staged_entry_p(const void** fn, int* lds_bytes, int* n) {
     using C = MarchCfg<NUFFT_T, NUFFT_CPLX, M, POLY, true>;
-    using C0 = MarchCfg<NUFFT_T, NUFFT_CPLX, M, POLY>;      // same columns and tasks as the plain kernel, or no staged variant
-    if constexpr (C::FITS_STAGED && !NUFFT_CPLX && M <= 7 && C::N1 == C0::N1 && C::N2 == C0::N2) {
+    if constexpr (C::FITS_STAGED && M <= 7) {
         *fn = reinterpret_cast<const void*>(&interp_march_staged_kernel<NUFFT_T, NUFFT_CPLX, M, POLY>);
         *lds_bytes = C::staged_lds_bytes();
         n[0] = C::N1; n[1] = C::N2; n[2] = C::kSegMax; n[3] = C::THREADS;

@@ -82,7 +82,13 @@ struct MarchCfg {
 #ifndef NUFFT_STAGED_POLY_THREADS
 #define NUFFT_STAGED_POLY_THREADS 768
 #endif
-        if (STG && POLY && sizeof(T) == 8) return NUFFT_STAGED_POLY_THREADS;
+        if (STG && POLY && sizeof(T) == 8) return (!CPLX && M >= 6) ? 512 : NUFFT_STAGED_POLY_THREADS;      // (m = 6, 7: 15 / 9 registers spilled at 12 waves)
+        // round 6, the staged kernel for every (T, M): where it spilled at 16 waves (hipcc -S: Float64 Direct() m = 3, 6, 7: 15 / 17 / 6 registers;
+        // Float32 m <= 3: 6 - 36, m = 6 polynomial: 10; ComplexF32 m <= 3: 21 - 38, m = 4 / 6 polynomial: 10 / 16) it is slower than the plain ring
+        // (interpolation 256^3 -> 512^3, Np = 1e7: Float32 m = 2 polynomial 0.97 against 0.55 ms, Float64 m = 3 Direct() 1.64 against 1.42) — 12 waves there
+        if (STG && sizeof(T) == 8 && !POLY) return (M == 3 || M >= 6) ? 768 : 1024;
+        if (STG && sizeof(T) == 4 && !CPLX) return (M <= 3 || (POLY && M == 6)) ? 768 : 1024;
+        if (STG && sizeof(T) == 4 && CPLX) return (M <= 3 || (POLY && (M == 4 || M == 6))) ? 768 : 1024;
         if (!POLY) return 1024;                                 // Direct(): no spills at 128 registers in any instantiation
         if (sizeof(T) == 8) return M <= (CPLX ? 6 : 5) ? 1024 : 512;
         return 1024;                                            // Float32, ComplexF32 (m = 8: with row groups of 4, below)
@@ -135,9 +141,13 @@ struct MarchCfg {
     static constexpr int row_stride_of(int n1) { return (NUFFT_MARCH_RS_PAD) ? padded_row_stride(NC * (n1 + HALO), NC * L, (int)sizeof(T)) : NC * (n1 + HALO); }
     static constexpr int strip_bytes() { return REGW ? 0 : round_up(GP::PPW * 3 * L * (int)sizeof(T), 16); }   // (REGW = false: ZP = 1)
     // [runs of the segment: layer x row][passes of the longest run per layer][pass counter, flag]
-    static constexpr int table_bytes(int segl) { return round_up(kMarchMaxRows * segl * 8 + segl * 4 + 64, 16); }
+    // (staged kernel: a layer of the column is ONE run — one row per layer)
+    static constexpr int RUN_ROWS = STG ? 1 : kMarchMaxRows;
+    static constexpr int table_bytes(int segl) { return round_up(RUN_ROWS * segl * 8 + segl * 4 + 64, 16); }
     static constexpr int kSegMax = 64;
-    static constexpr int fixed_bytes_for(int threads) { return table_bytes(kSegMax) + threads / kWave * strip_bytes() + 64; }
+    // staged kernel: the stage of the next chunk's records (16 bytes per thread), two sets of 64 bin counters
+    static constexpr int staged_extra_for(int threads) { return STG ? 16 * threads + 2 * 64 * 4 + 64 : 0; }
+    static constexpr int fixed_bytes_for(int threads) { return table_bytes(kSegMax) + threads / kWave * strip_bytes() + 64 + staged_extra_for(threads); }
     // column interior (n1, n2): multiples of the bin edge, minimal halo amplification within the LDS budget
     struct Dims { int n1, n2; };
     static constexpr Dims search(int threads) {
@@ -187,9 +197,11 @@ struct MarchCfg {
         return for_y ? sy : sx;
     }
     static constexpr int KSX = key_shift(NBX, NBY, false), KSY = key_shift(NBX, NBY, true), KNX = (NBX + (1 << KSX) - 1) >> KSX;
-    static constexpr int staged_extra_bytes() { return STAGE_BYTES + 2 * 64 * 4 + 64; }
-    static constexpr int staged_lds_bytes() { return lds_bytes() + staged_extra_bytes(); }
-    static constexpr bool FITS_STAGED = FITS && staged_lds_bytes() <= 163840 - 256 && (REC_BYTES % 16 == 0);
+    // (STG: the column search above has left room for the stage and the counters; they sit behind the strips)
+    static constexpr int staged_extra_bytes() { return staged_extra_for(THREADS); }
+    static constexpr int staged_lds_bytes() { return lds_bytes(); }
+    static constexpr int stage_offset() { return lds_bytes() - staged_extra_bytes(); }
+    static constexpr bool FITS_STAGED = STG && FITS && staged_lds_bytes() <= 163840 - 256 && (REC_BYTES % 16 == 0);
 };
 
 // A task is a column and a segment of its bin layers (at most kSegMax) from set_points' table: segments of about equal
@@ -230,7 +242,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_
             item = __builtin_amdgcn_readfirstlane(item);
             if (item >= nitems) break;
             const int rl = item % nrl, kl = rl / nrows;
-            const uint2 pr = runs[(lay0 + kl) * kMarchMaxRows + rl % nrows];
+            const uint2 pr = runs[(lay0 + kl) * C::RUN_ROWS + rl % nrows];
             const uint32_t p0 = pr.x + (uint32_t)(item / nrl) * PPW, p1 = pr.y;
             if (p0 >= p1) continue;
             const uint32_t p = p0 + grp;
@@ -272,14 +284,14 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY, true>::THREADS)) void i
     int pm = 0;                                         // (BZ * layer) mod RZ: slot of the first plane of the window
     constexpr int PIECES = C::PIECES, SREC = C::STAGE_RECS;
     typedef uint32_t U4 __attribute__((ext_vector_type(4)));
-    unsigned char* stage = smem + C::lds_bytes();
+    unsigned char* stage = smem + C::stage_offset();
     uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + C::STAGE_BYTES);        // [2][64]
     const PointRec<T, 3>* staged = reinterpret_cast<const PointRec<T, 3>*>(stage);
     const int myrec = tid / PIECES, mysub = tid % PIECES;
     // (run bounds through readfirstlane: uniform values in scalar registers — as vector registers they cost this kernel, which sits
     // at the 128-register limit of 16 waves per CU, spills in the serial section between the two barriers of a chunk)
     auto run_of = [&](int lay, int& r0, int& n) __attribute__((always_inline)) {
-        const uint2 pr = runs[lay * kMarchMaxRows];
+        const uint2 pr = runs[lay * C::RUN_ROWS];
         r0 = __builtin_amdgcn_readfirstlane((int)pr.x);
         n = __builtin_amdgcn_readfirstlane((int)(pr.y - pr.x));
     };

@@ -169,6 +169,7 @@ struct nufft_plan {
     // bin sort
     int64_t Np = -1;
     int64_t Np_capacity = 0;
+    int64_t binrank_capacity = 0;      // bytes of d_binrank (sized per point set: see nufft_set_points)
     uint32_t* d_counts = nullptr;      // [ntiles + 1]  histogram
     bool counts_clean = false;         // d_counts is all zero (plan creation; every completed set_points leaves it so)
     uint32_t* d_offsets = nullptr;     // [ntiles + 1]  exclusive scan
@@ -176,6 +177,10 @@ struct nufft_plan {
                                        // the slab height chosen per point set (nufft_set_points)
     int slab_fill = 85;                // a slab's average load, percent of what a level-2 workgroup holds, at most (NUFFT_SLAB_FILL)
     int64_t slab_min_points = 0;       // smaller point sets take the fine sort with global atomics (NUFFT_SLAB_MIN_POINTS)
+    bool dense_available = false;      // the spreading window's dense-set engine exists for this plan (dmarch_kernels.h)
+    bool dense_now = false;            // ... and serves the current point set (set_points: mean bin load >= dense_min)
+    int dense_min = 1 << 30;
+    int sort_column_pred[2] = {0, 0};  // host-only plans: the column-layer sort a device plan of these parameters would take (predict_sort_column)
     int slab_max_keys = 0;             // keys the level-1 table was allocated for: min(kCoarseMaxKeys, nb[1] * nb[2])
     nufft::CoarseSort coarse{};        // column-layer sort (binsort.hip): enabled on plans whose two rings own the same columns; table allocated
     void* d_binrank = nullptr;         // uint2[Np]: (tile, rank)

@@ -174,6 +174,8 @@ static int ring_max_half_support(const nufft_plan* p) {
     return p->dtype == NUFFT_F64 ? 4 : 3;
 }
 
+static void predict_sort_column(nufft_plan* p);
+
 static int build_host(nufft_plan* p, const nufft_params* in) {
     p->opts.parse(in->options);
     set_current_options(&p->opts);
@@ -432,7 +434,62 @@ static int build_host(nufft_plan* p, const nufft_params* in) {
         if (p->smarch.eligible && (req == NUFFT_SPREAD_MARCHING_RING || (req == NUFFT_SPREAD_AUTO && prefer_ring)))
             p->spread_method = NUFFT_SPREAD_MARCHING_RING;
     }
+    if (p->device < 0) predict_sort_column(p);
     return NUFFT_OK;
+}
+
+// Column-layer sort: ONE column for both rings — the spreading window's (chosen for this grid by its launch model, smarch_plan); the
+// interpolation ring takes it wherever its kernels can hold it (a column <= their compile-time one: march_setup.inc).  Round 6; before,
+// only plans whose two rings happened to pick the same column qualified (Float64 / ComplexF64 m = 4).  `sm`: the window's final plan
+// (halo variant), p->interp_parts decided.  Pure host arithmetic: also what the prediction for host-only plans runs (predict_sort_column).
+static bool shared_ring_column(const nufft_plan* p, const SMarchPlan& sm, ColumnTasks* shared) {
+    if (!sm.eligible || sm.halo != 2 || p->D != 3) return false;
+    const int nkeys = sm.ct.ncolx * sm.ct.ncoly * p->tile.nb[2];
+    const int mcplx = p->interp_parts == 2 ? 0 : (int)p->is_complex;
+    const bool poly = p->evalmode != NUFFT_EVAL_DIRECT;
+    if (p->Nover[0] % sm.n1 != 0 || p->Nover[1] % sm.n2 != 0 || nkeys > kCoarseMaxKeys) return false;
+    if (!interp_march_staged_available(p->dtype, mcplx, p->M, poly, sm.n1, sm.n2)) return false;
+    const ColumnTasks ct = march_column_tasks(p->dtype, mcplx, p->M, poly, make_geom(p), sm.n1, sm.n2);
+    if (ct.ntasks <= 0 || ct.ncolx != sm.ct.ncolx || ct.ncoly != sm.ct.ncoly || (size_t)ct.ncolx * ct.ncoly >= 65536 || p->tile.nb[2] > 2048) return false;
+    *shared = ct;
+    return true;
+}
+
+// interpolation ring: which form (complex data part by part through the real kernels?) and whether it exists for this plan — host arithmetic
+static bool choose_interp_ring(nufft_plan* p) {
+    p->interp_march_mode = env_int("NUFFT_INTERP_MARCH", 1);
+    // ComplexF64 part by part through the REAL ring kernels (march_setup.inc, MarchGeom::parts = 2): the complex instantiation reads 128-bit pairs
+    // from LDS at a quarter of the rate (scripts/microbench7.hip) and owns a narrower column — two passes of the real kernel are faster from
+    // m = 4 on (interpolation stage 256^3 -> 512^3, Np = 1e7: 2.76 against 2 x 1.2 ms; m = 8: 20.4 against 2 x 5.8), and the plan can then share
+    // its columns with the spreading window (column-layer sort).  ComplexF32 keeps its paired-lane kernel (1.25 ms against 2 x 1.08).
+    // NUFFT_INTERP_SPLIT=0: the complex instantiations (A/B runs, tests)
+    p->interp_parts = (p->is_complex && p->dtype == NUFFT_F64 && env_int("NUFFT_INTERP_SPLIT", 1) != 0) ? 2 : 1;
+    const bool other = needs_other_eval(p->kernel, p->evalmode), poly = p->evalmode != NUFFT_EVAL_DIRECT;
+    bool ok = p->interp_march_mode != 0 && interp_march_available(p->dtype, p->interp_parts == 2 ? 0 : (int)p->is_complex, p->D, p->M, poly, make_geom(p), other);
+    if (!ok && p->interp_parts == 2) {
+        p->interp_parts = 1;
+        ok = p->interp_march_mode != 0 && interp_march_available(p->dtype, p->is_complex, p->D, p->M, poly, make_geom(p), other);
+    }
+    return ok;
+}
+
+// What a device plan of these parameters would report as nufft_info.sort_column on a 256-CU device whose side buffer can be allocated:
+// the decisions of build_device that need no device, in its order.  Host-only plans report it (tests compute a GPU test's eligibility here).
+static void predict_sort_column(nufft_plan* p) {
+    p->sort_column_pred[0] = p->sort_column_pred[1] = 0;
+    if (p->D != 3 || p->spread_method != NUFFT_SPREAD_MARCHING_RING || env_int("NUFFT_COARSE_SORT", 1) == 0) return;
+    bool pruned = env_int("NUFFT_PRUNED_FFT", 1) != 0;
+    for (int d = p->is_complex ? 0 : 1; d < p->D && pruned; ++d) pruned = fft_lines_supported(p->dtype, p->Nover[d]);
+    const bool compact = pruned && (p->is_complex || (real_lines_supported(p->dtype, p->Nover[0]) && env_int("NUFFT_COMPACT_DIM1", 1) != 0));
+    int want_halo = p->smarch.halo;
+    if (want_halo == 2 && !(pruned && compact) && env_int("NUFFT_SMARCH_HALO", 0) != 2) want_halo = 0;
+    if (want_halo != 2) return;
+    SMarchPlan sm = smarch_plan(p->dtype, p->is_complex, p->D, p->M, make_geom(p), needs_other_eval(p->kernel, p->evalmode), 256, p->C, want_halo, p->smarch_parts);
+    if (!sm.eligible || sm.halo != 2) return;
+    const int save_parts = p->interp_parts, save_mode = p->interp_march_mode;
+    ColumnTasks shared{};
+    if (choose_interp_ring(p) && shared_ring_column(p, sm, &shared)) { p->sort_column_pred[0] = shared.bxw; p->sort_column_pred[1] = shared.byw; }
+    p->interp_parts = save_parts; p->interp_march_mode = save_mode;
 }
 
 static int build_device(nufft_plan* p) {
@@ -626,23 +683,10 @@ static int build_device(nufft_plan* p) {
     // the two kernels gathers a point set is decided on the device at set_points (heaviest ring task and total work against the
     // ring's fitted advantage over the tile kernel: balance.hip, d_march_choice[2]); the mode is latched here —
     // NUFFT_INTERP_MARCH = 0: never the ring (A/B runs), 2: always (tests of its instantiations on small grids)
-    p->interp_march_mode = env_int("NUFFT_INTERP_MARCH", 1);
     p->debug_tasks = env_int("NUFFT_DEBUG_TASKS", 0) != 0;
     p->halo_fuse = env_int("NUFFT_SMARCH_HALO_FUSE", 1) != 0;
-    // ComplexF64 part by part through the REAL ring kernels (march_setup.inc, MarchGeom::parts = 2): the complex instantiation reads 128-bit pairs
-    // from LDS at a quarter of the rate (scripts/microbench7.hip) and owns a narrower column — two passes of the real kernel are faster from
-    // m = 4 on (interpolation stage 256^3 -> 512^3, Np = 1e7: 2.76 against 2 x 1.2 ms; m = 8: 20.4 against 2 x 5.8), and the plan can then share
-    // its columns with the spreading window (column-layer sort).  ComplexF32 keeps its paired-lane kernel (1.25 ms against 2 x 1.08).
-    // NUFFT_INTERP_SPLIT=0: the complex instantiations (A/B runs, tests)
-    p->interp_parts = (p->is_complex && p->dtype == NUFFT_F64 && env_int("NUFFT_INTERP_SPLIT", 1) != 0) ? 2 : 1;
+    p->interp_march = choose_interp_ring(p);
     auto march_cplx = [&]() { return p->interp_parts == 2 ? 0 : (int)p->is_complex; };
-    p->interp_march = p->interp_march_mode != 0 &&
-                      interp_march_available(p->dtype, march_cplx(), D, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
-    if (!p->interp_march && p->interp_parts == 2) {
-        p->interp_parts = 1;
-        p->interp_march = p->interp_march_mode != 0 &&
-                          interp_march_available(p->dtype, p->is_complex, D, p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p), needs_other_eval(p->kernel, p->evalmode));
-    }
     if (p->interp_march) {
         NUFFT_HIP(prepare_interp_march(p->dtype, march_cplx(), p->M, p->evalmode != NUFFT_EVAL_DIRECT));
         p->march_ct = march_column_tasks(p->dtype, march_cplx(), p->M, p->evalmode != NUFFT_EVAL_DIRECT, make_geom(p));
@@ -713,12 +757,19 @@ static int build_device(nufft_plan* p) {
     // into LDS.  Per point set: only while both rings serve it (device flags); NUFFT_COARSE_SORT=0 keeps the fine sort (A/B runs).
     p->coarse = CoarseSort{};
     if (p->spread_method == NUFFT_SPREAD_MARCHING_RING && p->smarch.halo == 2 && p->interp_march && D == 3 && env_int("NUFFT_COARSE_SORT", 1) != 0) {
-        const ColumnTasks &sc = p->smarch.ct, &mc = p->march_ct;
-        const int nkeys = sc.ncolx * sc.ncoly * p->tile.nb[2];
-        const bool same = sc.ncolx == mc.ncolx && sc.ncoly == mc.ncoly && p->smarch.n1 == 4 * mc.bxw && p->smarch.n2 == 4 * mc.byw &&
-                          p->Nover[0] % p->smarch.n1 == 0 && p->Nover[1] % p->smarch.n2 == 0;
+        ColumnTasks shared{};
+        const bool same = shared_ring_column(p, p->smarch, &shared);
+        const int nkeys = p->smarch.ct.ncolx * p->smarch.ct.ncoly * p->tile.nb[2];
         const int mcplx = p->interp_parts == 2 ? 0 : (int)p->is_complex;
-        if (same && nkeys <= kCoarseMaxKeys && interp_march_staged_available(p->dtype, mcplx, p->M, p->evalmode != NUFFT_EVAL_DIRECT)) {
+        if (same) {
+            // the ring's task tables for the shared column (they were sized for the ring's own column above)
+            p->march_ct = shared;
+            const ColumnTasks& mc = p->march_ct;
+            const size_t ncols = (size_t)mc.ncolx * mc.ncoly;
+            dev_free(p, p->d_march_cols);
+            dev_free(p, p->d_march_tasks);
+            if ((rc = dev_alloc(p, reinterpret_cast<void**>(&p->d_march_cols), (2 * ncols + 2) * sizeof(uint32_t)))) return rc;
+            if ((rc = dev_alloc(p, &p->d_march_tasks, (size_t)column_task_table_entries(mc, p->tile.nb[2]) * 8))) return rc;
             p->coarse.enabled = 1;
             p->coarse.cbx = mc.bxw; p->coarse.cby = mc.byw; p->coarse.ncx = mc.ncolx; p->coarse.ncy = mc.ncoly;
             p->coarse.nkeys = nkeys;
@@ -731,9 +782,19 @@ static int build_device(nufft_plan* p) {
         }
     }
 
+    // Dense-set engine of the spreading window (dmarch_kernels.h): the points of a bin accumulated in registers by the FP64 matrix pipe, one flush
+    // per bin.  Taken per point set from the mean bin load (set_points: dense_now); it needs the fine-bin order, so on plans of the
+    // column-layer sort a dense point set takes the slab sort below.  NUFFT_DENSE=0: never; NUFFT_DENSE_MIN: the threshold (points per bin).
+    p->dense_available = p->spread_method == NUFFT_SPREAD_MARCHING_RING && env_int("NUFFT_DENSE", 1) != 0 && !needs_other_eval(p->kernel, p->evalmode) &&
+                         spread_dense_available(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT, p->smarch);
+    if (p->dense_available) NUFFT_HIP(prepare_spread_dense(p->dtype, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
+    // break-even of the matrix pipe + one flush per bin against the stream of atomics, points per bin (measured: profiles/round6_*dense*)
+    static const int dense_min_default[7] = {0, 0, 16, 14, 10, 4, 2};
+    p->dense_min = env_int("NUFFT_DENSE_MIN", p->M <= 6 ? dense_min_default[p->M] : 1 << 30);
+
     // every other 3-D plan: two-level slab sort (column_tasks.h) — the sorted array and offsets of the fine sort, without global atomics
     p->slab = CoarseSort{};
-    if (D == 3 && !p->coarse.enabled && env_int("NUFFT_SLAB_SORT", 1) != 0 && p->tile.nb[0] <= kSlabMaxBins && p->tile.nb[2] <= kCoarseMaxKeys) {
+    if (D == 3 && (!p->coarse.enabled || p->dense_available) && env_int("NUFFT_SLAB_SORT", 1) != 0 && p->tile.nb[0] <= kSlabMaxBins && p->tile.nb[2] <= kCoarseMaxKeys) {
         p->slab.enabled = 1;
         p->slab.mode = 2;
         p->slab_min_points = env_int("NUFFT_SLAB_MIN_POINTS", 16384);
@@ -824,7 +885,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
     a.march = interp && p->interp_march;      // (the ring applies per-point weights itself)
     a.interp_parts = p->interp_parts;
-    a.coarse = p->coarse.enabled;
+    a.coarse = p->coarse.enabled && !p->dense_now;      // (a dense point set of a column-layer plan was sorted by fine bins: the plain ring gathers it)
     a.coarse_a = p->coarse.flag_a;
     a.coarse_b = p->coarse.flag_b;
     a.march_ct = p->march_ct;
@@ -1206,8 +1267,9 @@ int nufft_plan_info(const nufft_plan* p, nufft_info* o) {
     o->ring_column[1] = ring ? p->smarch.n2 : 0;
     o->ring_segments = ring ? p->smarch.ct.nseg : 0;
     o->ring_halo = (ring && p->smarch.halo == 2) ? 1 : 0;
-    o->sort_column[0] = p->coarse.enabled ? p->coarse.cbx : 0;
-    o->sort_column[1] = p->coarse.enabled ? p->coarse.cby : 0;
+    // (host-only plans: what a device plan of these parameters would report — predict_sort_column)
+    o->sort_column[0] = p->device < 0 ? p->sort_column_pred[0] : (p->coarse.enabled ? p->coarse.cbx : 0);
+    o->sort_column[1] = p->device < 0 ? p->sort_column_pred[1] : (p->coarse.enabled ? p->coarse.cby : 0);
     return NUFFT_OK;
 }
 
@@ -1234,8 +1296,9 @@ int nufft_plan_get_index_map(const nufft_plan* p, int dim, int64_t* out, int64_t
 
 // bytes per point of the {bin, rank} array of the fine sort; plans of the slab sort keep the records of its level 1 in the same allocation
 // (a point set takes one sort or the other)
-static int64_t binrank_bytes(const nufft_plan* p) {
-    return p->slab.enabled ? std::max<int64_t>(8, (int64_t)point_record_bytes(p->dtype, p->D)) : 8;
+// (plans of the column-layer sort use neither unless a point set is clustered — the fine sort, 8 bytes — or dense — the slab sort, a record)
+static int64_t binrank_bytes(const nufft_plan* p, bool slab_sort) {
+    return slab_sort ? std::max<int64_t>(8, (int64_t)point_record_bytes(p->dtype, p->D)) : 8;
 }
 
 int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void* stream_) {
@@ -1252,14 +1315,26 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     if (np > p->Np_capacity) {
         // resize_no_copy!, src/blocking/blocking.jl:55-61 (old contents are discarded).  hipFree / hipMalloc are not
         // capturable: pre-size the plan with the largest point set before capturing set_points in a hipGraph.
-        dev_free(p, p->d_binrank);
         dev_free(p, p->d_sorted);
         dev_free(p, p->d_vsorted);
         p->Np_capacity = 0;
         if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES && (rc = dev_alloc(p, &p->d_vsorted, (size_t)np * value_bytes(p) * p->C, "vsorted"))) return rc;
-        if ((rc = dev_alloc(p, &p->d_binrank, (size_t)np * binrank_bytes(p), "sort_scratch"))) return rc;
         if ((rc = dev_alloc(p, &p->d_sorted, (size_t)np * point_record_bytes(p->dtype, p->D), "sorted"))) return rc;
         p->Np_capacity = np;
+    }
+    // dense point set (mean load of the 4^3-cell bins): the matrix-pipe engine serves it where the ring does, from the fine-bin order
+    p->dense_now = p->dense_available && np >= (int64_t)p->dense_min * p->tile.nbins;
+    {
+        // scratch of the sort this point set takes: {bin, rank} of the fine sort (8 bytes per point; also what a clustered set of a
+        // column-layer plan falls back to, decided on the device), or the level-1 records of the slab sort
+        const bool slab_scratch = p->slab.enabled && (!p->coarse.enabled || p->dense_now);
+        const int64_t need = np * binrank_bytes(p, slab_scratch);
+        if (need > p->binrank_capacity) {
+            dev_free(p, p->d_binrank);
+            p->binrank_capacity = 0;
+            if ((rc = dev_alloc(p, &p->d_binrank, (size_t)need, "sort_scratch"))) return rc;
+            p->binrank_capacity = need;
+        }
     }
     note_capture(p, stream);
     p->halo_hint = false;              // a deferred spread of the previous point set that was never consumed is void (the ring's task kernel
@@ -1281,9 +1356,10 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     s.scan_tmp = p->d_scan_tmp;
     s.scan_tmp_bytes = p->scan_tmp_bytes;
     s.cs = p->coarse;
-    const bool coarse = p->coarse.enabled != 0;
+    const bool coarse = p->coarse.enabled != 0 && !p->dense_now;
+    if (p->coarse.enabled && !coarse) s.cs = CoarseSort{};
     bool slab = false;
-    if (p->slab.enabled && np >= std::max<int64_t>(p->slab_min_points, 1)) {
+    if (!coarse && p->slab.enabled && np >= std::max<int64_t>(p->slab_min_points, 1)) {
         // slab height for this point set: the tallest slab (longest runs in level 1: C3 `set_points` 5.2 ms with 32 768 slabs, 4.4 ms with 16 384)
         // whose average load is at most 85 % of what a level-2 workgroup can hold (fuller slabs take its two-pass form), while there are
         // slabs enough to fill the chip
@@ -1462,6 +1538,7 @@ int nufft_spread_engine_used(nufft_plan* p, int* engine_out, void* stream_) {
     NUFFT_HIP(hipMemcpyAsync(&flag, src + 2, sizeof(flag), hipMemcpyDeviceToHost, stream));
     NUFFT_HIP(hipStreamSynchronize(stream));
     *engine_out = flag ? p->spread_method : NUFFT_SPREAD_LDS_TILES;
+    if (flag && p->spread_method == NUFFT_SPREAD_MARCHING_RING && p->dense_now) *engine_out = NUFFT_SPREAD_MARCHING_RING_DENSE;
     return NUFFT_OK;
 }
 
@@ -1474,7 +1551,7 @@ int nufft_sort_columns_used(nufft_plan* p, int* used_out, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t fa = 0, fb = 0;
-    if (p->slab.enabled) {
+    if (p->slab.enabled && (!p->coarse.enabled || p->dense_now)) {
         NUFFT_HIP(hipMemcpyAsync(&fa, p->slab.flag_a, sizeof(fa), hipMemcpyDeviceToHost, stream));
         NUFFT_HIP(hipStreamSynchronize(stream));
         *used_out = fa != 0 ? 2 : 0;
@@ -1538,7 +1615,7 @@ static int spread_impl(nufft_plan* p, const void* const* values_in, void* stream
     NUFFT_HIP(launch_spread(a, stream));
     if (p->spread_method == NUFFT_SPREAD_MARCHING_RING) {
         // (halo variant: the kernel sets the device word "side buffer pending")
-        NUFFT_HIP(launch_spread_march(a, p->smarch, p->d_smarch_choice + 2, static_cast<const uint2*>(p->d_smarch_tasks), p->d_smarch_choice + kHaloStateWord, stream));
+        NUFFT_HIP(launch_spread_march(a, p->smarch, p->d_smarch_choice + 2, static_cast<const uint2*>(p->d_smarch_tasks), p->d_smarch_choice + kHaloStateWord, p->dense_now, stream));
         // halo variant: the grid is complete once the side buffer has been added — here, or by the first FFT pass
         if (halo_plan(p)) {
             p->halo_hint = true;

@@ -564,74 +564,7 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
 #if NUFFT_SMARCH_ABL != 5
         __syncthreads();
 
-        // ---- retire + shift: the 4 lowest planes of the window are complete — store the owned ones; the other 2M - 1 move
-        //      down four slots, the top four are zeroed.  One thread per pair of reals of a plane, all RZ planes of that
-        //      position (no thread touches another's positions: no hazard inside the pass) ----
-        {
-            typedef double D2 __attribute__((ext_vector_type(2)));
-            typedef T T2 __attribute__((ext_vector_type(2)));
-            const int rp = (NC * wnx + 1) / 2;          // pairs per row of the window (an odd last real pairs with a padding zero)
-#if NUFFT_SMARCH_ABL == 7
-            const int npair = 0;
-#else
-            const int npair = wny * rp;
-#endif
-            for (int e = tid; e < npair; e += THREADS) {
-                const int r = e / rp, xp = e - r * rp;
-                D2* pos = reinterpret_cast<D2*>(ring + r * RS + 2 * xp);
-                // the four finished planes leave first, then the others move down (fewer values live at a time)
-                {
-                    D2 v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = pos[k * (PS / 2)];
-#if NUFFT_SMARCH_ABL != 3
-                    // where the pair goes: the column's own cells into the grid; the halo variant's reach into the column's
-                    // record of the side buffer (the consumer of the grid adds it to the neighbours' cells)
-                    const int lx = 2 * xp / NC - C::XLO, ly = r - C::YLO;          // relative to the column's first cell
-                    T* dst0;
-                    int64_t pstride;                                               // reals between consecutive planes
-                    bool to_grid = true;
-                    if ((HX || HY) && (lx < 0 || lx >= neff1 || ly < 0 || ly >= neff2)) {
-                        // (one planar side buffer per component, or per (component, part) for split complex data)
-                        dst0 = static_cast<T*>(mg.halo) + (int64_t)yrow * mg.halo_comp + (int64_t)(4 * zb0) * hl.plane +
-                               ((int64_t)ty * mg.ntx + tx) * hl.rec + halo_record_offset(hl, 2 * xp, ly);
-                        pstride = hl.plane;
-                        to_grid = false;
-                    } else {
-                        const int gx = wrap_index(org1 + lx, g.Nover[0]), gy = wrap_index(org2 + ly, g.Nover[1]);
-                        pstride = (int64_t)g.Nover[1] * g.Nover[0] * (NC * vgs);
-                        dst0 = grid + (int64_t)(4 * zb0) * pstride + (((int64_t)gy * g.Nover[0] + gx) * NC + (2 * xp) % NC) * vgs;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int qq = wq + k;
-                        if (qq >= 0 && qq < nq) {       // (plane 4 zb0 + qq < Nover[2]: the task owns it)
-                            T* d = dst0 + (int64_t)qq * pstride;
-                            if (split && to_grid) { d[0] = (T)v[k].x; d[2] = (T)v[k].y; }      // this part of two neighbouring complex cells
-                            else *reinterpret_cast<T2*>(d) = T2{(T)v[k].x, (T)v[k].y};
-                        }
-                    }
-#else
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(v[k]));
-#endif
-                }
-#if NUFFT_SMARCH_ABL != 4
-                {
-                    D2 v[RZ - 4];
-#pragma unroll
-                    for (int k = 0; k < RZ - 4; ++k) v[k] = pos[(k + 4) * (PS / 2)];
-#pragma unroll
-                    for (int k = 0; k < RZ - 4; ++k) pos[k * (PS / 2)] = v[k];
-                }
-#pragma unroll
-                for (int k = RZ - 4; k < RZ; ++k) pos[k * (PS / 2)] = D2{0.0, 0.0};
-#else
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pos[k * (PS / 2)] = D2{0.0, 0.0};
-#endif
-            }
-        }
+#include "smarch_retire.inc"
         __syncthreads();
 #endif
     }

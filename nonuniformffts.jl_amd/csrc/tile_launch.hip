@@ -31,9 +31,10 @@ static const void* march_staged_kernel(int dtype, int is_complex, int M, bool po
     if (dtype == NUFFT_F32) return is_complex ? march_kernel_f32c_staged(M, poly, lds_bytes, n) : march_kernel_f32r_staged(M, poly, lds_bytes, n);
     return is_complex ? march_kernel_f64c_staged(M, poly, lds_bytes, n) : march_kernel_f64r_staged(M, poly, lds_bytes, n);
 }
-bool interp_march_staged_available(int dtype, int is_complex, int M, bool poly) {
+// is there a staged instantiation, and does its compile-time column hold a column of n1 x n2 cells?
+bool interp_march_staged_available(int dtype, int is_complex, int M, bool poly, int n1, int n2) {
     int lds = 0, n[4];
-    return march_staged_kernel(dtype, is_complex, M, poly, &lds, n) != nullptr;
+    return march_staged_kernel(dtype, is_complex, M, poly, &lds, n) != nullptr && n1 <= n[0] && n2 <= n[1];
 }
 hipError_t prepare_interp_march_staged(int dtype, int is_complex, int M, bool poly) {
     int lds = 0, n[4];
@@ -56,10 +57,15 @@ hipError_t prepare_interp_march(int dtype, int is_complex, int M, bool poly) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
-ColumnTasks march_column_tasks(int dtype, int is_complex, int M, bool poly, const Geom& g) {
+// n1, n2 > 0: the column the plan gives the ring instead of the kernel's own (<= the compile-time columns of the kernels that will run)
+ColumnTasks march_column_tasks(int dtype, int is_complex, int M, bool poly, const Geom& g, int n1, int n2) {
     int lds = 0, n[4];
     ColumnTasks ct{};
     if (!march_kernel(dtype, is_complex, M, poly, &lds, n)) return ct;
+    if (n1 > 0 && n2 > 0) {
+        if (n1 > n[0] || n2 > n[1] || n1 % 4 || n2 % 4) return ct;
+        n[0] = n1; n[1] = n2;
+    }
     ct.ncolx = (g.Nover[0] + n[0] - 1) / n[0];
     ct.ncoly = (g.Nover[1] + n[1] - 1) / n[1];
     ct.bxw = n[0] / 4;
@@ -398,6 +404,8 @@ static hipError_t launch_t(bool interp, const TileKernelArgs& a, hipStream_t str
             mg.tasktab = a.march_tasks;
             mg.coarse_a = a.coarse ? a.coarse_a : nullptr;
             mg.coarse_b = a.coarse ? a.coarse_b : nullptr;
+            mg.n1 = 4 * a.march_ct.bxw;      // the column of this plan (= the kernel's own unless the plan shares the spreading window's)
+            mg.n2 = 4 * a.march_ct.byw;
             void* mparams[] = {&k, &mg};
             // (parts = 2: both parts of a task side by side on one XCD — march_setup.inc)
             const unsigned gx = parts == 2 ? 2u * (((unsigned)mg.ntasks + 7u) & ~7u) : (unsigned)mg.ntasks;
@@ -610,11 +618,35 @@ hipError_t launch_gather_planar(int dtype, int D, const void* sorted, int64_t np
     return hipErrorInvalidValue;
 }
 
+// ---- dense-set engine on the same window (dmarch_kernels.h): matrix-pipe register accumulation per bin ----
+const void* dmarch_kernel_f32r(int M, bool poly, int* lds_bytes, int* n);
+const void* dmarch_kernel_f64r(int M, bool poly, int* lds_bytes, int* n);
+static const void* dmarch_kernel(int dtype, int M, bool poly, int* lds_bytes, int* n) {
+    return dtype == NUFFT_F32 ? dmarch_kernel_f32r(M, poly, lds_bytes, n) : dmarch_kernel_f64r(M, poly, lds_bytes, n);
+}
+// plans of the spreading window's halo variant on real data (or complex data part by part), M <= 6, a column the kernel's window holds
+bool spread_dense_available(int dtype, int is_complex, int M, bool poly, const SMarchPlan& sp) {
+    int lds = 0, n[4];
+    if (!sp.eligible || sp.halo != 2 || (is_complex && sp.parts != 2)) return false;
+    return dmarch_kernel(dtype, M, poly, &lds, n) != nullptr && sp.n1 <= n[0] && sp.n2 <= n[1];
+}
+hipError_t prepare_spread_dense(int dtype, int M, bool poly) {
+    int lds = 0, n[4];
+    const void* fn = dmarch_kernel(dtype, M, poly, &lds, n);
+    if (!fn) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
 template <typename T>
-static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, hipStream_t stream) {
+static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, bool dense, hipStream_t stream) {
     int lds = 0, n[5];
     const int parts = (sp.parts == 2 && a.is_complex) ? 2 : 1;      // complex data part by part through the real kernel
     const void* fn = smarch_kernel(a.dtype, parts == 2 ? 0 : a.is_complex, a.M, sp.halo, a.evalmode != NUFFT_EVAL_DIRECT, &lds, n);
+    if (dense) {
+        int dn[4];
+        fn = dmarch_kernel(a.dtype, a.M, a.evalmode != NUFFT_EVAL_DIRECT, &lds, dn);
+        n[4] = dn[2];
+    }
     if (!fn) return hipErrorInvalidValue;
     if (sp.halo == 2 && !a.halo) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a.C; c0 += kMaxCompPerLaunch) {
@@ -642,8 +674,8 @@ static hipError_t launch_smarch_t(const TileKernelArgs& a, const SMarchPlan& sp,
     }
     return hipSuccess;
 }
-hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, hipStream_t stream) {
-    return a.dtype == NUFFT_F32 ? launch_smarch_t<float>(a, sp, flag, tasktab, halo_state, stream) : launch_smarch_t<double>(a, sp, flag, tasktab, halo_state, stream);
+hipError_t launch_spread_march(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, const uint2* tasktab, uint32_t* halo_state, bool dense, hipStream_t stream) {
+    return a.dtype == NUFFT_F32 ? launch_smarch_t<float>(a, sp, flag, tasktab, halo_state, dense, stream) : launch_smarch_t<double>(a, sp, flag, tasktab, halo_state, dense, stream);
 }
 hipError_t launch_smarch_halo_add(const TileKernelArgs& a, const SMarchPlan& sp, const uint32_t* flag, hipStream_t stream) {
     if (sp.halo != 2) return hipSuccess;

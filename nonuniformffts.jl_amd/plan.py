@@ -370,7 +370,7 @@ class PlanNUFFT:
         patch engine decide per point set on the device; this reads the decision back and synchronises)."""
         out = C.c_int(0)
         _check(lib.nufft_spread_engine_used(self._handle, C.byref(out), self._stream()))
-        return {1: "lds_tiles", 2: "mfma_patches", 3: "marching_ring"}[out.value]
+        return {1: "lds_tiles", 2: "mfma_patches", 3: "marching_ring", 4: "marching_ring_dense"}[out.value]
 
     def interp_engine_used(self) -> str:
         """Engine that interpolates the point set of the last set_points in exec_type2: "lds_tiles" or "marching_ring"

@@ -2,7 +2,7 @@
 # GPU parity suite + smoke on the tree as it stands (the driver's round-end check, run early)
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 TAG=${1:-r6}
-python3 -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/${TAG}_gputests.txt 2>&1
+python3 -m pytest tests -m gpu -q -p no:cacheprovider > $O/${TAG}_gputests.txt 2>&1
 echo "pytest rc=$?" >> $O/${TAG}_gputests.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1
 echo "smoke rc=$?" >> $O/${TAG}_smoke.txt

@@ -239,6 +239,39 @@ def test_config_c4_ntransforms3_spot_check():
     assert float((o1 - outs[1]).norm() / o1.norm()) < 1e-12
 
 
+def test_c4_full_grid_rel_l2_of_every_component_against_c_oracle():
+    """BASELINE config C4 at its stated size (256^3, Np = 1e7, Float64, m = 4, ntransforms = 3) with Direct(), the ROC default: full
+    rel-L2 over all 129 x 256 x 256 modes of EVERY component against the C oracle's three-component transform of the same inputs, and
+    of type 2 over all points of every component (next to the exact spot checks above).  The components
+    carry independent values, so a swapped or shared component cannot pass."""
+    from oracle import c_oracle as CO, nufft_oracle as O
+    from nufft_pkg import nufft
+    if not CO.available():
+        pytest.skip("oracle/libnufft_oracle.so not built")
+    Np, C = NP, 3
+    rng = np.random.default_rng(4004)
+    xs = [rng.random(Np) * O.TWO_PI for _ in range(3)]
+    vs = [rng.standard_normal(Np) for _ in range(C)]
+    oplan = O.OraclePlan((N, N, N), is_real=True, M=M, sigma=SIGMA, evalmode=O.DIRECT, ntransforms=C)
+    O.set_points(oplan, xs)
+    refs = CO.exec_type1(oplan, vs)
+    plan = nufft.PlanNUFFT(torch.float64, (N, N, N), m=M, sigma=SIGMA, ntransforms=C, backend=nufft.ROCBackend(0), kernel_evalmode=nufft.Direct())
+    nufft.set_points(plan, tuple(torch.from_numpy(x).cuda() for x in xs))
+    us = tuple(torch.empty(plan.shape, dtype=torch.complex128, device="cuda") for _ in range(C))
+    nufft.exec_type1(us, plan, tuple(torch.from_numpy(v).cuda() for v in vs))
+    got = [u.cpu().numpy() for u in us]
+    e1 = [float(np.linalg.norm((got[c] - refs[c]).ravel()) / np.linalg.norm(refs[c].ravel())) for c in range(C)]
+    # cross terms: component c against the oracle's component c' != c must be far off (independent values)
+    assert float(np.linalg.norm((got[0] - refs[1]).ravel()) / np.linalg.norm(refs[1].ravel())) > 0.5
+    outs = tuple(torch.empty(Np, dtype=torch.float64, device="cuda") for _ in range(C))
+    nufft.exec_type2(outs, plan, us)
+    ref2 = CO.exec_type2(oplan, got)
+    e2 = [float(np.linalg.norm(outs[c].cpu().numpy() - ref2[c]) / np.linalg.norm(ref2[c])) for c in range(C)]
+    print(f"C4 full size, Direct: type 1 rel-L2 per component vs C oracle {e1}, type 2 {e2}; engines {plan.spread_engine_used()} / "
+          f"{plan.interp_engine_used()}, column-layer sort {plan.sort_columns_used()}")
+    assert max(e1) < 1e-11 and max(e2) < 1e-11, (e1, e2)
+
+
 def test_config_c3_complexf32_m8_1024_cubed_spot_check():
     """BASELINE config C3 shape: 3-D, Ns = 512^3, ComplexF32, m = 8 (oversampled 1024^3, 8.6 GB grid; LDS pressure).
     at the stated Np = 1e8; exact spot checks of type-1 modes and type-2 points in Float64.
@@ -284,7 +317,8 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
     nufft.exec_type2(out, plan, w)
     w64 = w.to(torch.complex128)
     num = den = 0.0
-    for j in rng.integers(0, Np, 12):
+    npts2 = 64
+    for j in rng.integers(0, Np, npts2):
         e1 = torch.polar(torch.ones_like(k), k * x64[0][j])
         e2 = torch.polar(torch.ones_like(k), k * x64[1][j])
         e3 = torch.polar(torch.ones_like(k), k * x64[2][j])
@@ -292,7 +326,7 @@ def test_config_c3_complexf32_m8_1024_cubed_spot_check():
         num += float((out[j].to(torch.complex128) - exact).abs() ** 2)
         den += float(exact.abs() ** 2)
     e2 = np.sqrt(num / den)
-    print(f"C3 full size: type 2 rel-L2 over 12 points vs exact sums {e2:.2e}")
+    print(f"C3 full size: type 2 rel-L2 over {npts2} points vs exact sums {e2:.2e}")
     assert e2 < 5e-5, e2
 
 

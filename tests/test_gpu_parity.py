@@ -505,6 +505,76 @@ def test_spreading_ring_halo_variant_every_instantiation(Z, C, M, monkeypatch):
     _ring_halo_variant_case(Z, C, M, monkeypatch, split=True)
 
 
+@pytest.mark.parametrize("M", range(2, 7))
+@pytest.mark.parametrize("Z,C", [(np.float32, 1), (np.float64, 1), (np.float64, 2), (np.complex64, 1), (np.complex128, 2)])
+def test_dense_window_engine_every_instantiation(Z, C, M, monkeypatch):
+    """The dense-set engine of the spreading window (dmarch_kernels.h, round 6: the points of a 4^3-cell bin accumulated in registers by
+    v_mfma_f64_16x16x4, one flush of the bin's (2M + 3)^3 footprint into the window) for every element type and M = 2 .. 6, both window
+    evaluations, against the C oracle (Float64; Float32 plans: points located in Float32 as a Float32 plan of the reference does, bound 1e-5):
+    a dense uniform set (about 20 points per bin: full and partly filled batches of four, several loads of sixteen records per bin), a set
+    concentrated in a corner (bins with hundreds of points next to empty ones; tasks of equal point count with clipped first / last
+    layers), and a sparse one that the plan itself would not give to this engine (forced: bins with one to three points, mostly empty
+    batch slots).  The engine is read back; set_points picks it from the mean bin load (the dense set: the plan's own threshold).  Grid
+    96 x 96 x 112 as for the halo variant above: columns at the periodic boundary, several segments along dimension 3.  Also: the
+    stage-level entry point (complete grid against the oracle's spread field) and type 2 on the fine-sorted point set.
+    Semantics: src/spreading/gpu.jl:237-377."""
+    from oracle import c_oracle as CO
+    if not CO.available():
+        pytest.skip("C oracle not built")
+    nufft = _nufft()
+    Zt = np.dtype(Z)
+    is_real = Zt.kind == "f"
+    T = plan_real_dtype(Z)
+    wide = np.float64 if is_real else np.complex128
+    tol = 1e-5 if T == np.float32 else 1e-7
+    dims = (48, 48, 56)
+    nbins = (96 // 4) * (96 // 4) * (112 // 4)
+    monkeypatch.setenv("NUFFT_SMARCH_HALO", "2")
+    rng = np.random.default_rng(1300 + M)
+    for evalmode in (O.DIRECT, O.FAST_APPROXIMATION):
+        mode = nufft.Direct() if evalmode == O.DIRECT else nufft.FastApproximation()
+        oplan = O.OraclePlan(dims, is_real=is_real, dtype=np.float64, coord_dtype=(np.float32 if T == np.float32 else None), M=M, sigma=2.0,
+                             evalmode=evalmode, ntransforms=C)
+        for name, Np, force in (("dense", 20 * nbins, False), ("corner", 6 * nbins, True), ("sparse", nbins // 2, True)):
+            if force:
+                monkeypatch.setenv("NUFFT_DENSE_MIN", "0")
+            else:
+                monkeypatch.delenv("NUFFT_DENSE_MIN", raising=False)
+            plan = nufft.PlanNUFFT(Zt, dims, m=M, sigma=2.0, ntransforms=C, kernel_evalmode=mode, spread_method="marching_ring", backend=nufft.ROCBackend(0))
+            info = plan.info()
+            assert info.spread_method == 3 and info.ring_halo == 1, (M, list(info.ring_column))
+            dev = plan.device
+            xs = [((rng.random(Np) * 3 - 1) * O.TWO_PI).astype(T) for _ in dims]      # points outside the unit cell too
+            if name == "corner":
+                xs = [(0.3 * np.mod(x, T(O.TWO_PI)) ** 2 / (2 * np.pi)).astype(T) for x in xs]
+            vs = [(rng.standard_normal(Np) if is_real else rng.standard_normal(Np) + 1j * rng.standard_normal(Np)).astype(Zt) for _ in range(C)]
+            nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in xs))
+            O.set_points(oplan, xs)
+            us = tuple(torch.empty(plan.shape, dtype=plan.eltype, device=dev) for _ in range(C))
+            vd = tuple(torch.from_numpy(v).to(dev) for v in vs)
+            nufft.exec_type1(us if C > 1 else us[0], plan, vd if C > 1 else vd[0])
+            assert plan.spread_engine_used() == "marching_ring_dense", (name, evalmode, M)
+            ref = CO.exec_type1(oplan, [v.astype(wide) for v in vs])
+            for c in range(C):
+                assert _rel(us[c].cpu().numpy().astype(np.complex128), ref[c]) < tol, ("type 1", name, evalmode, c)
+            if name == "dense" and evalmode == O.DIRECT:
+                refg = CO.spread(oplan, [v.astype(wide) for v in vs])
+                nufft.spread_from_points(plan, vd if C > 1 else vd[0])
+                scale = 2.0 ** sum(info.window_scale_log2[d] for d in range(3))
+                for c in range(C):
+                    gc = nufft.oversampled_grid(plan, c).cpu().numpy().astype(wide) / scale
+                    assert _rel(gc, refg[c]) < (1e-12 if T == np.float64 else 2e-6), ("grid", c)
+                ctype = np.complex64 if T == np.float32 else np.complex128
+                ws = [(rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)).astype(ctype) for _ in range(C)]
+                out = tuple(torch.empty(Np, dtype=vd[0].dtype, device=dev) for _ in range(C))
+                wd = tuple(torch.from_numpy(w).to(dev) for w in ws)
+                nufft.exec_type2(out if C > 1 else out[0], plan, wd if C > 1 else wd[0])
+                ref2 = CO.exec_type2(oplan, [w.astype(np.complex128) for w in ws])
+                for c in range(C):
+                    assert _rel(out[c].cpu().numpy().astype(wide), ref2[c]) < tol, ("type 2", c)
+            plan.close()
+
+
 @pytest.mark.parametrize("M", range(2, 6))
 @pytest.mark.parametrize("Z", [np.complex64, np.complex128])
 def test_spreading_ring_halo_variant_interleaved_complex_instantiations(Z, M, monkeypatch):
@@ -656,26 +726,41 @@ def test_forwarded_kernel_data_reproduces_the_plan(Z, dims, M, sigma, kname):
     assert _rel(outs[1][0], outs[0][0]) < tol and _rel(outs[1][1], outs[0][1]) < tol
 
 
-@pytest.mark.parametrize("Z,M,C,evalmode", [(np.float64, 4, 1, O.FAST_APPROXIMATION), (np.float64, 4, 1, O.DIRECT), (np.float64, 4, 3, O.FAST_APPROXIMATION),
-                                             (np.float32, 4, 1, O.DIRECT), (np.float64, 2, 1, O.DIRECT), (np.float64, 3, 2, O.FAST_APPROXIMATION),
-                                             (np.float64, 5, 1, O.DIRECT), (np.float32, 6, 1, O.FAST_APPROXIMATION), (np.float64, 6, 1, O.DIRECT),
-                                             (np.float32, 7, 1, O.DIRECT),
-                                             # ComplexF64: both rings run the real kernels part by part, so the plan shares their columns
-                                             (np.complex128, 4, 1, O.FAST_APPROXIMATION), (np.complex128, 4, 2, O.DIRECT), (np.complex128, 6, 2, O.DIRECT)])
+# every (element type, M) for which the spreading window runs in its halo variant: since round 6 the interpolation ring takes the window's
+# column (one chooser, plan.cpp shared_ring_column) and interp_march_staged_kernel is instantiated for all of them — the list holds only
+# eligible combinations and the test ASSERTS eligibility (tests/test_host_abi.py::test_gpu_parametrisations_are_eligible_by_construction
+# checks the same from host-only plans, so a list that would mostly skip fails on the CPU already)
+COLUMN_LAYER_CASES = [(np.float64, 4, 1, O.FAST_APPROXIMATION), (np.float64, 4, 1, O.DIRECT), (np.float64, 4, 3, O.FAST_APPROXIMATION),
+                      (np.float32, 4, 1, O.DIRECT), (np.float64, 2, 1, O.DIRECT), (np.float64, 3, 2, O.FAST_APPROXIMATION),
+                      (np.float64, 5, 1, O.DIRECT), (np.float32, 6, 1, O.FAST_APPROXIMATION), (np.float64, 6, 1, O.DIRECT),
+                      (np.float32, 7, 1, O.DIRECT), (np.float32, 2, 1, O.FAST_APPROXIMATION), (np.float32, 3, 1, O.DIRECT), (np.float32, 5, 2, O.DIRECT),
+                      (np.float64, 6, 1, O.FAST_APPROXIMATION), (np.float64, 5, 1, O.FAST_APPROXIMATION),
+                      # ComplexF64: both rings run the real kernels part by part; ComplexF32: the window part by part, the paired-lane ring
+                      (np.complex128, 4, 1, O.FAST_APPROXIMATION), (np.complex128, 4, 2, O.DIRECT), (np.complex128, 6, 2, O.DIRECT),
+                      (np.complex128, 2, 1, O.DIRECT), (np.complex128, 5, 1, O.FAST_APPROXIMATION),
+                      (np.complex64, 4, 1, O.DIRECT), (np.complex64, 6, 1, O.FAST_APPROXIMATION), (np.complex64, 3, 2, O.DIRECT), (np.complex64, 5, 1, O.DIRECT)]
+COLUMN_LAYER_DIMS = (256, 256, 32)          # 512 x 512 x 64: 16 x 16 columns of 32 x 32 cells as at C2, 16 layers of bins
+
+
+@pytest.mark.parametrize("Z,M,C,evalmode", COLUMN_LAYER_CASES)
 def test_column_layer_sort_and_staged_interpolation(Z, M, C, evalmode, monkeypatch):
     """Plans whose spreading window (halo variant) and interpolation ring own the same columns sort the points by (column, layer of
     bins) only (binsort.hip, CoarseSort: LDS histograms, no global atomics) and interpolate with interp_march_staged_kernel, which
     orders a layer's points by bin on their way into LDS.  Type 1 and type 2 against the oracle on a uniform set (column-layer sort,
     read back), with per-point weights (the ring applies them itself).  The sort result is a permutation grouped by column layer."""
-    dims, Np = (256, 256, 32), 60000        # 512 x 512 x 64: 16 x 16 columns of 32 x 32 cells as at C2, 16 layers of bins
+    dims, Np = COLUMN_LAYER_DIMS, 60000
     monkeypatch.setenv("NUFFT_SMARCH_HALO", "2")
     monkeypatch.delenv("NUFFT_COARSE_SORT", raising=False)
     monkeypatch.setenv("NUFFT_INTERP_MARCH", "2")                # always the ring: the grid is too small to fill the chip
     nufft, plan, oplan, xs, vs = _make_case(Z, dims, M, 2.0, evalmode, C, Np, seed=900 + M, spread_method="marching_ring")
     info = plan.info()
     assert info.spread_method == 3 and info.ring_halo == 1
-    if info.sort_column[0] == 0:
-        pytest.skip(f"no common column for M = {M}, {np.dtype(Z).name}: spreading ring {list(info.ring_column)}")
+    # eligible by construction — and the column is the spreading window's
+    assert info.sort_column[0] > 0 and [4 * info.sort_column[0], 4 * info.sort_column[1]] == list(info.ring_column), (list(info.sort_column), list(info.ring_column))
+    # ... as the host-only prediction says (what the CPU-side eligibility test relies on)
+    hp = nufft.PlanNUFFT(Z, dims, m=M, sigma=2.0, ntransforms=C, kernel_evalmode=nufft.Direct() if evalmode == O.DIRECT else nufft.FastApproximation(),
+                         spread_method="marching_ring", backend=None)
+    assert list(hp.info().sort_column) == list(info.sort_column)
     dev = plan.device
     tup = (lambda t: t if C > 1 else t[0])
     xd = tuple(torch.from_numpy(x).to(dev) for x in xs)
