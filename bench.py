@@ -486,6 +486,10 @@ def main():
         kname = f"spread_patch_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, false, {head['patch_planar']}>"
         binding = ("issue and latency of the per-visit point set-up at 8 waves per CU (VALU 36 %, LDS 44 %, FP64 matrix pipe 16 % "
                    "busy), not HBM: see DESIGN.md section 4.4")
+    elif head["spread_engine"] == "marching_ring_dense":
+        kname = f"spread_march_dense_kernel<{tname}, {cfg['m']}, {'false' if head['evalmode'] == 'Direct' else 'true'}>"
+        binding = ("the FP64 matrix pipe (v_mfma_f64_16x16x4: the points of a 4^3-cell bin accumulated in registers, NT instructions per four points) "
+                   "and the vector work that builds its operands, then one flush of 4 NT LDS atomics per bin; not HBM: see DESIGN.md section 4.12")
     elif head["spread_engine"] == "marching_ring":
         kname = f"spread_march_kernel<{tname}, {'true' if is_complex else 'false'}, {cfg['m']}, {'false' if head['evalmode'] == 'Direct' else 'true'},"
         binding = ("the LDS atomic pipe (ds_add_f64: 8 array cycles per 64-lane wave instruction, 11.9 of them per point at 1.49 visits; "

@@ -21,9 +21,10 @@
 // where the record sits, and each of the four batches broadcasts its points inside the quads (DPP quad_perm).  Window values: the
 // group mapping of the other kernels (WindowEval, 16 lanes per point), written into the wave's LDS strip [point][dimension][16] at
 // offset (cell mod 4) inside zero-filled rows — the padding.  Operands: lane (k, i) reads its face products from two strip rows,
-// tile row i holds face position 16 t + 4 (i mod 4) + i / 4: the accumulator registers r = 0..3 of a lane are then four face
-// positions 4 apart, and the four lane groups of a flush instruction add CONSECUTIVE cells of a window row on planes z = lane mod 16 —
-// with the plane stride congruent to 2 modulo the 32 double-word banks no two lanes of a half-wave share a bank.
+// tile row i holds face position 16 t + i.  The C/D layout of the instruction (column = lane mod 16, row = lane / 16 + 4 x register)
+// puts the face positions 16 t + 4 r + 0..3 of accumulator register r into the four lane groups: a flush instruction adds four
+// CONSECUTIVE cells of a window row on planes z = lane mod 16 — with the plane stride congruent to 2 modulo the 32 double-word banks
+// no two lanes of a half-wave share a bank.
 #pragma once
 
 #include "smarch_kernels.h"
@@ -39,7 +40,14 @@ struct DMarchCfg {
     static constexpr int L = 2 * M, RZ = L + 3, FP = L + 3;
     static constexpr int NFACE = FP * FP, NT = (NFACE + 15) / 16;
     static_assert(FP <= 15, "a padded window row has 16 entries, the last one always zero");
-    static constexpr int THREADS = 512, NW = THREADS / kWave;      // 8 waves: 256 registers per lane (4 NT accumulators: 120 at M = 6)
+#ifndef NUFFT_DMARCH_THREADS
+#define NUFFT_DMARCH_THREADS 512
+#endif
+#ifndef NUFFT_DMARCH_ABL
+#define NUFFT_DMARCH_ABL 0          // ablation builds, bit mask: 1 = no flush atomics, 2 = no matrix instructions, 4 = no window evaluation, 8 = no operand reads,
+                                    // 16 = no record / value loads, 32 = no strip writes
+#endif
+    static constexpr int THREADS = NUFFT_DMARCH_THREADS, NW = THREADS / kWave;      // 8 waves: 256 registers per lane (4 NT accumulators: 120 at M = 6)
     static constexpr int HLO = S::HLO, HHI = S::HHI;
     static constexpr int XLO = S::XLO, XHI = S::XHI, YLO = S::YLO, YHI = S::YHI;
     static constexpr int N1 = S::N1, N2 = S::N2;
@@ -55,6 +63,11 @@ struct DMarchCfg {
     static constexpr int lds_bytes() { return RING_BYTES + NW * strip_bytes() + TAB_WORDS * 4 + 64; }
     static_assert(!FITS || lds_bytes() <= 163840 - 256, "window + strips exceed the LDS");
 };
+
+// Orders the LDS traffic of one wave for the COMPILER only.  The hardware executes the LDS instructions of a wave in issue order (a ds_read
+// behind a ds_write of the same wave sees the written value), so no s_waitcnt is needed between them — wave_lds_fence() (device_common.h)
+// drained the LDS queue three times per batch here: 0.5 of 3.0 ms at rho = 1.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
 // quad broadcast: every lane takes the value of lane B of its quad (DPP quad_perm [B, B, B, B])
 template <int B>
@@ -146,11 +159,12 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
     we.init(am, i16);
     // the lane's strip rows [dimension][16] of its point group
     double* srow = strip + k * 48;
-    // operands: tile t, row i16 of the tile = face position 16 t + 4 (i16 mod 4) + i16 / 4
+    // operands: tile t, row i16 of the tile = face position 16 t + i16.  (C/D layout of v_mfma_f64_16x16x4: column = lane mod 16, row =
+    // lane / 16 + 4 x register — the four lane groups of accumulator register r hold the CONSECUTIVE face positions 16 t + 4 r + 0..3)
     int fxy[NT];                                        // fx | fy << 8
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int f = 16 * t + 4 * (i16 & 3) + (i16 >> 2);
+        const int f = 16 * t + i16;
         const int fx = f < C::NFACE ? f % FP : 15, fy = f < C::NFACE ? f / FP : 15;      // (entry 15 of a padded row is always zero)
         fxy[t] = fx | (fy << 8);
     }
@@ -168,47 +182,149 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
         // planes of this layer's window the task owns (the first and last layers of a segment reach into the neighbouring segments)
         const bool zok = i16 < RZ && wq + i16 >= 0 && wq + i16 < nq;
 
-        for (int jb = 0; jb < nbw; ++jb) {
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)p0_l, jb), r1 = (uint32_t)__builtin_amdgcn_readlane((int)p1_l, jb);
-            if (r1 <= r0) continue;
-            const int b = wave + NW * jb, bxi = b % nbx, byi = b / nbx;
-            // footprint origin of the bin in window coordinates: cell 4 b - (M - 1) relative to the window's first cell
-            double* bin_base = ring + ((4 * byi + C::YLO - (M - 1)) * RS + 4 * bxi + C::XLO - (M - 1)) + i16 * PS;      // ... on this lane's plane
-            DMv4 acc[NT];
+        // ---- the wave's bins of this layer as ONE sequence of loads of sixteen records: the record load runs two steps ahead of the matrix
+        //      work, the value load (which needs the record's index) one step — a load of sixteen is 4 batches x NT matrix instructions
+        //      of work for the wave, about the latency of one trip to memory ----
+        struct Step { int jb; uint32_t p, r1; };        // bin of the wave, first record of the load, end of the bin's run (scalars)
+        auto advance = [&](Step& st) __attribute__((always_inline)) -> bool {
+            st.p += 16u;
+            while (st.p >= st.r1) {
+                if (++st.jb >= nbw) return false;
+                st.p = (uint32_t)__builtin_amdgcn_readlane((int)p0_l, st.jb);
+                st.r1 = (uint32_t)__builtin_amdgcn_readlane((int)p1_l, st.jb);
+            }
+            return true;
+        };
+        // (every load of the pipeline is UNCONDITIONAL, from an index clamped into the array: a load behind a branch makes the compiler wait for
+        // all outstanding loads where the branches join — the first version waited out both round trips in every step, 0.41 of 3.0 ms)
+        const T* wsrc = a.weights ? a.weights : vin;    // (no weights: a valid address, the value is not used)
+        const int wstride = a.weights ? 1 : vgs;
+        auto load_rec = [&](const Step& st, bool ok) __attribute__((always_inline)) -> PointRec<T, 3> {
+            const uint32_t pr = st.p + 4u * (uint32_t)qd + (uint32_t)k;
+#if NUFFT_DMARCH_ABL & 16
+            PointRec<T, 3> fake{};
+            fake.r[0] = T(org1 + 4 * (mybin % nbx)) + T(0.37) * T(1 + qd); fake.r[1] = T(org2 + 4 * ((mybin / nbx) % nby)) + T(0.21) * T(1 + k); fake.r[2] = T(1.5) + T(pr & 1u);
+            fake.idx = (int)pr;
+            return fake;
+#endif
+            const uint32_t last = ok ? st.r1 - 1u : 0u;
+            return sorted[ok && pr < st.r1 ? pr : last];
+        };
+        struct Val { T v, w; };
+        auto load_val = [&](const PointRec<T, 3>& rec) __attribute__((always_inline)) -> Val {
+#if NUFFT_DMARCH_ABL & 16
+            return Val{T(rec.idx & 7), T(1)};
+#endif
+            return Val{vin[(int64_t)rec.idx * vgs], wsrc[(int64_t)rec.idx * wstride]};
+        };
+        // value of the lane's slot: 0 beyond the run (its row of B is then zero), times the point's weight of the callback menu
+        // (callbacks.nonuniform(v, n), src/spreading/gpu.jl:289)
+        auto value_of = [&](const Step& st, const Val& x) __attribute__((always_inline)) -> T {
+            const bool have = st.p + 4u * (uint32_t)qd + (uint32_t)k < st.r1;
+            const T v = a.weights ? x.v * x.w : x.v;
+            return have ? v : T(0);
+        };
+        Step s0{-1, 0u, 0u};
+        bool ok0 = advance(s0);
+        Step s1 = s0;
+        bool ok1 = ok0 && advance(s1);
+        Step s2 = s1;
+        bool ok2 = ok1 && advance(s2);
+        PointRec<T, 3> rec0{}, rec1{}, rec2{};
+        Val val0{T(0), T(1)}, val1{T(0), T(1)};
+        if (ok0) {                                       // (a layer without points in the wave's bins: nothing is loaded at all)
+            rec0 = load_rec(s0, true);
+            rec1 = load_rec(s1, ok1);
+            val0 = load_val(rec0);
+        }
+        DMv4 acc[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = DMv4{0.0, 0.0, 0.0, 0.0};
-
-            for (uint32_t p = r0; p < r1; p += 16u) {
+        for (int t = 0; t < NT; ++t) acc[t] = DMv4{0.0, 0.0, 0.0, 0.0};
+        // Software pipeline over the batches of four points: the operands of batch i + 1 are built (window evaluation, padded rows into the
+        // strip, face products read back into registers) BEFORE the matrix instructions of batch i are issued — their issue (NT x 64 cycles
+        // of the matrix pipe) then covers the strip's LDS round trip, and the other wave of the SIMD evaluates windows meanwhile.
+        // (First version: evaluate, write, read, wait, multiply, issue — per batch: VALU 37 %, matrix pipe 25 %, LDS 32 % busy, waves waiting
+        // 46 % of their cycles at two waves per SIMD: 3.85 ms at rho = 1 against 2.97 ms for the stream of atomics.)
+        struct Ops { double ap[NT]; double b; };        // A (face products of the lane's tile rows) and B (its plane's value-weighted dimension-3 entry)
+        Ops cur{};
+        bool pending = false;                            // `cur` holds a batch whose matrix instructions have not been issued
+        int cur_jb = 0;                                  // ... of this bin of the wave
+        auto issue = [&](const Ops& o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#if NUFFT_DMARCH_ABL & 2
+                acc[t][0] += o.ap[t] * o.b;
+#else
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ap[t], o.b, acc[t], 0, 0, 0);
+#endif
+            }
+        };
+        auto flush = [&](int jb) __attribute__((always_inline)) {
+            // the bin is complete: its footprint onto the window, 4 NT atomics (lanes: plane z = lane mod 16, four consecutive face positions)
+            const int b = wave + NW * jb, bxi = b % nbx, byi = b / nbx;
+            // footprint origin of the bin in window coordinates: cell 4 b - (M - 1) relative to the window's first cell; ... on this lane's plane
+            double* bin_base = ring + ((4 * byi + C::YLO - (M - 1)) * RS + 4 * bxi + C::XLO - (M - 1)) + i16 * PS;
+            // (the table entries of ALL tiles first: LDS instructions return in order, so a read behind four atomics waits for them —
+            // tile by tile the flush was 8 round trips per bin, 0.6 of 3.0 ms at rho = 1)
+            // (M = 6: 15 tiles — four at a time, the registers are the accumulators')
+            constexpr int TG = NT <= 11 ? NT : 4;
+            uint4 off[TG];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t % TG == 0) {
+#pragma unroll
+                    for (int u = 0; u < TG; ++u)
+                        if (t + u < NT) off[u] = tab_lane[4 * (t + u)];
+                }
+                const uint32_t offs[4] = {off[t % TG].x, off[t % TG].y, off[t % TG].z, off[t % TG].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#if NUFFT_DMARCH_ABL & 1
+                    asm volatile("" ::"v"(acc[t][r]), "v"(offs[r]));
+#else
+                    if (zok && offs[r] != 0xffffffffu) atomicAdd(bin_base + offs[r], acc[t][r]);
+#endif
+                }
+                acc[t] = DMv4{0.0, 0.0, 0.0, 0.0};
+            }
+        };
+        while (ok0) {
+            val1 = load_val(rec1);
+            rec2 = load_rec(s2, ok2);
+            {
                 // ---- sixteen records: lane (k, i) holds point 4 (i mod 4) + k of them; its cell, fraction and value ----
-                const uint32_t pr = p + 4u * (uint32_t)qd + (uint32_t)k;
-                const bool have = pr < r1;
-                const PointRec<T, 3> rec = sorted[have ? pr : r1 - 1u];
+                const uint32_t p = s0.p, r1 = s0.r1;
                 T X[3];
                 int spk = 0;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    const int c = cell_of(rec.r[d], g.Nover[d]);
-                    X[d] = rec.r[d] - T(c);
+                    const int c = cell_of(rec0.r[d], g.Nover[d]);
+                    X[d] = rec0.r[d] - T(c);
                     spk |= (c & 3) << (2 * d);          // offset of the stencil inside the bin's footprint
                 }
-                T v = T(0);
-                if (have) {
-                    v = vin[(int64_t)rec.idx * vgs];
-                    if (a.weights) v *= a.weights[rec.idx];       // callbacks.nonuniform(v, n), src/spreading/gpu.jl:289
-                }
+                const T v = value_of(s0, val0);
+                // operands of batch B of the sixteen (into registers), then the matrix instructions of the batch before it
                 auto batch = [&](auto bc) __attribute__((always_inline)) {
                     constexpr int B = decltype(bc)::value;
                     T Xb[3];
 #pragma unroll
                     for (int d = 0; d < 3; ++d) Xb[d] = quad_bcast<B>(X[d]);
                     const int sb = quad_bcast<B>(spk);
-                    const T vb = quad_bcast<B>(v);      // (0 for a point beyond the run: its row of B is zero)
+                    const T vb = quad_bcast<B>(v);
                     T wv[WE::NSLOT];
+#if NUFFT_DMARCH_ABL & 4
+#pragma unroll
+                    for (int sl = 0; sl < WE::NSLOT; ++sl) wv[sl] = Xb[sl % 3];
+#else
                     we.eval_regs(am, Xb, wv);
-                    wave_lds_fence();                   // the previous batch's operand reads are done
+#endif
+                    lds_order();                   // (the previous batch's operands are in registers already)
+#if NUFFT_DMARCH_ABL & 32
+                    asm volatile("" ::"v"(wv[0]), "v"(sb), "v"(vb));
+#else
 #pragma unroll
                     for (int d = 0; d < 3; ++d) srow[16 * d + i16] = 0.0;
-                    wave_lds_fence();
+                    lds_order();
 #pragma unroll
                     for (int sl = 0; sl < WE::NSLOT; ++sl)
                         if (we.has[sl]) {
@@ -216,13 +332,57 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
                             const int sd = (sb >> (2 * d)) & 3;
                             srow[16 * d + sd + we.jsel[sl]] = (double)(d == 2 ? wv[sl] * vb : wv[sl]);
                         }
-                    wave_lds_fence();
-                    const double bop = srow[32 + i16];
+#endif
+                    lds_order();
+                    Ops nx;
+                    // (wide stencils: 2 NT operand registers in flight next to 4 NT accumulators do not fit 256 registers — there the matrix
+                    // instructions of the batch before go out first, over the strip writes, and the products are formed as the reads return)
+                    // (M = 6: 15 tiles — 120 accumulator registers; no batch is held back at all: its own matrix instructions follow its products)
+                    constexpr bool READS_FIRST = NT <= 8, LAG = NT <= 11;
+                    if constexpr (!READS_FIRST && LAG) {
+                        if (pending) {
+                            issue(cur);
+                            if (cur_jb != s0.jb) flush(cur_jb);       // ... and it was the last batch of its bin
+                        }
+                    }
+                    nx.b = srow[32 + i16];
+                    if constexpr (!LAG) {
+                        // no batch held back: read, multiply, issue — tile by tile (nothing but the accumulators stays live)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const double a1 = srow[fxy[t] & 0xff], a2 = srow[16 + (fxy[t] >> 8)];
+#if NUFFT_DMARCH_ABL & 2
+                            acc[t][0] += a1 * a2 * nx.b;
+#else
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * a2, nx.b, acc[t], 0, 0, 0);
+#endif
+                        }
+                    } else {
+                    double a1[NT], a2[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const double a1 = srow[fxy[t] & 0xff];
-                        const double a2 = srow[16 + (fxy[t] >> 8)];
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * a2, bop, acc[t], 0, 0, 0);
+#if NUFFT_DMARCH_ABL & 8
+                        a1[t] = nx.b; a2[t] = (double)(fxy[t] + 1);
+#else
+                        a1[t] = srow[fxy[t] & 0xff];
+                        a2[t] = srow[16 + (fxy[t] >> 8)];
+#endif
+                        if constexpr (!READS_FIRST) nx.ap[t] = a1[t] * a2[t];
+                    }
+                    if constexpr (READS_FIRST) {
+                        // the batch before this one: its matrix instructions go out while the reads above are in flight
+                        if (pending) {
+                            issue(cur);
+                            if (cur_jb != s0.jb) flush(cur_jb);       // ... and it was the last batch of its bin
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) nx.ap[t] = a1[t] * a2[t];
+                    }
+                    }
+                    if constexpr (LAG) {
+                        cur = nx;
+                        cur_jb = s0.jb;
+                        pending = true;
                     }
                 };
                 batch(std::integral_constant<int, 0>{});
@@ -230,15 +390,16 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
                 if (p + 8u < r1) batch(std::integral_constant<int, 2>{});
                 if (p + 12u < r1) batch(std::integral_constant<int, 3>{});
             }
-            // ---- flush: the bin's footprint onto the window, 4 NT atomics (lanes: plane z = lane mod 16, four consecutive face positions) ----
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint4 off = tab_lane[4 * t];
-                const uint32_t offs[4] = {off.x, off.y, off.z, off.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (zok && offs[r] != 0xffffffffu) atomicAdd(bin_base + offs[r], acc[t][r]);
+            if constexpr (NT > 11) {
+                if (!ok1 || s1.jb != s0.jb) flush(s0.jb);             // (no batch held back: the bin ends with this load of sixteen)
             }
+            s0 = s1; rec0 = rec1; val0 = val1; ok0 = ok1;
+            s1 = s2; rec1 = rec2; ok1 = ok2;
+            if (ok2) ok2 = advance(s2);
+        }
+        if (pending) {
+            issue(cur);
+            flush(cur_jb);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();

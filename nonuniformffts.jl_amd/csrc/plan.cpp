@@ -448,6 +448,13 @@ static bool shared_ring_column(const nufft_plan* p, const SMarchPlan& sm, Column
     const int mcplx = p->interp_parts == 2 ? 0 : (int)p->is_complex;
     const bool poly = p->evalmode != NUFFT_EVAL_DIRECT;
     if (p->Nover[0] % sm.n1 != 0 || p->Nover[1] % sm.n2 != 0 || nkeys > kCoarseMaxKeys) return false;
+    // Measured (256^3 -> 512^3, Np = 1e7, set_points + spread / set_points + interpolation against the plan without it, ms; scripts/r6_e.sh,
+    // profiles/round6_*): Float64 m = 2 / 3 / 4 -0.18 / -0.18 / -0.12 and -0.14 / -0.20 / -0.21, ComplexF64 m = 4 -0.12 / -0.29, Float32 m = 3 / 4
+    // -0.06 / -0.03 and -0.07 / -0.04, ComplexF32 m = 3 / 4 -0.15 / -0.04 and -0.02 / -0.02 (polynomial window: +0.02) — and Float32 m = 2
+    // -0.11 but +0.12 (Direct) / +0.22 (polynomial) on the type-2 side: its ring gathers through the LDS strips (no register window at 4-lane
+    // rows) from a 64 x 64 column of its own, which the 32 x 32 window column cannot replace.  That one keeps its own column
+    // (NUFFT_COARSE_SORT=2: shared all the same — the test of its staged instantiation).
+    if (p->dtype == NUFFT_F32 && !p->is_complex && p->M == 2 && env_int("NUFFT_COARSE_SORT", 1) != 2) return false;
     if (!interp_march_staged_available(p->dtype, mcplx, p->M, poly, sm.n1, sm.n2)) return false;
     const ColumnTasks ct = march_column_tasks(p->dtype, mcplx, p->M, poly, make_geom(p), sm.n1, sm.n2);
     if (ct.ntasks <= 0 || ct.ncolx != sm.ct.ncolx || ct.ncoly != sm.ct.ncoly || (size_t)ct.ncolx * ct.ncoly >= 65536 || p->tile.nb[2] > 2048) return false;
@@ -546,8 +553,30 @@ static int build_device(nufft_plan* p) {
         p->spec_elems *= p->Nspec[d];
     }
     if ((rc = dev_alloc(p, &p->d_us, (size_t)p->grid_elems * value_bytes(p) * p->C, "us"))) return rc;
-    if (!p->is_complex) {
-        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->spec_elems * 2 * real_bytes(p) * p->C, "uhat"))) return rc;
+    // pruned FFT path: D >= 2, every higher dimension (and dimension 1 of complex plans) of an instantiated length — decided before the
+    // spectra and the rocFFT plans are set up: a plan on this path never runs the D-dimensional rocFFT transform, so it neither creates
+    // those plans nor allocates their work buffer (round 6: 1.07 GB of C2's 4.5 GB, 8.6 GB of C3's 27.8 GB were that buffer), and a real
+    // plan whose dimension-1 pass is the library's own keeps the COMPACT spectrum only (N1/2 + 1 modes per line, rows padded to 128 bytes:
+    // 0.57 instead of 1.08 GB per component at C2)
+    p->pruned_fft = D >= 2 && env_int("NUFFT_PRUNED_FFT", 1) != 0;
+    for (int d = p->is_complex ? 0 : 1; d < D && p->pruned_fft; ++d) p->pruned_fft = fft_lines_supported(p->dtype, p->Nover[d]);
+    p->compact_dim1 = p->pruned_fft && (p->is_complex || (real_lines_supported(p->dtype, p->Nover[0]) && env_int("NUFFT_COMPACT_DIM1", 1) != 0));
+    // row stride of the compact dimension-1 spectrum and of tmp2: the strided passes read groups of adjacent columns,
+    // 128 bytes per row — with rows of N1/2 + 1 = 129 elements every group straddled two cache lines (PMC: 1.6x the bytes
+    // read); real plans pad their intermediate rows to 128 bytes
+    p->spec_row = p->compact_dim1 ? p->Nout[0] : p->Nspec[0];
+    if (p->compact_dim1 && !p->is_complex && env_int("NUFFT_FFT_PAD_ROWS", 1) != 0) {
+        const int64_t q = 128 / (int64_t)(2 * real_bytes(p));
+        p->spec_row = (p->Nout[0] + q - 1) / q * q;
+        if (p->spec_row > p->Nspec[0]) p->spec_row = p->Nout[0];      // (cannot happen for sigma >= 1.25)
+    }
+    p->pspec_elems = p->spec_elems;
+    if (p->compact_dim1) {
+        p->pspec_elems = p->is_complex ? p->Nout[0] : p->spec_row;
+        for (int d = 1; d < D; ++d) p->pspec_elems *= p->Nover[d];
+    }
+    if (!p->is_complex || p->pruned_fft) {
+        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->pspec_elems * 2 * real_bytes(p) * p->C, "uhat"))) return rc;
     }
 
     // bin-sort scratch that does not depend on Np
@@ -575,43 +604,34 @@ static int build_device(nufft_plan* p) {
         if ((rc = dev_alloc(p, &b.d_tmp, b.tmp_bytes))) return rc;
     }
 
-    // rocFFT plans (plan_rfft / plan_brfft / plan_fft! / plan_bfft!, src/plan.jl:45-46,57-58)
+    // rocFFT plans (plan_rfft / plan_brfft / plan_fft! / plan_bfft!, src/plan.jl:45-46,57-58): the general path only
     size_t lengths[3] = {1, 1, 1};
     for (int d = 0; d < D; ++d) lengths[d] = (size_t)p->Nover[d];
     const rocfft_precision prec = p->dtype == NUFFT_F32 ? rocfft_precision_single : rocfft_precision_double;
-    if (p->is_complex) {
-        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_fw, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec,
-                                        (size_t)D, lengths, (size_t)p->C, nullptr));
-        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_bw, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec,
-                                        (size_t)D, lengths, (size_t)p->C, nullptr));
-    } else {
-        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_fw, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec,
-                                        (size_t)D, lengths, (size_t)p->C, nullptr));
-        NUFFT_ROCFFT(rocfft_plan_create(&p->fft_bw, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec,
-                                        (size_t)D, lengths, (size_t)p->C, nullptr));
-    }
-    size_t wf = 0, wb = 0;
-    NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft_fw, &wf));
-    NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft_bw, &wb));
-    p->fft_work_bytes = std::max(wf, wb);
     NUFFT_ROCFFT(rocfft_execution_info_create(&p->fft_info));
-    if (p->fft_work_bytes > 0) {
-        if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes, "rocfft_work"))) return rc;
-        NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
+    if (!p->pruned_fft) {
+        if (p->is_complex) {
+            NUFFT_ROCFFT(rocfft_plan_create(&p->fft_fw, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec,
+                                            (size_t)D, lengths, (size_t)p->C, nullptr));
+            NUFFT_ROCFFT(rocfft_plan_create(&p->fft_bw, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec,
+                                            (size_t)D, lengths, (size_t)p->C, nullptr));
+        } else {
+            NUFFT_ROCFFT(rocfft_plan_create(&p->fft_fw, rocfft_placement_notinplace, rocfft_transform_type_real_forward, prec,
+                                            (size_t)D, lengths, (size_t)p->C, nullptr));
+            NUFFT_ROCFFT(rocfft_plan_create(&p->fft_bw, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, prec,
+                                            (size_t)D, lengths, (size_t)p->C, nullptr));
+        }
+        size_t wf = 0, wb = 0;
+        NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft_fw, &wf));
+        NUFFT_ROCFFT(rocfft_plan_get_work_buffer_size(p->fft_bw, &wb));
+        p->fft_work_bytes = std::max(wf, wb);
+        if (p->fft_work_bytes > 0) {
+            if ((rc = dev_alloc(p, &p->d_fft_work, p->fft_work_bytes, "rocfft_work"))) return rc;
+            NUFFT_ROCFFT(rocfft_execution_info_set_work_buffer(p->fft_info, p->d_fft_work, p->fft_work_bytes));
+        }
     }
 
-    // pruned FFT path: D >= 2, every higher dimension (and dimension 1 of complex plans) of an instantiated length
-    p->pruned_fft = D >= 2 && env_int("NUFFT_PRUNED_FFT", 1) != 0;
-    for (int d = p->is_complex ? 0 : 1; d < D && p->pruned_fft; ++d) p->pruned_fft = fft_lines_supported(p->dtype, p->Nover[d]);
-    p->pspec_elems = p->spec_elems;
-    if (p->pruned_fft && p->is_complex) {
-        // complex plans transform in place on the general path; the pruned passes work out of place with a compact
-        // spectrum (N1 kept modes per line of dimension 1)
-        p->pspec_elems = p->Nout[0];
-        for (int d = 1; d < D; ++d) p->pspec_elems *= p->Nover[d];
-        if ((rc = dev_alloc(p, &p->d_uhat, (size_t)p->pspec_elems * 2 * real_bytes(p) * p->C, "uhat"))) return rc;
-    }
-    if (p->pruned_fft && !p->is_complex) {
+    if (p->pruned_fft && !p->is_complex && !p->compact_dim1) {
         size_t len1[1] = {(size_t)p->Nover[0]};
         size_t batch = (size_t)p->C;
         for (int d = 1; d < D; ++d) batch *= (size_t)p->Nover[d];
@@ -642,7 +662,6 @@ static int build_device(nufft_plan* p) {
             rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_one, one) : upload<double>(p, &p->d_one, one);
             if (rc) return rc;
         }
-        p->compact_dim1 = p->is_complex || (real_lines_supported(p->dtype, p->Nover[0]) && env_int("NUFFT_COMPACT_DIM1", 1) != 0);
         for (int d = p->compact_dim1 ? 0 : 1; d < D; ++d) {
             const int64_t n = p->Nover[d];
             std::vector<double> twf(2 * (size_t)n), twb(2 * (size_t)n);
@@ -655,15 +674,6 @@ static int build_device(nufft_plan* p) {
             if (rc) return rc;
             rc = p->dtype == NUFFT_F32 ? upload<float>(p, &p->d_tw_bw[d], twb) : upload<double>(p, &p->d_tw_bw[d], twb);
             if (rc) return rc;
-        }
-        // row stride of the compact dimension-1 spectrum and of tmp2: the strided passes read groups of adjacent columns,
-        // 128 bytes per row — with rows of N1/2 + 1 = 129 elements every group straddled two cache lines (PMC: 1.6x the bytes
-        // read); real plans pad their intermediate rows to 128 bytes (the buffers of the general path are large enough)
-        p->spec_row = p->compact_dim1 ? p->Nout[0] : p->Nspec[0];
-        if (p->compact_dim1 && !p->is_complex && env_int("NUFFT_FFT_PAD_ROWS", 1) != 0) {
-            const int64_t q = 128 / (int64_t)(2 * real_bytes(p));
-            p->spec_row = (p->Nout[0] + q - 1) / q * q;
-            if (p->spec_row > p->Nspec[0]) p->spec_row = p->Nout[0];      // (cannot happen for sigma >= 1.25; keeps d_uhat's size)
         }
         if (D == 3) {
             const size_t elems = (size_t)(p->compact_dim1 ? p->spec_row : p->Nout[0]) * p->Nout[1] * p->Nover[2];
@@ -788,9 +798,16 @@ static int build_device(nufft_plan* p) {
     p->dense_available = p->spread_method == NUFFT_SPREAD_MARCHING_RING && env_int("NUFFT_DENSE", 1) != 0 && !needs_other_eval(p->kernel, p->evalmode) &&
                          spread_dense_available(p->dtype, p->is_complex, p->M, p->evalmode != NUFFT_EVAL_DIRECT, p->smarch);
     if (p->dense_available) NUFFT_HIP(prepare_spread_dense(p->dtype, p->M, p->evalmode != NUFFT_EVAL_DIRECT));
-    // break-even of the matrix pipe + one flush per bin against the stream of atomics, points per bin (measured: profiles/round6_*dense*)
-    static const int dense_min_default[7] = {0, 0, 16, 14, 10, 4, 2};
-    p->dense_min = env_int("NUFFT_DENSE_MIN", p->M <= 6 ? dense_min_default[p->M] : 1 << 30);
+    // Break-even against the stream of atomics, mean points per bin — measured (profiles/round6_dense_engine.md; 256^3 Float64, spread stage, ms, dense /
+    // atomic): m = 4 Direct() 3.69 / 2.97 at 19 per bin, 9.38 / 9.21 at 60; polynomial window 2.76 / 2.72 at 19, 6.66 / 8.40 at 60, and on the
+    // reference's folded N(0, 1) sets 4.52 / 5.57 at a mean of 19; m = 5 Direct() 6.38 / 4.13 at 4.8, 12.99 / 14.18 at 19, polynomial 5.05 / 3.91 and
+    // 8.79 / 13.27; m = 6 Direct() 7.70 / 6.48 and 15.80 / 22.61, polynomial 7.95 / 7.49 and 15.14 / 23.63; m = 2, 3 lose at 19 per bin (1.15 - 1.4 x).
+    // The FP64 matrix instructions run on the SIMD's FP64 vector ALUs (vector 37 % + matrix 25 % + LDS 32 % of the kernel's cycles ADD UP,
+    // counters in the same file): the engine only trades LDS-atomic time for vector time, which pays where a point costs 20 - 36 atomics
+    // (m = 5, 6) or the window evaluation is cheap (polynomial) and the bins are full.
+    static const int dense_min_direct[7] = {0, 0, 1 << 30, 1 << 30, 96, 16, 12};
+    static const int dense_min_poly[7] = {0, 0, 1 << 30, 1 << 30, 24, 10, 6};
+    p->dense_min = env_int("NUFFT_DENSE_MIN", p->M <= 6 ? (p->evalmode == NUFFT_EVAL_DIRECT ? dense_min_direct : dense_min_poly)[p->M] : 1 << 30);
 
     // every other 3-D plan: two-level slab sort (column_tasks.h) — the sorted array and offsets of the fine sort, without global atomics
     p->slab = CoarseSort{};
@@ -1015,7 +1032,7 @@ static int pruned_forward_fft(nufft_plan* p, hipStream_t stream, bool fuse) {
             const int64_t per = nlines / p->C;
             for (int c = 0; c < p->C; ++c) {
                 const void* in = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
-                void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
+                void* out = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * 2 * rb;
                 hh.buffer = static_cast<char*>(p->d_smarch_halo) + (size_t)c * p->smarch.halo_reals * rb;
                 NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], true, in, out, per, (int)p->Nout[0], (int)p->spec_row, p->d_tw_fw[0], stream,
                                             fuse ? &hh : nullptr));
@@ -1736,7 +1753,7 @@ int nufft_fft_backward(nufft_plan* p, void* stream_) {
         for (int d = 1; d < p->D; ++d) per *= p->Nover[d];
         const size_t rb = real_bytes(p);
         for (int c = 0; c < p->C; ++c) {
-            const void* in = static_cast<char*>(p->d_uhat) + (size_t)c * p->spec_elems * 2 * rb;
+            const void* in = static_cast<char*>(p->d_uhat) + (size_t)c * p->pspec_elems * 2 * rb;
             void* out = static_cast<char*>(p->d_us) + (size_t)c * p->grid_elems * rb;
             NUFFT_HIP(launch_real_lines(p->dtype, p->Nover[0], false, in, out, per, (int)p->Nout[0], (int)p->spec_row, p->d_tw_bw[0], stream));
         }
@@ -1840,7 +1857,7 @@ int nufft_grid_ptr(const nufft_plan* p, int which, int component, void** out_ptr
         *out_ptr = static_cast<char*>(p->d_us) + bytes * component;
         if (out_bytes) *out_bytes = (int64_t)bytes;
     } else if (which == 1 && !p->is_complex) {
-        const size_t bytes = (size_t)p->spec_elems * 2 * real_bytes(p);
+        const size_t bytes = (size_t)p->pspec_elems * 2 * real_bytes(p);      // (the compact spectrum on plans of the library's own FFT passes)
         *out_ptr = static_cast<char*>(p->d_uhat) + bytes * component;
         if (out_bytes) *out_bytes = (int64_t)bytes;
     } else {
@@ -1864,7 +1881,7 @@ int nufft_copy_grid(nufft_plan* p, int which, int component, void* dst, int64_t 
     if (component < 0 || component >= p->C) return fail(NUFFT_ERR_INVALID_ARG, "bad argument");
     if (which != 0 && !(which == 1 && !p->is_complex)) return fail(NUFFT_ERR_INVALID_ARG, "which must be 0 (us) or 1 (ûs, real plans only)");
     if (!dst) return fail(NUFFT_ERR_INVALID_ARG, "null destination");
-    const size_t bytes = which == 0 ? (size_t)p->grid_elems * value_bytes(p) : (size_t)p->spec_elems * 2 * real_bytes(p);
+    const size_t bytes = which == 0 ? (size_t)p->grid_elems * value_bytes(p) : (size_t)p->pspec_elems * 2 * real_bytes(p);
     if (capacity_bytes < (int64_t)bytes) return fail(NUFFT_ERR_DIM_MISMATCH, "destination buffer too small");
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);

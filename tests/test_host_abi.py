@@ -367,7 +367,7 @@ def test_gpu_parametrisations_are_eligible_by_construction(nufft, monkeypatch):
     spec = importlib.util.spec_from_file_location("gpu_parity_list", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
     src = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
     assert "pytest.skip(f\"no common column" not in src
-    body = src[src.index("COLUMN_LAYER_CASES = ["):src.index("@pytest.mark.parametrize(\"Z,M,C,evalmode\", COLUMN_LAYER_CASES)")]
+    body = src[src.index("COLUMN_LAYER_CASES = ["):src.index("@pytest.mark.parametrize(\"Z,M,C,evalmode\", COLUMN_LAYER_CASES")]
     from oracle import nufft_oracle as O
     ns = {"np": np, "O": O}
     exec(body, ns)
