@@ -150,6 +150,22 @@ __device__ __forceinline__ int xcd_remap_chunked(int b, int nblocks, int ch) {
     return ((k / ch) * 8 + xcd) * ch + k % ch;
 }
 
+// Workgroup barrier for LDS data only.  __syncthreads() is a workgroup-scope fence + barrier: the compiler puts s_waitcnt vmcnt(0) in front of
+// s_barrier, i.e. every wave waits until its outstanding GLOBAL stores have been acknowledged (on gfx9 stores count in vmcnt) — in the
+// z-marching kernels that is the latency of the retire pass's stores (or of the scattered value stores) once per bin layer, for data no
+// wave of the kernel ever reads back.  This barrier waits for the wave's LDS traffic only; loads that are still in flight are waited
+// for where their registers are used (the compiler keeps counting them across the asm).  NUFFT_LDS_BARRIER=0: __syncthreads() (A/B builds).
+#ifndef NUFFT_LDS_BARRIER
+#define NUFFT_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if NUFFT_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // Order LDS traffic of one wave without a workgroup barrier: LDS instructions of a wave complete
 // in issue order; this only stops the compiler from moving accesses across the point.
 __device__ __forceinline__ void wave_lds_fence() {

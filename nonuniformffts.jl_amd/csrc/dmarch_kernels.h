@@ -402,10 +402,10 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
             flush(cur_jb);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        lds_barrier();
 
 #include "smarch_retire.inc"
-        __syncthreads();
+        lds_barrier();
     }
 }
 

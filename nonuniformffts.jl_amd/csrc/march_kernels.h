@@ -250,7 +250,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_
             const PointRec<T, 3> rec = sorted[min(p, p1 - 1)];
 #include "march_gather.inc"
         }
-        __syncthreads();                                 // every wave has finished with this phase's window
+        lds_barrier();                                   // every wave has finished with this phase's window (no wait for the value stores)
         if (more) {
             if (tid == 0) counter[0] = 0;
             // the BZ new planes take the slots of the BZ oldest: slots pm .. pm + BZ - 1 (mod RZ)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY>::THREADS)) void interp_
             }
             pm += BZ;
             if (pm >= RZ) pm -= RZ;
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY, true>::THREADS)) void i
         int key = 0;
         uint32_t rank = 0u;
         if (has_next && mysub == 0 && myrec < next_n) { key = key_of(pc); rank = atomicAdd(&cnt[par * 64 + key], 1u); }
-        __syncthreads();                                 // every wave has finished with the stage (and, if the layer ends, with its window)
+        lds_barrier();                                   // every wave has finished with the stage (and, if the layer ends, with its window)
         if (!has_next) break;
         place_piece(pc, key, rank, next_n, cnt + par * 64);
         if (tid < 64) cnt[(par ^ 1) * 64 + tid] = 0u;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__((MarchCfg<T, CPLX, M, POLY, true>::THREADS)) void i
             if (pm >= RZ) pm -= RZ;
         }
         lay = nlay2; ch = nch2; cur_n = next_n; par ^= 1;
-        __syncthreads();
+        lds_barrier();
     }
 }
 

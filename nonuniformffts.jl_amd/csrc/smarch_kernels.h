@@ -562,10 +562,10 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         // the immediate-offset atomics are inline assembly: the compiler does not know that they are in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if NUFFT_SMARCH_ABL != 5
-        __syncthreads();
+        lds_barrier();
 
 #include "smarch_retire.inc"
-        __syncthreads();
+        lds_barrier();      // (not __syncthreads(): that would wait for the retire pass's global stores to be acknowledged, once per layer)
 #endif
     }
 }

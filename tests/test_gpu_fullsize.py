@@ -391,7 +391,9 @@ def test_dense_point_sets_match_c_oracle(Z, M, engine):
     oplan = O.OraclePlan((n, n, n), is_real=is_real, dtype=np.float64, coord_dtype=(np.float32 if T == np.float32 else None),
                          M=M, sigma=2.0, evalmode=O.FAST_APPROXIMATION)
     nufft.set_points(plan, tuple(torch.from_numpy(x).cuda() for x in xs))
-    assert plan.spread_engine_used() == engine
+    # (61 points per bin: on plans of the marching window set_points hands such a set to the window's dense-set engine — the matrix pipe
+    # accumulates a bin in registers, DESIGN.md section 4.12 — from 24 (m = 4) / 6 (m = 6) points per bin on with the polynomial window)
+    assert plan.spread_engine_used() == (engine + "_dense" if engine == "marching_ring" and M >= 4 else engine)
     O.set_points(oplan, xs)
     wide = np.float64 if is_real else np.complex128
     u = torch.empty(plan.shape, dtype=plan.eltype, device="cuda")
