@@ -300,8 +300,16 @@ __global__ __launch_bounds__(256) void coarse_clear_kernel(Geom g, CoarseGeom c,
 template <typename T>
 __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(BinArgs<T, 3> a, CoarseGeom c, const uint32_t* __restrict__ table,
                                                                        const uint32_t* __restrict__ offsets, PointRec<T, 3>* __restrict__ sorted,
-                                                                       uint32_t* __restrict__ counts, const uint32_t* fa, const uint32_t* fb) {
+                                                                       uint32_t* __restrict__ counts, const uint32_t* fa, const uint32_t* fb,
+                                                                       const uint32_t* ra, const uint32_t* rb, uint32_t* feedback, uint32_t seq) {
     extern __shared__ uint32_t cursor[];
+    if (feedback && blockIdx.x == 0 && threadIdx.x == 0) {
+        // what the rings decided for this point set, for the host's choice of sort at the NEXT set_points (host-mapped memory, no synchronisation)
+        __atomic_store_n(&feedback[0], *ra, __ATOMIC_RELAXED);
+        __atomic_store_n(&feedback[1], *rb, __ATOMIC_RELAXED);
+        __threadfence_system();
+        __atomic_store_n(&feedback[2], seq, __ATOMIC_RELAXED);
+    }
     if (*fa == 0u || *fb == 0u) return;                 // fine sort
     const int tid = threadIdx.x, w = blockIdx.x;
     const uint32_t* row = table + (size_t)w * c.nkeys;
@@ -516,7 +524,8 @@ static hipError_t coarse_finish_t(const SortArgs& s, hipStream_t stream) {
     if (e != hipSuccess) return e;
     // (slab sort: level 1 leaves its records in the temporary array, level 2 sorts every slab by fine bin into `sorted`)
     hipLaunchKernelGGL((coarse_scatter_kernel<T>), dim3((unsigned)s.cs.groups), dim3(kCoarseThreads), (size_t)c.nkeys * 4, stream, a, c, s.cs.table, s.offsets,
-                       static_cast<PointRec<T, 3>*>(s.cs.mode == 2 ? s.cs.temp : s.sorted), s.counts, fa, fb);
+                       static_cast<PointRec<T, 3>*>(s.cs.mode == 2 ? s.cs.temp : s.sorted), s.counts, fa, fb, s.cs.fb_a, s.cs.fb_b,
+                       (s.cs.fb_a && s.cs.fb_b) ? s.cs.feedback : (uint32_t*)nullptr, s.cs.seq);
     if (s.cs.mode == 2)
         hipLaunchKernelGGL((slab_sort_kernel<T>), dim3((unsigned)c.nkeys), dim3(kSlabThreads), (size_t)s.cs.lds2, stream, s.g, c, s.cs.cap,
                            static_cast<const PointRec<T, 3>*>(s.cs.temp), static_cast<PointRec<T, 3>*>(s.sorted), s.offsets, fa);
@@ -526,6 +535,18 @@ static hipError_t coarse_finish_t(const SortArgs& s, hipStream_t stream) {
         hipLaunchKernelGGL((bin_scatter_kernel<T, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, a, s.offsets, static_cast<const uint2*>(s.binrank),
                            static_cast<PointRec<T, 3>*>(s.sorted), s.counts, s.g.nbins + 1, fa, fb);
     }
+    return hipGetLastError();
+}
+
+// the rings' decisions for the host's next choice of sort, where no scatter pass of the column-layer sort carries them (CoarseSort::feedback)
+__global__ void sort_feedback_kernel(const uint32_t* ra, const uint32_t* rb, uint32_t* feedback, uint32_t seq) {
+    __atomic_store_n(&feedback[0], *ra, __ATOMIC_RELAXED);
+    __atomic_store_n(&feedback[1], *rb, __ATOMIC_RELAXED);
+    __threadfence_system();
+    __atomic_store_n(&feedback[2], seq, __ATOMIC_RELAXED);
+}
+hipError_t launch_sort_feedback(const uint32_t* ra, const uint32_t* rb, uint32_t* feedback, uint32_t seq, hipStream_t stream) {
+    hipLaunchKernelGGL(sort_feedback_kernel, dim3(1), dim3(1), 0, stream, ra, rb, feedback, seq);
     return hipGetLastError();
 }
 

@@ -88,6 +88,12 @@ struct CoarseSort {
     void* temp;
     int cap, lds2;
     uint32_t* flagmem;
+    // feedback of the device-side decisions to the host, without a synchronisation: workgroup 0 of the scatter pass writes {ring flag a, ring flag b,
+    // sequence number} into host-mapped memory; the NEXT set_points reads whatever has arrived (plan.cpp: adaptive sort choice)
+    const uint32_t* fb_a;
+    const uint32_t* fb_b;
+    uint32_t* feedback;
+    uint32_t seq;
 };
 // Two-level fine sort (mode 2; plans without a column-layer sort, D = 3): the same two passes with a SLAB of bins as the key — cbx = nb[0]
 // (one column along x), cby rows of bins, one layer: a contiguous range of fine bins — into a temporary array; then one workgroup per slab

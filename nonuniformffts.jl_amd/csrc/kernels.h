@@ -39,6 +39,7 @@ int slab_sort_lds_bytes(int dtype, int cap);
 hipError_t prepare_binsort_slab(int dtype, int lds_bytes);
 hipError_t launch_binsort_coarse_count(const SortArgs& s, hipStream_t stream);
 hipError_t launch_binsort_coarse_finish(const SortArgs& s, hipStream_t stream);
+hipError_t launch_sort_feedback(const uint32_t* ra, const uint32_t* rb, uint32_t* feedback, uint32_t seq, hipStream_t stream);
 // zero fill by a kernel (hipGraph-safe, see binsort.hip); dst 16-byte aligned, bytes a multiple of 4
 hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);
 hipError_t launch_extract_perm(int dtype, int D, const void* sorted, int64_t np, int32_t* perm_dev, hipStream_t stream);

@@ -177,6 +177,15 @@ struct nufft_plan {
                                        // the slab height chosen per point set (nufft_set_points)
     int slab_fill = 85;                // a slab's average load, percent of what a level-2 workgroup holds, at most (NUFFT_SLAB_FILL)
     int64_t slab_min_points = 0;       // smaller point sets take the fine sort with global atomics (NUFFT_SLAB_MIN_POINTS)
+    // adaptive sort choice on plans of the column-layer sort: the rings' per-point-set decisions come back through host-mapped memory
+    // (CoarseSort::feedback); after two point sets in a row that a ring handed to the tile kernels (the column-layer attempt then ends in the
+    // fine sort with global atomics: 1.8 ms at 1.7e7 folded-normal points against 1.1 ms for the slab sort) set_points takes the slab sort
+    // directly, and returns to the column-layer sort as soon as both rings would serve a set again
+    uint32_t* sort_feedback = nullptr;       // host-mapped {flag a, flag b, sequence}
+    uint32_t sort_seq = 0, sort_seq_seen = 0;
+    int sort_miss_streak = 0;
+    bool sort_prefer_slab = false;
+    bool coarse_now = false;                 // the current point set went through the column-layer path (set_points)
     bool dense_available = false;      // the spreading window's dense-set engine exists for this plan (dmarch_kernels.h)
     bool dense_now = false;            // ... and serves the current point set (set_points: mean bin load >= dense_min)
     int dense_min = 1 << 30;

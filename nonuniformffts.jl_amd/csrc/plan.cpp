@@ -811,7 +811,7 @@ static int build_device(nufft_plan* p) {
 
     // every other 3-D plan: two-level slab sort (column_tasks.h) — the sorted array and offsets of the fine sort, without global atomics
     p->slab = CoarseSort{};
-    if (D == 3 && (!p->coarse.enabled || p->dense_available) && env_int("NUFFT_SLAB_SORT", 1) != 0 && p->tile.nb[0] <= kSlabMaxBins && p->tile.nb[2] <= kCoarseMaxKeys) {
+    if (D == 3 && env_int("NUFFT_SLAB_SORT", 1) != 0 && p->tile.nb[0] <= kSlabMaxBins && p->tile.nb[2] <= kCoarseMaxKeys) {
         p->slab.enabled = 1;
         p->slab.mode = 2;
         p->slab_min_points = env_int("NUFFT_SLAB_MIN_POINTS", 16384);
@@ -826,6 +826,12 @@ static int build_device(nufft_plan* p) {
         NUFFT_HIP(prepare_binsort_slab(p->dtype, kLdsLimit - 256));
     }
 
+    if (p->coarse.enabled && p->slab.enabled && env_int("NUFFT_SORT_ADAPTIVE", 1) != 0) {
+        // (host-mapped: the scatter pass writes the rings' decisions here, set_points reads them without synchronising — nufft_internal.h)
+        NUFFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->sort_feedback), 16, hipHostMallocMapped));
+        p->sort_feedback[0] = p->sort_feedback[1] = 1u;
+        p->sort_feedback[2] = 0u;
+    }
     if (p->spread_method == NUFFT_SPREAD_MFMA_PATCHES || p->spread_method == NUFFT_SPREAD_MARCHING_RING || p->interp_march) NUFFT_HIP(prepare_column_tasks());
 
     for (int s = 0; s < NUFFT_NUM_STAGES; ++s) {
@@ -844,6 +850,7 @@ static void release(nufft_plan* p) {
     if (p->device >= 0) {
         DeviceGuard guard(p->device);
         (void)hipDeviceSynchronize();
+        if (p->sort_feedback) (void)hipHostFree(p->sort_feedback);
         for (auto& al : p->allocs) (void)hipFree(al.first);      // every device buffer of the plan (dev_alloc)
         p->allocs.clear();
         if (p->fft1_fw) (void)rocfft_plan_destroy(p->fft1_fw);
@@ -902,7 +909,7 @@ static TileKernelArgs tile_args(const nufft_plan* p, bool interp) {
     a.fixed_tile = interp ? p->interp_fixed : p->spread_fixed;
     a.march = interp && p->interp_march;      // (the ring applies per-point weights itself)
     a.interp_parts = p->interp_parts;
-    a.coarse = p->coarse.enabled && !p->dense_now;      // (a dense point set of a column-layer plan was sorted by fine bins: the plain ring gathers it)
+    a.coarse = p->coarse_now;      // (a dense point set of a column-layer plan, or one behind two clustered ones, was sorted by fine bins: the plain ring gathers it)
     a.coarse_a = p->coarse.flag_a;
     a.coarse_b = p->coarse.flag_b;
     a.march_ct = p->march_ct;
@@ -1344,7 +1351,21 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     {
         // scratch of the sort this point set takes: {bin, rank} of the fine sort (8 bytes per point; also what a clustered set of a
         // column-layer plan falls back to, decided on the device), or the level-1 records of the slab sort
-        const bool slab_scratch = p->slab.enabled && (!p->coarse.enabled || p->dense_now);
+        // adaptive choice (nufft_internal.h: sort_feedback): what the rings decided for the point sets before this one
+        if (p->sort_feedback) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+            if (!capturing) (void)hipGetLastError();
+            const uint32_t seq = __atomic_load_n(&p->sort_feedback[2], __ATOMIC_ACQUIRE);
+            if (!capturing && seq != p->sort_seq_seen && seq == p->sort_seq) {      // the record of the latest point set has arrived: count it once
+                p->sort_seq_seen = seq;
+                const bool both = p->sort_feedback[0] != 0u && p->sort_feedback[1] != 0u;
+                if (both) { p->sort_miss_streak = 0; p->sort_prefer_slab = false; }
+                else if (++p->sort_miss_streak >= 2) p->sort_prefer_slab = true;
+            }
+        }
+        p->coarse_now = p->coarse.enabled && !p->dense_now && !(p->sort_prefer_slab && p->slab.enabled);
+        const bool slab_scratch = p->slab.enabled && !p->coarse_now;
         const int64_t need = np * binrank_bytes(p, slab_scratch);
         if (need > p->binrank_capacity) {
             dev_free(p, p->d_binrank);
@@ -1373,8 +1394,12 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
     s.scan_tmp = p->d_scan_tmp;
     s.scan_tmp_bytes = p->scan_tmp_bytes;
     s.cs = p->coarse;
-    const bool coarse = p->coarse.enabled != 0 && !p->dense_now;
+    const bool coarse = p->coarse_now;
     if (p->coarse.enabled && !coarse) s.cs = CoarseSort{};
+    if (coarse && p->sort_feedback) {      // (the scatter pass of the column-layer sort reports the rings' decisions: it runs behind their task kernels)
+        s.cs.fb_a = p->coarse.flag_a; s.cs.fb_b = p->coarse.flag_b;
+        s.cs.feedback = p->sort_feedback; s.cs.seq = ++p->sort_seq;
+    }
     bool slab = false;
     if (!coarse && p->slab.enabled && np >= std::max<int64_t>(p->slab_min_points, 1)) {
         // slab height for this point set: the tallest slab (longest runs in level 1: C3 `set_points` 5.2 ms with 32 768 slabs, 4.4 ms with 16 384)
@@ -1501,6 +1526,9 @@ int nufft_set_points(nufft_plan* p, int64_t np, const void* const* coords, void*
         // both rings have decided: column-layer scatter, or the fine sort for a point set one of them hands to the tile kernels
         NUFFT_HIP(launch_binsort_coarse_finish(s, stream));
         if ((rc = balance())) return rc;
+    } else if (p->sort_feedback && p->coarse.enabled && !p->dense_now) {
+        // a plan of the column-layer sort on the slab sort (the sets before this one went to the tile kernels): what the rings say about THIS set
+        NUFFT_HIP(launch_sort_feedback(p->coarse.flag_a, p->coarse.flag_b, p->sort_feedback, ++p->sort_seq, stream));
     }
     if (p->debug_tasks) {
         // development check: every column's tasks tile [0, nb[2]) without gaps or overlaps
@@ -1568,7 +1596,7 @@ int nufft_sort_columns_used(nufft_plan* p, int* used_out, void* stream_) {
     DeviceGuard guard(p->device);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t fa = 0, fb = 0;
-    if (p->slab.enabled && (!p->coarse.enabled || p->dense_now)) {
+    if (p->slab.enabled && !p->coarse_now) {
         NUFFT_HIP(hipMemcpyAsync(&fa, p->slab.flag_a, sizeof(fa), hipMemcpyDeviceToHost, stream));
         NUFFT_HIP(hipStreamSynchronize(stream));
         *used_out = fa != 0 ? 2 : 0;

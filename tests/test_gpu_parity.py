@@ -852,6 +852,51 @@ def test_column_layer_sort_falls_back_to_fine_bins_for_clustered_points(monkeypa
     assert q.info().sort_column[0] == 0
 
 
+def test_adaptive_sort_choice_follows_the_rings_decisions(monkeypatch):
+    """Plans of the column-layer sort (round 6: most 3-D plans): a point set that a ring hands to the tile kernels ends its column-layer attempt in
+    the fine sort with global atomics (1.8 ms at 1.7e7 folded-normal points against 1.1 ms for the slab sort).  The rings' decisions come back to
+    the host through host-mapped memory (no synchronisation); after TWO such sets in a row set_points takes the slab sort directly, and goes back
+    to the column-layer sort once both rings would serve a set again (plan.cpp, nufft_internal.h: sort_feedback).  Every set, whichever sort it
+    took, transforms correctly (types 1 and 2 against the oracle)."""
+    for var in ("NUFFT_INTERP_MARCH", "NUFFT_SPREAD_METHOD", "NUFFT_PREFER_RING", "NUFFT_PREFER_PATCHES", "NUFFT_SMARCH_ADVANTAGE", "NUFFT_COARSE_SORT",
+                "NUFFT_SMARCH_HALO", "NUFFT_SORT_ADAPTIVE"):
+        monkeypatch.delenv(var, raising=False)
+    dims, Np = (256, 256, 32), 120000
+    nufft, plan, oplan, xs, vs = _make_case(np.float64, dims, 4, 2.0, O.DIRECT, 1, Np, seed=79)
+    assert plan.info().sort_column[0] > 0
+    dev = plan.device
+    u = torch.empty(plan.shape, dtype=plan.eltype, device=dev)
+    out = torch.empty(Np, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(8)
+    w = rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)
+    corner = tuple((0.05 * x).astype(x.dtype) for x in xs)
+    #            point set   sort the host enqueues / the device ends up with
+    script = [("uniform", xs, "column_layers"),
+              ("corner", corner, "fine_bins"),       # column-layer attempt, the device falls back (first miss)
+              ("corner", corner, "fine_bins"),       # second miss in a row ...
+              ("corner", corner, "slabs"),           # ... now the slab sort directly
+              ("corner", corner, "slabs"),
+              ("uniform", xs, "slabs"),              # still the slab sort (the host cannot know), but both rings serve the set:
+              ("uniform", xs, "column_layers"),      # back to the column-layer sort
+              ("corner", corner, "fine_bins")]       # and a single clustered set does not switch
+    for step, (name, pts, want) in enumerate(script):
+        nufft.set_points(plan, tuple(torch.from_numpy(x).to(dev) for x in pts))
+        torch.cuda.synchronize()                     # (the feedback record of this set has arrived before the next set_points looks)
+        assert plan.sort_method_used() == want, (step, name, plan.sort_method_used())
+        O.set_points(oplan, pts)
+        nufft.exec_type1(u, plan, torch.from_numpy(vs[0]).to(dev))
+        assert _rel(u.cpu().numpy(), O.exec_type1(oplan, vs[0])) < 1e-7, (step, name)
+        nufft.exec_type2(out, plan, torch.from_numpy(w).to(dev))
+        assert _rel(out.cpu().numpy(), O.exec_type2(oplan, w)) < 1e-7, (step, name)
+    # with the switch off the fallback stays the fine sort
+    monkeypatch.setenv("NUFFT_SORT_ADAPTIVE", "0")
+    q = nufft.PlanNUFFT(np.float64, dims, m=4, sigma=2.0, backend=nufft.ROCBackend(0))
+    for _ in range(4):
+        nufft.set_points(q, tuple(torch.from_numpy(x).to(dev) for x in corner))
+        torch.cuda.synchronize()
+        assert q.sort_method_used() == "fine_bins"
+
+
 def test_halo_side_buffer_allocation_failure_keeps_the_ring(monkeypatch):
     """when the side buffer (half a grid per component) cannot be allocated the plan keeps the ring with clipped
     columns instead of failing (NUFFT_TEST_HALO_ALLOC_FAIL simulates the failure)."""
