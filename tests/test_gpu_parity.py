@@ -869,7 +869,8 @@ def test_adaptive_sort_choice_follows_the_rings_decisions(monkeypatch):
     out = torch.empty(Np, dtype=torch.float64, device=dev)
     rng = np.random.default_rng(8)
     w = rng.standard_normal(plan.shape) + 1j * rng.standard_normal(plan.shape)
-    corner = tuple((0.05 * x).astype(x.dtype) for x in xs)
+    # (a quarter of every axis: a ring declines the set, and its fullest slab still fits the slab sort's second level)
+    corner = tuple((0.25 * np.mod(x, 2 * np.pi)).astype(x.dtype) for x in xs)
     #            point set   sort the host enqueues / the device ends up with
     script = [("uniform", xs, "column_layers"),
               ("corner", corner, "fine_bins"),       # column-layer attempt, the device falls back (first miss)
