@@ -18,6 +18,9 @@ const void* patch32_kernel_f32c(int M, bool other, int* lds_bytes, int* pby) {
     *pby = 0;
     if (other) return nullptr;      // the remaining window kernels and per-point weights use the LDS-tile kernel
     switch (M) {
+#if defined(NUFFT_PATCH32_ONLY_M)       // development builds: one instantiation (compile time)
+        case NUFFT_PATCH32_ONLY_M: patch32_entry<NUFFT_PATCH32_ONLY_M>(&fn, lds_bytes, pby); break;
+#else
         case 2: patch32_entry<2>(&fn, lds_bytes, pby); break;
         case 3: patch32_entry<3>(&fn, lds_bytes, pby); break;
         case 4: patch32_entry<4>(&fn, lds_bytes, pby); break;
@@ -27,6 +30,7 @@ const void* patch32_kernel_f32c(int M, bool other, int* lds_bytes, int* pby) {
         case 8: patch32_entry<8>(&fn, lds_bytes, pby); break;
         case 9: patch32_entry<9>(&fn, lds_bytes, pby); break;
         case 10: patch32_entry<10>(&fn, lds_bytes, pby); break;
+#endif
         default: break;
     }
     return fn;

@@ -415,6 +415,220 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
 #if defined(NUFFT_PATCH_PROFILE)
     unsigned long long nmfma = 0, nbatchcol = 0, nbatch = 0;
 #endif
+#ifndef NUFFT_PATCH32_PIPE
+#define NUFFT_PATCH32_PIPE 0            // 1: the travelling-work loop below (round 6 experiment: measured slower, see its header); 0: round 5's K-batch loop
+#endif
+#if NUFFT_PATCH32_PIPE
+    // ---- EXPERIMENT (round 6, review item 4a; NUFFT_PATCH32_PIPE=1 builds it; parity-green, lint-clean, SLOWER — kept for the record).
+    //      K-batches of four points with the non-matrix work of a batch moved into the gaps between its matrix instructions:
+    //        column 1               | addresses of batch i + 1's operand reads and of batch i + 2's meta data, a slice per gap
+    //        READS                  | the one issue site (registers an inline-assembly read has been issued into must not meet at a join)
+    //        columns 0 and 3
+    //        column 2               | its first row covers the reads; then the wait and batch i + 1's operands, in place: columns 0 and 1 of a
+    //                               | row behind the row's last matrix instruction, columns 2 and 3 a gap later (column 2 read them at issue)
+    //      The premise — an instruction behind a v_mfma issues while it runs — does not hold for v_mfma_f32_16x16x4_f32: it forms its 1024 products
+    //      in 32 cycles = 64 FLOP per cycle and SIMD, exactly the rate of v_pk_fma_f32: the FP32 matrix instruction runs on the vector ALUs
+    //      (as v_mfma_f64_16x16x4 does on the FP64 ones), so vector work between two of them adds its full time.
+    //      Measured, C3 spread stage (profiles/round6_c3_patch32_phases.md; round 5's loop 75.0 ms, batches phase 1.15e11 wave cycles):
+    //        one triangle per cube ROW, the work between the triangles, operands by v_pk_mul_f32      81.3 ms
+    //        the same with v_mul_f32 (a packed Float32 instruction beside matrix instructions is dearer)   80.8 ms
+    //        one triangle per column, the work in its gaps (this code)                                 82.2 ms, batches phase 1.29e11
+    //      — every form pays for what it adds (scalar multiplies instead of packed ones, the second triangle, pins) and hides nothing.
+    auto batches = [&](auto RBc, int n) __attribute__((always_inline)) {
+        constexpr int RB = decltype(RBc)::value - CHI;                 // relative bin row: cube rows RB + CLO .. RB + CHI
+        constexpr int NV = [] { int c = 0; for (int o = 0; o < NCB; ++o) c += (RB + CLO + o >= 0 && RB + CLO + o < PBY) ? 1 : 0; return c; }();
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i m;
+        float vsel;                                                    // component bcl of the point's value
+        v2f32 w3p[(NOB + 1) / 2], w2p[(NCB + 1) / 2], w1p[PBX / 2];      // operand values in register pairs (ds_read2_b32)
+        const uint32_t vsel_off = (uint32_t)bcl * 4u;
+        // what the gaps of column 1 prepare for the reads (slices of at most four vector instructions: the shadow of one matrix instruction
+        // hides about five; every slice is pinned where it is written, or the optimiser sinks it across the matrix blocks to its use)
+        uint32_t pbn = 0u, az = 0u, ay = 0u, ax = 0u, am = 0u, nmask = 0u;
+        int pidx_n = 0, pidx_m = 0;
+        float vnext = 0.f;
+        constexpr int NSL = 5;
+        auto pre_slice = [&](int S, int b0) __attribute__((always_inline)) {
+            if (S == 0) {
+                pidx_n = b0 + 4 + mk < n ? b0 + 4 + mk : CH;
+                pidx_m = b0 + 8 + mk < n ? b0 + 8 + mk : CH;
+                asm volatile("" : "+v"(pidx_n), "+v"(pidx_m));
+            } else if (S == 1) {
+                pbn = wbase + (uint32_t)(pidx_n * PSTRIDE);
+                az = pbn + WZ + (uint32_t)m.z + (uint32_t)bzl * 4;    // octets: 8 planes apart
+                asm volatile("" : "+v"(pbn), "+v"(az));
+            } else if (S == 2) {
+                ay = pbn + WY + (uint32_t)m.y + (uint32_t)mb * 4;     // cube rows: 4 cells apart
+                ax = pbn + WX + (uint32_t)m.x + (uint32_t)mi * 4;     // cube columns of the patch
+                vnext = vsel;
+                asm volatile("" : "+v"(ay), "+v"(ax), "+v"(vnext));
+            } else if (S == 3) {
+                const int nvalid = max(1, min(4, n - (b0 + 4)));
+                const int lo = max(__builtin_amdgcn_readlane(m.w, 0) + CLO, 0);
+                const int hi = min(__builtin_amdgcn_readlane(m.w, 16 * (nvalid - 1)) + CHI, PBX - 1);
+                nmask = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+                asm volatile("" : "+s"(nmask));
+            } else {
+                am = wbase + (uint32_t)(pidx_m * PSTRIDE + MT);
+                asm volatile("" : "+v"(am));
+            }
+        };
+        auto reads = [&]() __attribute__((always_inline)) {
+            lds_read_strided<NOB, 8>(w3p, az);
+            lds_read_strided<NCB, 4>(w2p, ay);
+            lds_read_strided<PBX, 4>(w1p, ax);
+            const uint32_t amv = am + vsel_off;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(m) : "v"(am));
+            asm volatile("ds_read_b32 %0, %1 offset:16" : "=v"(vsel) : "v"(amv));
+        };
+        auto wait_all = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(m), "+v"(vsel));
+#pragma unroll
+            for (int s = 0; s < (NOB + 1) / 2; ++s) asm volatile("" : "+v"(w3p[s]));
+#pragma unroll
+            for (int o = 0; o < (NCB + 1) / 2; ++o) asm volatile("" : "+v"(w2p[o]));
+#pragma unroll
+            for (int cx = 0; cx < PBX / 2; ++cx) asm volatile("" : "+v"(w1p[cx]));
+        };
+        // operands of a batch: A = w1 w2 per cube column and row, B = v w3 per octet.  One v_mul_f32 each, NOT v_pk_mul_f32: a packed Float32
+        // instruction next to matrix instructions costs ~22 cycles more than two plain ones (MI355X_MICROARCH.md, "price of one filler") — the first
+        // version of this loop built the operands in pairs and ran 8 % slower than round 5's (C3 spread 81.3 against 75.0 ms).
+        float Af[NCB][PBX], Bf[NOB];
+        auto build_A = [&](int o, int pr) __attribute__((always_inline)) {
+            // (inline assembly: pinned where it is written, and the vectoriser cannot pack it with a neighbour)
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(Af[o][2 * pr]) : "v"(w1p[pr][0]), "v"(w2p[o / 2][o % 2]));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(Af[o][2 * pr + 1]) : "v"(w1p[pr][1]), "v"(w2p[o / 2][o % 2]));
+        };
+        auto build_B = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < NOB; ++s) {
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(Bf[s]) : "v"(w3p[s / 2][s % 2]), "v"(vnext));
+            }
+        };
+        auto row_valid = [](int o) __attribute__((always_inline)) -> bool { return RB + CLO + o >= 0 && RB + CLO + o < PBY; };
+        auto mfma_one = [&](int cx, int o, int s) __attribute__((always_inline)) {
+            constexpr int dummy = 0;
+            const int col = (RB + CLO + o) * PBX + cx;
+            if (col < NCA) mfma_acc<true>(accA[s][col < NCA ? col : dummy], Af[o][cx], Bf[s]);
+            else mfma_acc<false>(accV[s][col >= NCA ? col - NCA : dummy], Af[o][cx], Bf[s]);
+        };
+        // rows [first, last) (ordinals among the valid rows) of a cube column, nothing in the gaps
+        auto column_rows = [&](int cx, int first, int last) __attribute__((always_inline)) {
+            int ord = 0;
+#pragma unroll
+            for (int o = 0; o < NCB; ++o) {
+                if (!row_valid(o)) continue;
+                if (ord >= first && ord < last) {
+#pragma unroll
+                    for (int s = 0; s < NOB; ++s) mfma_one(cx, o, s);
+                }
+                ++ord;
+            }
+        };
+#if defined(NUFFT_PATCH_PROFILE)
+#define NUFFT_P32_COUNT(rows) do { nmfma += (unsigned long long)((rows) * NOB); nbatchcol += 1; } while (0)
+#else
+#define NUFFT_P32_COUNT(rows) do { } while (0)
+#endif
+        // ---- prologue: meta data of batch 0; operand reads of batch 0 and meta data of batch 1; operands of batch 0 ----
+        {
+            const int pidx = mk < n ? mk : CH;
+            am = wbase + (uint32_t)(pidx * PSTRIDE + MT);
+            const uint32_t amv = am + vsel_off;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(m) : "v"(am));
+            asm volatile("ds_read_b32 %0, %1 offset:16" : "=v"(vsel) : "v"(amv));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(m), "+v"(vsel));
+        }
+#pragma unroll
+        for (int S = 0; S < NSL; ++S) pre_slice(S, -4);
+        reads();
+        wait_all();
+#pragma unroll
+        for (int o = 0; o < NCB; ++o)
+            if (row_valid(o)) { build_A(o, 0); build_A(o, 1); }
+        build_B();
+        uint32_t mask = nmask;
+#pragma unroll 1
+        for (int b0 = 0; b0 < n; b0 += 4) {
+#if defined(NUFFT_PATCH_PROFILE)
+            nbatch += 1;
+#endif
+            // (a column's matrix instructions sit in ONE triangle — `if (column in the mask) { ... }` — with the travelling work in its gaps, at
+            // most five instructions per gap: a lone wave issues an instruction of any kind every ~4 cycles and a matrix instruction runs 32.  The batch
+            // that skips the column does the same work in a second triangle — not an else arm: around a diamond the register allocator copied
+            // every accumulator.  The conditions are opaque, or the compiler threads the two triangles back into one diamond.  Measured on the
+            // way (C3 spread, round 5's loop 75.0 ms): one triangle per ROW with the work between the triangles 80.8 ms — three scalar instructions
+            // per triangle and the work of a row in one gap overflow the gaps.)
+            auto has_col = [&](uint32_t bit) __attribute__((always_inline)) -> bool {
+                uint32_t mm = mask;
+                asm volatile("" : "+s"(mm));
+                return (mm & bit) != 0u;
+            };
+            // ---- column 1: the addresses of the next reads in its gaps ----
+            if (has_col(2u)) {
+                NUFFT_P32_COUNT(NV);
+                constexpr int K1 = NV * NOB;
+                int gap = 0;
+#pragma unroll
+                for (int o = 0; o < NCB; ++o) {
+                    if (!row_valid(o)) continue;
+#pragma unroll
+                    for (int s = 0; s < NOB; ++s) {
+                        mfma_one(1, o, s);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int S = 0; S < NSL; ++S)
+                            if ((K1 >= NSL ? S * (K1 / NSL) : S * K1 / NSL) == gap) pre_slice(S, b0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++gap;
+                    }
+                }
+            }
+            if (!has_col(2u)) {
+#pragma unroll
+                for (int S = 0; S < NSL; ++S) pre_slice(S, b0);
+            }
+            reads();
+            if (mask & 1u) { NUFFT_P32_COUNT(NV); column_rows(0, 0, NV); }
+            if (mask & 8u) { NUFFT_P32_COUNT(NV); column_rows(3, 0, NV); }
+            // ---- column 2: the reads land behind its first row; then the operands of the next batch in its gaps — columns 0 and 1 of a row
+            //      behind the row's last matrix instruction, columns 2 and 3 a gap later (column 2 read them at issue) ----
+            if (has_col(4u)) {
+                NUFFT_P32_COUNT(NV);
+                int prev = -1;
+#pragma unroll
+                for (int o = 0; o < NCB; ++o) {
+                    if (!row_valid(o)) continue;
+#pragma unroll
+                    for (int s = 0; s < NOB; ++s) {
+                        mfma_one(2, o, s);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s == 0 && prev >= 0) build_A(prev, 1);
+                        if (s == NOB - 1) {
+                            if (prev < 0) wait_all();
+                            build_A(o, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    prev = o;
+                }
+                if (prev >= 0) build_A(prev, 1);
+                build_B();
+            }
+            if (!has_col(4u)) {
+                wait_all();
+#pragma unroll
+                for (int o = 0; o < NCB; ++o)
+                    if (row_valid(o)) { build_A(o, 0); build_A(o, 1); }
+                build_B();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (no path without a wait, whatever the opaque conditions: the build's lint follows the control flow)
+            mask = nmask;
+        }
+    };
+#else
     // ---- K-batches of four points (k = lane >> 4; the all-zero point pads the last one), software-pipelined as in
     //      spread_patch_kernel: the LDS reads of batch i + 1 (operands) and i + 2 (meta data) fly while batch i's MFMAs issue
     auto batches = [&](auto RBc, int n) __attribute__((always_inline)) {
@@ -519,6 +733,8 @@ __global__ __launch_bounds__(kPatchWaves * kWave, NUFFT_PATCH32_OCC) void spread
             wait_all();
         }
     };
+
+#endif
 
 #if defined(NUFFT_PATCH_PROFILE)
     unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();

@@ -61,6 +61,9 @@
 
 namespace nufft {
 
+#ifndef NUFFT_SMARCH_DEFER
+#define NUFFT_SMARCH_DEFER 0        // 1: the retire pass's global stores issued behind its second barrier (experiment, round 6)
+#endif
 #ifndef NUFFT_SMARCH_ABL
 #define NUFFT_SMARCH_ABL 0          // ablation builds: 1 = no LDS atomics, 2 = no point visits, 3 = no retire stores, 4 = no shift
 #endif
@@ -318,6 +321,10 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     const HaloLayout hl = make_halo_layout(mg.n1, mg.n2, M, NC, mg.ntx, mg.nty);
     __syncthreads();
 
+#if NUFFT_SMARCH_DEFER
+    typedef double HeldD2 __attribute__((ext_vector_type(2)));
+    HeldD2 held[4];
+#endif
     for (int li = 0; li < nli; ++li) {
         // ---- the runs of this layer (requested a layer ago): chunks per run, inclusive scan over the lanes ----
         const uint32_t p0_l = nx0, p1_l = nx1;
@@ -564,8 +571,26 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
 #if NUFFT_SMARCH_ABL != 5
         lds_barrier();
 
+#if NUFFT_SMARCH_DEFER
+        // (experiment, round 6: the stores of the finished planes — address arithmetic and issue — behind the second barrier, next to the
+        // next layer's first chunks, instead of between the barriers where every wave waits for them)
+        const bool defer = wny * ((NC * wnx + 1) / 2) <= THREADS;
+        if (defer) {
+#define NUFFT_RETIRE_SECTION 1
+#include "smarch_retire.inc"
+        } else {
+#include "smarch_retire.inc"
+        }
+        lds_barrier();
+        if (defer) {
+            const int held_wq = wq;
+#define NUFFT_RETIRE_SECTION 2
+#include "smarch_retire.inc"
+        }
+#else
 #include "smarch_retire.inc"
         lds_barrier();      // (not __syncthreads(): that would wait for the retire pass's global stores to be acknowledged, once per layer)
+#endif
 #endif
     }
 }
