@@ -61,6 +61,12 @@
 
 namespace nufft {
 
+#ifndef NUFFT_SMARCH_SPLIT_TAIL
+#define NUFFT_SMARCH_SPLIT_TAIL 0   // (see the main loop)
+#endif
+#ifndef NUFFT_SMARCH_AHEAD
+#define NUFFT_SMARCH_AHEAD 0        // 1: a wave prepares its first chunk of the next layer before the retire pass (round 6)
+#endif
 #ifndef NUFFT_SMARCH_DEFER
 #define NUFFT_SMARCH_DEFER 0        // 1: the retire pass's global stores issued behind its second barrier (experiment, round 6)
 #endif
@@ -325,6 +331,14 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
     typedef double HeldD2 __attribute__((ext_vector_type(2)));
     HeldD2 held[4];
 #endif
+    // what accum needs of a prepared chunk (its window values sit in the wave's strip)
+    struct ChunkState { unsigned long long okmask; uint32_t soff; unsigned long long lmask; int q0, s0, s1; T vmine; };
+    // Round 6: a wave prepares its FIRST chunk of the next layer (records requested a chunk into this layer; windows evaluated and staged in
+    // its strip) before the two barriers of the retire pass, while the slower waves finish — after the pass the atomics start at once
+    // instead of behind sixteen simultaneous window evaluations (the strip is the wave's own; the pass touches the window only).
+    constexpr bool AHEAD = NUFFT_SMARCH_AHEAD && !NUFFT_SMARCH_SPLIT_TAIL && NUFFT_SMARCH_ABL == 0;
+    bool have_carry = false;
+    ChunkState carry{};
     for (int li = 0; li < nli; ++li) {
         // ---- the runs of this layer (requested a layer ago): chunks per run, inclusive scan over the lanes ----
         const uint32_t p0_l = nx0, p1_l = nx1;
@@ -338,13 +352,14 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         const int wq = 4 * (li - HLO) - (M - 1);        // first plane of the layer's window (in owned-plane coordinates)
         const bool clipz = wq < 0 || wq + RZ > nq;      // planes of this window belong to other segments
 
-        auto lookup = [&](int item, uint32_t& p0, uint32_t& p1) __attribute__((always_inline)) {
-            const unsigned long long mk = __ballot((uint32_t)item < cum_l);
+        auto lookup_in = [&](int item, uint32_t cum, uint32_t r0, uint32_t r1, uint32_t& p0, uint32_t& p1) __attribute__((always_inline)) {
+            const unsigned long long mk = __ballot((uint32_t)item < cum);
             const int i = (int)__builtin_ctzll(mk);
-            const uint32_t before = i ? (uint32_t)__builtin_amdgcn_readlane((int)cum_l, i - 1) : 0u;
-            p0 = (uint32_t)__builtin_amdgcn_readlane((int)p0_l, i) + ((uint32_t)item - before) * PPW;
-            p1 = (uint32_t)__builtin_amdgcn_readlane((int)p1_l, i);
+            const uint32_t before = i ? (uint32_t)__builtin_amdgcn_readlane((int)cum, i - 1) : 0u;
+            p0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, i) + ((uint32_t)item - before) * PPW;
+            p1 = (uint32_t)__builtin_amdgcn_readlane((int)r1, i);
         };
+        auto lookup = [&](int item, uint32_t& p0, uint32_t& p1) __attribute__((always_inline)) { lookup_in(item, cum_l, p0_l, p1_l, p0, p1); };
         auto value_of = [&](const PointRec<T, 3>& r) __attribute__((always_inline)) -> T {
             T v = T(0);
             if (FAST || q < NC) {                       // (FAST: every lane of the group holds the point's value)
@@ -360,7 +375,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
         // one chunk of up to PPW points
         // (part, nparts: the chunks of a layer's last, incomplete round are shared by nparts waves each — every wave evaluates the windows
         // of the whole chunk, wave `part` adds the points gi with gi nparts / PPW == part)
-        auto chunk = [&](auto clip_c, const PointRec<T, 3>& rec, T vmine, bool have, int part, int nparts) __attribute__((always_inline)) {
+        // prep: the chunk's windows into the wave's strip, what the accumulation needs from its records into `st` (wq_: first plane of the
+        // window of the chunk's layer — this layer's, or the NEXT one's for the chunk a wave prepares ahead of the retire pass, see below)
+        auto prep = [&](auto clip_c, const PointRec<T, 3>& rec, T vmine, bool have, int wq_, ChunkState& st) __attribute__((always_inline)) {
             constexpr bool CLIPZ = decltype(clip_c)::value;
             int s[2];
             T X[3];
@@ -381,9 +398,10 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             const int c3 = cell_of(rec.r[2], g.Nover[2]);
             X[2] = rec.r[2] - T(c3);
             const int dz = c3 & 3;                      // slot of the first stencil plane
-            const int q0 = wq + dz;                     // its plane (owned-plane coordinates)
+            const int q0 = wq_ + dz;                    // its plane (owned-plane coordinates)
             if constexpr (CLIPZ) ok = ok && (q0 + L - 1 >= 0) && (q0 < nq);
             const unsigned long long okmask = __ballot(ok);
+            st.okmask = okmask;
             if (okmask == 0ull) return;                 // nothing of this chunk touches the column
             // the point's LDS offset: stencil start in x, y and the slot of its first plane
             const uint32_t soff = (uint32_t)((s[0] * NC + s[1] * RS + dz * PS) * 8);
@@ -404,6 +422,18 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             for (int sl = 0; sl < WE::NSLOT; ++sl)
                 if (we.has[sl]) strip[q + sl * GP::G] = wv[sl];
             wave_lds_fence();
+            st.soff = soff; st.lmask = lmask; st.q0 = q0; st.s0 = s[0]; st.s1 = s[1]; st.vmine = vmine;
+        };
+        // accum: the staged chunk's points into the window
+        auto accum = [&](auto clip_c, const ChunkState& st, int part, int nparts) __attribute__((always_inline)) {
+            constexpr bool CLIPZ = decltype(clip_c)::value;
+            const unsigned long long okmask = st.okmask;
+            if (okmask == 0ull) return;
+            const uint32_t soff = st.soff;
+            const unsigned long long lmask = st.lmask;
+            const int q0 = st.q0;
+            const int s[2] = {st.s0, st.s1};
+            const T vmine = st.vmine;
 #if NUFFT_SMARCH_ABL != 2
             auto do_point = [&](int gi, const T (&w1v)[NPASS], const T (&w2v)[NPASS], T w3a) __attribute__((always_inline)) {
                 const int src = gi * GP::G;             // first lane of the point's group
@@ -511,6 +541,11 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(soff), "v"(lmask));
 #endif
         };
+        auto chunk = [&](auto clip_c, const PointRec<T, 3>& rec, T vmine, bool have, int part, int nparts) __attribute__((always_inline)) {
+            ChunkState st;
+            prep(clip_c, rec, vmine, have, wq, st);
+            accum(clip_c, st, part, nparts);
+        };
 
         // ---- chunks wave, wave + NW, ... of this layer; the next chunk's records are requested before the current one is
         //      processed, its values right after.  (Tried, round 5: the first chunk of the NEXT layer requested before the two barriers of
@@ -540,11 +575,36 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             bool valid = item >= 0;
             PointRec<T, 3> rec{};
             T vcur = T(0);
-            if (valid) {
+            const bool carried = AHEAD && have_carry;           // (then item == wave is valid: the chunk was found in this layer's runs a layer ago)
+            if (valid && !carried) {
                 lookup(item, p0, p1);
                 rec = sorted[min(p0 + (uint32_t)grp, p1 - 1)];
                 vcur = value_of(rec);
             }
+            // the wave's first chunk of the NEXT layer: requested once this layer's first chunk is done (the next layer's runs, requested at the
+            // top of this layer, have arrived by then), prepared behind the last chunk
+            bool ahead_req = false, ahead_valid = false, ahead_have = false;
+            PointRec<T, 3> rec_a{};
+            T v_a = T(0);
+            auto request_ahead = [&]() __attribute__((always_inline)) {
+                ahead_req = true;
+                if (li + 1 >= nli) return;
+                uint32_t cum_n = (nx1 - nx0 + PPW - 1) / PPW;
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const uint32_t v = __shfl_up(cum_n, o, kWave);
+                    if (lane >= o) cum_n += v;
+                }
+                const int nchunks_n = __builtin_amdgcn_readlane((int)cum_n, kWave - 1);
+                if (wave < nchunks_n) {
+                    uint32_t a0, a1;
+                    lookup_in(wave, cum_n, nx0, nx1, a0, a1);
+                    rec_a = sorted[min(a0 + (uint32_t)grp, a1 - 1)];
+                    v_a = value_of(rec_a);
+                    ahead_have = a0 + (uint32_t)grp < a1;
+                    ahead_valid = true;
+                }
+            };
+            bool first = true;
             while (valid) {
                 it += NW;
                 int partn = 0, npartsn = 1;
@@ -556,14 +616,31 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
                     lookup(item, n0, n1);
                     recn = sorted[min(n0 + (uint32_t)grp, n1 - 1)];
                 }
-                const bool have = p0 + (uint32_t)grp < p1;
-                if (clipz) chunk(std::true_type{}, rec, vcur, have, part, nparts);
-                else chunk(std::false_type{}, rec, vcur, have, part, nparts);
+                if (AHEAD && first && carried) {
+                    if (clipz) accum(std::true_type{}, carry, part, nparts);
+                    else accum(std::false_type{}, carry, part, nparts);
+                } else {
+                    const bool have = p0 + (uint32_t)grp < p1;
+                    if (clipz) chunk(std::true_type{}, rec, vcur, have, part, nparts);
+                    else chunk(std::false_type{}, rec, vcur, have, part, nparts);
+                }
+                first = false;
                 part = partn; nparts = npartsn;
                 // (requesting the next values in the middle of the visits instead — half a chunk more slack — measured slower:
                 // 2.50 against 2.45 ms at C2; the value gather costs 0.1 ms in all, ablation 6)
                 if (validn) vcur = value_of(recn);
                 rec = recn; p0 = n0; p1 = n1; valid = validn;
+                if (AHEAD && !ahead_req) request_ahead();
+            }
+            if constexpr (AHEAD) {
+                if (!ahead_req) request_ahead();                // (a wave without a chunk in this layer)
+                have_carry = false;
+                if (ahead_valid) {
+                    const int wqn = wq + 4;
+                    if (wqn < 0 || wqn + RZ > nq) prep(std::true_type{}, rec_a, v_a, ahead_have, wqn, carry);
+                    else prep(std::false_type{}, rec_a, v_a, ahead_have, wqn, carry);
+                    have_carry = true;
+                }
             }
         }
         // the immediate-offset atomics are inline assembly: the compiler does not know that they are in flight
