@@ -64,6 +64,11 @@ namespace nufft {
 #ifndef NUFFT_SMARCH_SPLIT_TAIL
 #define NUFFT_SMARCH_SPLIT_TAIL 0   // (see the main loop)
 #endif
+#ifndef NUFFT_SMARCH_PRIO
+#define NUFFT_SMARCH_PRIO 3         // wave priority during the accumulation of a chunk (s_setprio; 0: none).  Round 6: the waves that feed the LDS atomic pipe go ahead of
+                                    // those that evaluate windows — C2 spread 1.97 -> 1.90 ms Direct(), 1.90 -> 1.87 polynomial, C4 5.84 -> 5.55, ComplexF64 m = 4 3.96 -> 3.79, the
+                                    // reference protocol's folded-normal sets 3.66 -> 3.34; levels 1 / 2 / 3 within 1 % of each other (scripts/r6_ae.sh)
+#endif
 #ifndef NUFFT_SMARCH_AHEAD
 #define NUFFT_SMARCH_AHEAD 0        // 1: a wave prepares its first chunk of the next layer before the retire pass (round 6)
 #endif
@@ -434,6 +439,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             const int q0 = st.q0;
             const int s[2] = {st.s0, st.s1};
             const T vmine = st.vmine;
+#if NUFFT_SMARCH_PRIO
+            __builtin_amdgcn_s_setprio(NUFFT_SMARCH_PRIO);      // (experiment, round 6: the waves that feed the LDS atomic pipe ahead of those that evaluate windows)
+#endif
 #if NUFFT_SMARCH_ABL != 2
             auto do_point = [&](int gi, const T (&w1v)[NPASS], const T (&w2v)[NPASS], T w3a) __attribute__((always_inline)) {
                 const int src = gi * GP::G;             // first lane of the point's group
@@ -539,6 +547,9 @@ __global__ __launch_bounds__(1024) void spread_march_kernel(TileArgs<T> a, March
             }
 #else
             asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(soff), "v"(lmask));
+#endif
+#if NUFFT_SMARCH_PRIO
+            __builtin_amdgcn_s_setprio(0);
 #endif
         };
         auto chunk = [&](auto clip_c, const PointRec<T, 3>& rec, T vmine, bool have, int part, int nparts) __attribute__((always_inline)) {
