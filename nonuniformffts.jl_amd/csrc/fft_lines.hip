@@ -182,6 +182,16 @@ __device__ __forceinline__ void fft_line(typename Cplx2<T>::type* line, const ty
     fft_stages<T, N, N, 1, SIGN, TWS>(line, tw, lane);
 }
 
+#ifndef NUFFT_FFT_PRIO
+#define NUFFT_FFT_PRIO 0        // 1..3: the waves of a pass that are loading or storing go ahead of those that transform (s_setprio; experiment, round 6)
+#endif
+#if NUFFT_FFT_PRIO
+#define NUFFT_FFT_PRIO_MEM() __builtin_amdgcn_s_setprio(NUFFT_FFT_PRIO)
+#define NUFFT_FFT_PRIO_ALU() __builtin_amdgcn_s_setprio(0)
+#else
+#define NUFFT_FFT_PRIO_MEM() do { } while (0)
+#define NUFFT_FFT_PRIO_ALU() do { } while (0)
+#endif
 // FWD: full input (N along j), pruned output (nk along k').  BWD: pruned input, full output.
 // MULT: a real multiplier array (uniform callback menu) is applied on the pruned side.
 template <typename T, int N, bool FWD, int TA, bool MULT>
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
 
     const C* twg = static_cast<const C*>(a.twiddle);
     for (int i = tid; i < N; i += NT) tw[i] = twg[i];
+    NUFFT_FFT_PRIO_MEM();
 
     if (FWD) {
         // ceil(N / 64) loads per thread (rows tid / TA + 64 it of column tid % TA), issued eight at a time before the first is waited for: as a
@@ -285,8 +296,10 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     }
     __syncthreads();
 
+    NUFFT_FFT_PRIO_ALU();
     fft_line<T, N, FWD ? -1 : 1>(lines + wave * LINE, tw, lane);
     __syncthreads();
+    NUFFT_FFT_PRIO_MEM();
 
     if (FWD) {
         for (int e = tid; e < TA * a.nk; e += NT) {
@@ -446,12 +459,15 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
     C* line = lines + wave * LINE;
     if (FWD) {
         const C* zin = reinterpret_cast<const C*>(static_cast<const T*>(a.in) + line_id * N);
+        NUFFT_FFT_PRIO_MEM();
         load_line_wide(line, zin, M, lane);
         wave_lds_fence();
         if constexpr (HALO) {
             if (*a.hflag != 0u) add_halo_to_line<T, C, 1>(a.halo, a.hl, a.ny, line, line_id, lane, N);
         }
+        NUFFT_FFT_PRIO_ALU();
         fft_line<T, M, -1, 2>(line, tw, lane);
+        NUFFT_FFT_PRIO_MEM();
         C* xout = static_cast<C*>(a.out) + line_id * a.row;
         for (int k = lane; k < a.k1; k += kWave) {
             const C zk = line[lpad(k == M ? 0 : k)];
@@ -470,6 +486,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         // The partner of k is M - k: Z[M-k] = conj(E'[k]) + i conj(O'[k]), so one lane builds both from two
         // global loads and no staging copy of X is needed in LDS (X is zero beyond the kept modes).
         const C* xin = static_cast<const C*>(a.in) + line_id * a.row;
+        NUFFT_FFT_PRIO_MEM();
         for (int k = lane; k <= M / 2; k += kWave) {
             C xk, xm;
             xk.x = xk.y = xm.x = xm.y = T(0);
@@ -493,7 +510,9 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
             }
         }
         wave_lds_fence();
+        NUFFT_FFT_PRIO_ALU();
         fft_line<T, M, 1, 2>(line, tw, lane);
+        NUFFT_FFT_PRIO_MEM();
         C* zout = reinterpret_cast<C*>(static_cast<T*>(a.out) + line_id * N);
         store_line_wide(zout, line, M, lane);
     }
