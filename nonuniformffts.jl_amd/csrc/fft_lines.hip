@@ -183,7 +183,8 @@ __device__ __forceinline__ void fft_line(typename Cplx2<T>::type* line, const ty
 }
 
 #ifndef NUFFT_FFT_PRIO
-#define NUFFT_FFT_PRIO 0        // 1..3: the waves of a pass that are loading or storing go ahead of those that transform (s_setprio; experiment, round 6)
+#define NUFFT_FFT_PRIO 3        // BACKWARD strided passes: the waves that load or store go ahead of those that transform (s_setprio; 0: none).  Round 6, scripts/r6_ah.sh:
+                                // deconvolve + pad + dimensions 3, 2 of type 2 at C2 0.38 -> 0.32 ms, ComplexF64 0.71 -> 0.56, C4 1.12 -> 0.98; the forward passes lose 1 % with it
 #endif
 #if NUFFT_FFT_PRIO
 #define NUFFT_FFT_PRIO_MEM() __builtin_amdgcn_s_setprio(NUFFT_FFT_PRIO)
@@ -191,6 +192,16 @@ __device__ __forceinline__ void fft_line(typename Cplx2<T>::type* line, const ty
 #else
 #define NUFFT_FFT_PRIO_MEM() do { } while (0)
 #define NUFFT_FFT_PRIO_ALU() do { } while (0)
+#endif
+#ifndef NUFFT_FFT_PRIO_LINES
+#define NUFFT_FFT_PRIO_LINES 3  // the same in the contiguous-line kernel of dimension 1 of real plans, both directions: C2 r2c pass + halo 0.690 -> 0.678 ms, c2r 0.355 -> 0.342
+#endif
+#if NUFFT_FFT_PRIO_LINES
+#define NUFFT_FFT_PRIOL_MEM() __builtin_amdgcn_s_setprio(NUFFT_FFT_PRIO_LINES)
+#define NUFFT_FFT_PRIOL_ALU() __builtin_amdgcn_s_setprio(0)
+#else
+#define NUFFT_FFT_PRIOL_MEM() do { } while (0)
+#define NUFFT_FFT_PRIOL_ALU() do { } while (0)
 #endif
 // FWD: full input (N along j), pruned output (nk along k').  BWD: pruned input, full output.
 // MULT: a real multiplier array (uniform callback menu) is applied on the pruned side.
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
 
     const C* twg = static_cast<const C*>(a.twiddle);
     for (int i = tid; i < N; i += NT) tw[i] = twg[i];
-    NUFFT_FFT_PRIO_MEM();
+    if constexpr (!FWD) NUFFT_FFT_PRIO_MEM();
 
     if (FWD) {
         // ceil(N / 64) loads per thread (rows tid / TA + 64 it of column tid % TA), issued eight at a time before the first is waited for: as a
@@ -296,10 +307,10 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     }
     __syncthreads();
 
-    NUFFT_FFT_PRIO_ALU();
+    if constexpr (!FWD) NUFFT_FFT_PRIO_ALU();
     fft_line<T, N, FWD ? -1 : 1>(lines + wave * LINE, tw, lane);
     __syncthreads();
-    NUFFT_FFT_PRIO_MEM();
+    if constexpr (!FWD) NUFFT_FFT_PRIO_MEM();
 
     if (FWD) {
         for (int e = tid; e < TA * a.nk; e += NT) {
@@ -459,15 +470,15 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
     C* line = lines + wave * LINE;
     if (FWD) {
         const C* zin = reinterpret_cast<const C*>(static_cast<const T*>(a.in) + line_id * N);
-        NUFFT_FFT_PRIO_MEM();
+        NUFFT_FFT_PRIOL_MEM();
         load_line_wide(line, zin, M, lane);
         wave_lds_fence();
         if constexpr (HALO) {
             if (*a.hflag != 0u) add_halo_to_line<T, C, 1>(a.halo, a.hl, a.ny, line, line_id, lane, N);
         }
-        NUFFT_FFT_PRIO_ALU();
+        NUFFT_FFT_PRIOL_ALU();
         fft_line<T, M, -1, 2>(line, tw, lane);
-        NUFFT_FFT_PRIO_MEM();
+        NUFFT_FFT_PRIOL_MEM();
         C* xout = static_cast<C*>(a.out) + line_id * a.row;
         for (int k = lane; k < a.k1; k += kWave) {
             const C zk = line[lpad(k == M ? 0 : k)];
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
         // The partner of k is M - k: Z[M-k] = conj(E'[k]) + i conj(O'[k]), so one lane builds both from two
         // global loads and no staging copy of X is needed in LDS (X is zero beyond the kept modes).
         const C* xin = static_cast<const C*>(a.in) + line_id * a.row;
-        NUFFT_FFT_PRIO_MEM();
+        NUFFT_FFT_PRIOL_MEM();
         for (int k = lane; k <= M / 2; k += kWave) {
             C xk, xm;
             xk.x = xk.y = xm.x = xm.y = T(0);
@@ -510,9 +521,9 @@ __global__ __launch_bounds__(TL * kWave) void real_lines_kernel(RealLineArgs a) 
             }
         }
         wave_lds_fence();
-        NUFFT_FFT_PRIO_ALU();
+        NUFFT_FFT_PRIOL_ALU();
         fft_line<T, M, 1, 2>(line, tw, lane);
-        NUFFT_FFT_PRIO_MEM();
+        NUFFT_FFT_PRIOL_MEM();
         C* zout = reinterpret_cast<C*>(static_cast<T*>(a.out) + line_id * N);
         store_line_wide(zout, line, M, lane);
     }
