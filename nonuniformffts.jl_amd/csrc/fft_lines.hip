@@ -193,6 +193,17 @@ __device__ __forceinline__ void fft_line(typename Cplx2<T>::type* line, const ty
 #define NUFFT_FFT_PRIO_MEM() do { } while (0)
 #define NUFFT_FFT_PRIO_ALU() do { } while (0)
 #endif
+#ifndef NUFFT_FFT_PRIO_CLINES
+#define NUFFT_FFT_PRIO_CLINES 3 // ... and of ComplexF32 plans, backward (cplx_lines_kernel): C3 7.0 -> 6.5 ms for the backward FFT stage (the last pass 3.33 -> 2.90); the forward pass
+                                // and ComplexF64 lose 1 % with it and stay without (scripts/r6_ak.sh)
+#endif
+#if NUFFT_FFT_PRIO_CLINES
+#define NUFFT_FFT_PRIOC_MEM() __builtin_amdgcn_s_setprio(NUFFT_FFT_PRIO_CLINES)
+#define NUFFT_FFT_PRIOC_ALU() __builtin_amdgcn_s_setprio(0)
+#else
+#define NUFFT_FFT_PRIOC_MEM() do { } while (0)
+#define NUFFT_FFT_PRIOC_ALU() do { } while (0)
+#endif
 #ifndef NUFFT_FFT_PRIO_LINES
 #define NUFFT_FFT_PRIO_LINES 3  // the same in the contiguous-line kernel of dimension 1 of real plans, both directions: C2 r2c pass + halo 0.690 -> 0.678 ms, c2r 0.355 -> 0.342
 #endif
@@ -587,6 +598,7 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
             for (int k = lane; k < a.k1; k += kWave) xout[k] = line[lpad(a.map[k])];
         }
     } else {
+        if constexpr (sizeof(T) == 4) NUFFT_FFT_PRIOC_MEM();
         C z; z.x = T(0); z.y = T(0);
         for (int n = lane; n < N; n += kWave) line[lpad(n)] = z;
         wave_lds_fence();
@@ -604,7 +616,9 @@ __global__ __launch_bounds__(TL * kWave) void cplx_lines_kernel(CplxLineArgs a) 
             for (int k = lane; k < a.k1; k += kWave) line[lpad(a.map[k])] = xin[k];
         }
         wave_lds_fence();
+        if constexpr (sizeof(T) == 4) NUFFT_FFT_PRIOC_ALU();
         fft_line<T, N, 1>(line, tw, lane);
+        if constexpr (sizeof(T) == 4) NUFFT_FFT_PRIOC_MEM();
         C* zout = static_cast<C*>(a.out) + line_id * N;
         store_line_wide(zout, line, N, lane);
     }
