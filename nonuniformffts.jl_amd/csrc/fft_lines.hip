@@ -265,6 +265,9 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     const C* twg = static_cast<const C*>(a.twiddle);
     for (int i = tid; i < N; i += NT) tw[i] = twg[i];
     if constexpr (!FWD) NUFFT_FFT_PRIO_MEM();
+#if defined(NUFFT_FFT_PRIO_FWD_LOAD)
+    if constexpr (FWD) __builtin_amdgcn_s_setprio(NUFFT_FFT_PRIO_FWD_LOAD);
+#endif
 
     if (FWD) {
         // ceil(N / 64) loads per thread (rows tid / TA + 64 it of column tid % TA), issued eight at a time before the first is waited for: as a
@@ -318,10 +321,19 @@ __global__ __launch_bounds__(TA * kWave) void fft_lines_kernel(FftLineArgs a) {
     }
     __syncthreads();
 
+#if defined(NUFFT_FFT_PRIO_FWD_LOAD)
+    if constexpr (FWD) __builtin_amdgcn_s_setprio(0);
+#endif
     if constexpr (!FWD) NUFFT_FFT_PRIO_ALU();
     fft_line<T, N, FWD ? -1 : 1>(lines + wave * LINE, tw, lane);
     __syncthreads();
     if constexpr (!FWD) NUFFT_FFT_PRIO_MEM();
+#if defined(NUFFT_FFT_PRIO_FWD_STORE)       // (experiment: forward passes, the stores only)
+    if constexpr (FWD) __builtin_amdgcn_s_setprio(NUFFT_FFT_PRIO_FWD_STORE);
+#endif
+#if defined(NUFFT_FFT_PRIO_FWD_LOAD)        // (experiment: forward passes, the loads only)
+    if constexpr (FWD) __builtin_amdgcn_s_setprio(0);
+#endif
 
     if (FWD) {
         for (int e = tid; e < TA * a.nk; e += NT) {
