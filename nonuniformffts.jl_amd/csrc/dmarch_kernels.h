@@ -26,6 +26,9 @@
 // CONSECUTIVE cells of a window row on planes z = lane mod 16 — with the plane stride congruent to 2 modulo the 32 double-word banks
 // no two lanes of a half-wave share a bank.
 #pragma once
+#ifndef NUFFT_DMARCH_PRIO
+#define NUFFT_DMARCH_PRIO 0        // 1..3: wave priority while a wave issues a batch's matrix instructions / flushes a bin (experiment, round 6)
+#endif
 
 #include "smarch_kernels.h"
 
@@ -250,6 +253,9 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
         bool pending = false;                            // `cur` holds a batch whose matrix instructions have not been issued
         int cur_jb = 0;                                  // ... of this bin of the wave
         auto issue = [&](const Ops& o) __attribute__((always_inline)) {
+#if NUFFT_DMARCH_PRIO
+            __builtin_amdgcn_s_setprio(NUFFT_DMARCH_PRIO);      // (experiment, round 6: the wave that issues matrix instructions / atomics first)
+#endif
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #if NUFFT_DMARCH_ABL & 2
@@ -258,8 +264,14 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ap[t], o.b, acc[t], 0, 0, 0);
 #endif
             }
+#if NUFFT_DMARCH_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         auto flush = [&](int jb) __attribute__((always_inline)) {
+#if NUFFT_DMARCH_PRIO
+            __builtin_amdgcn_s_setprio(NUFFT_DMARCH_PRIO);
+#endif
             // the bin is complete: its footprint onto the window, 4 NT atomics (lanes: plane z = lane mod 16, four consecutive face positions)
             const int b = wave + NW * jb, bxi = b % nbx, byi = b / nbx;
             // footprint origin of the bin in window coordinates: cell 4 b - (M - 1) relative to the window's first cell; ... on this lane's plane
@@ -287,6 +299,9 @@ __global__ __launch_bounds__((DMarchCfg<T, M>::THREADS)) void spread_march_dense
                 }
                 acc[t] = DMv4{0.0, 0.0, 0.0, 0.0};
             }
+#if NUFFT_DMARCH_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         while (ok0) {
             val1 = load_val(rec1);
